@@ -1,0 +1,187 @@
+"""ctypes wrapper around oracle/liboracle.so — the CPU ORACLE.
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never from the product package (`vision.*` / libvp.so).  See the header of
+vp_oracle.c for what it restates and why parity is "unpinned" (the reference has no tests
+and cv2 is absent).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ERODE, DILATE, OPEN, CLOSE, GRADIENT = range(5)
+MORPH_RECT, MORPH_CROSS, MORPH_ELLIPSE = 0, 1, 2
+MODE_LAB, MODE_HSV, MODE_GRAY = 0, 1, 2
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "vp_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_ccl_u8.restype = C.c_int
+        _LIB.orc_chain_u8.restype = C.c_int
+        _LIB.orc_morph_u8.restype = C.c_int
+        _LIB.orc_structuring_element.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def _c(a, dtype=np.uint8):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def tables(variant=None):
+    gamma = np.zeros(256, np.uint16)
+    cbrt = np.zeros(3072, np.uint16)
+    sdiv = np.zeros(256, np.int32)
+    hdiv = np.zeros(256, np.int32)
+    labc = np.zeros(9, np.int32)
+    lib().orc_get_tables(_p(gamma, C.c_void_p), _p(cbrt, C.c_void_p), _p(sdiv, _i32p), _p(hdiv, _i32p), _p(labc, _i32p))
+    if variant is not None:
+        lib().orc_build_lab_tables(C.c_int(variant), _p(gamma, C.c_void_p), _p(cbrt, C.c_void_p))
+    return gamma, cbrt, sdiv, hdiv, labc
+
+
+def _cvt3(fn, bgr):
+    bgr = _c(bgr)
+    h, w, _ = bgr.shape
+    out = np.empty_like(bgr)
+    fn(_p(bgr, _u8p), C.c_size_t(w * 3), w, h, _p(out, _u8p), C.c_size_t(w * 3))
+    return out
+
+
+def bgr2lab(bgr):
+    return _cvt3(lib().orc_bgr2lab_u8, bgr)
+
+
+def bgr2hsv(bgr):
+    return _cvt3(lib().orc_bgr2hsv_u8, bgr)
+
+
+def bgr2gray(bgr):
+    bgr = _c(bgr)
+    h, w, _ = bgr.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray_u8(_p(bgr, _u8p), C.c_size_t(w * 3), w, h, _p(out, _u8p), C.c_size_t(w))
+    return out
+
+
+def gray2bgr(gray):
+    gray = _c(gray)
+    h, w = gray.shape
+    out = np.empty((h, w, 3), np.uint8)
+    lib().orc_gray2bgr_u8(_p(gray, _u8p), C.c_size_t(w), w, h, _p(out, _u8p), C.c_size_t(w * 3))
+    return out
+
+
+def split3(img):
+    img = _c(img)
+    h, w, _ = img.shape
+    ps = [np.empty((h, w), np.uint8) for _ in range(3)]
+    lib().orc_split3_u8(_p(img, _u8p), C.c_size_t(w * 3), w, h, *[_p(p, _u8p) for p in ps])
+    return tuple(ps)
+
+
+def inrange(img, lo, hi):
+    if img.dtype == np.float32:
+        img = _c(img, np.float32)
+        h, w = img.shape
+        out = np.empty((h, w), np.uint8)
+        lib().orc_inrange_f32(_p(img, _f32p), C.c_size_t(w * 4), w, h, C.c_float(lo), C.c_float(hi), _p(out, _u8p), C.c_size_t(w))
+        return out
+    img = _c(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    lo = np.ascontiguousarray(np.broadcast_to(np.asarray(lo, np.int64), (cn,)).astype(np.int32))
+    hi = np.ascontiguousarray(np.broadcast_to(np.asarray(hi, np.int64), (cn,)).astype(np.int32))
+    out = np.empty((h, w), np.uint8)
+    lib().orc_inrange_u8(_p(img, _u8p), C.c_size_t(w * cn), w, h, cn, _p(lo, _i32p), _p(hi, _i32p), _p(out, _u8p), C.c_size_t(w))
+    return out
+
+
+def color_distance(planes, color, wts, skipmask=0):
+    ps = [_c(p) for p in planes]
+    h, w = ps[0].shape
+    color = np.asarray(color, np.float32)
+    wts = np.asarray(wts, np.float32)
+    d2 = np.empty((h, w), np.float32)
+    sq = np.empty((h, w), np.uint8)
+    lib().orc_color_distance_u8(_p(ps[0], _u8p), _p(ps[1], _u8p), _p(ps[2], _u8p), w, h, _p(color, _f32p), _p(wts, _f32p),
+                                int(skipmask), _p(d2, _f32p), _p(sq, _u8p))
+    return d2, sq
+
+
+def structuring_element(shape, kw, kh):
+    out = np.empty((kh, kw), np.uint8)
+    if lib().orc_structuring_element(shape, kw, kh, _p(out, _u8p)) != 0:
+        raise ValueError("bad structuring element size")
+    return out
+
+
+def morph(op, img, kernel, iterations=1, anchor=(-1, -1), fast=False):
+    img = _c(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    out = np.empty_like(img)
+    if kernel is None:
+        kp, kw, kh = None, 0, 0
+    else:
+        kernel = _c(kernel)
+        kh, kw = kernel.shape
+        kp = _p(kernel, _u8p)
+    rc = lib().orc_morph_u8(op, _p(img, _u8p), w, h, cn, kp, kw, kh, anchor[0], anchor[1], iterations, _p(out, _u8p), int(fast))
+    assert rc == 0
+    return out
+
+
+def ccl(mask, block=2, max_k=None, want_labels=True):
+    mask = _c(mask)
+    h, w = mask.shape
+    if max_k is None:
+        max_k = (h * w + 1) // 1 + 1
+        max_k = min(max_k, ((h + 1) // 2) * ((w + 1) // 2) + 1)
+    labels = np.empty((h, w), np.int32) if want_labels else None
+    stats = np.empty((max_k, 5), np.int32)
+    cent = np.empty((max_k, 2), np.float64)
+    n = lib().orc_ccl_u8(_p(mask, _u8p), C.c_size_t(w), w, h, block, _p(labels, _i32p), _p(stats, _i32p), _p(cent, _f64p), max_k)
+    k = min(n, max_k)
+    return n, labels, stats[:k].copy(), cent[:k].copy()
+
+
+def chain(bgr, mode, lo, hi, ops, kw=5, kh=5, block=2, max_k=4096, want_labels=True):
+    """colour -> inRange -> rect morphology ops -> CCL (+stats).  Returns dict."""
+    bgr = _c(bgr)
+    h, w, _ = bgr.shape
+    lo = np.ascontiguousarray(np.asarray(lo, np.int32))
+    hi = np.ascontiguousarray(np.asarray(hi, np.int32))
+    ops = np.ascontiguousarray(np.asarray(ops, np.int32))
+    th = np.empty((h, w), np.uint8)
+    cl = np.empty((h, w), np.uint8)
+    labels = np.empty((h, w), np.int32) if (want_labels and block) else None
+    stats = np.empty((max_k, 5), np.int32)
+    cent = np.empty((max_k, 2), np.float64)
+    n = lib().orc_chain_u8(_p(bgr, _u8p), w, h, mode, _p(lo, _i32p), _p(hi, _i32p), _p(ops, _i32p), len(ops), kw, kh, block,
+                           _p(th, _u8p), _p(cl, _u8p), _p(labels, _i32p), _p(stats, _i32p), _p(cent, _f64p), max_k)
+    k = min(n, max_k)
+    return dict(threshed=th, cleaned=cl, labels=labels, nlabels=n, stats=stats[:k].copy(), centroids=cent[:k].copy())
