@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the fused colour -> inRange -> OPEN/CLOSE 5x5 -> CCL chain at 1080p.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  A "step" is one vp_chain_run over one batch of
+synthetic 1080p frames already resident in HBM (BASELINE.json configs[1]: preprocessor+red_buoy
+chain, S1 frames, LAB-a in [150,255], OPEN then CLOSE with a 5x5 rect, 8-connected CCL + stats).
+Frames are independent, so ranks shard them with no data-path collective ("weak" scaling: every
+rank processes its own batch); torch.distributed is used only for the barrier and the max over
+ranks of the timed region.
+
+Prints ONE JSON line on rank 0: metric / value / ... plus
+  roofline:     dominant kernel's algorithmic bytes per launch / its HIP-event duration vs 8 TB/s
+  cpu_baseline: the CPU oracle (scalar C port, 1 thread) timed on a bounded sample of the same frames
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "cuauv-vision-pipeline_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+W, H = 1920, 1080
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per pixel of each kernel
+KERNEL_BYTES_PER_PX = {
+    "k_color_thresh": 3 + 1 + 1.0 / 8,      # read BGR, write 0/255 mask + bit-packed mask
+    "k_morph_bits": 1.0 / 8 + 1 + 1.0 / 8,  # read bits, write cleaned mask + cleaned bits
+    "k_ccl_write": 1.0 / 8 + 4,             # read bits, write int32 labels
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="1080p frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-labels", type=int, default=256)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    n_gpus = max(world, 1)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libvp has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import frames as F
+    from vision import _vp
+    ctx = _vp.Context(local_rank)
+    L = _vp.lib()
+
+    # ---- synthetic input, resident in HBM before the timed region -------------------------------
+    B = args.batch
+    distinct = [F.s1_buoy(rank * 1000 + i, W, H) for i in range(min(args.distinct, B))]
+    host = np.stack([distinct[i % len(distinct)] for i in range(B)])
+    d_bgr = torch.from_numpy(host).cuda()
+    d_thr = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+    d_cln = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+    d_lab = torch.empty((B, H, W), dtype=torch.int32, device="cuda")
+    d_stats = torch.zeros((B, args.max_labels, 5), dtype=torch.int32, device="cuda")
+    d_cent = torch.zeros((B, args.max_labels, 2), dtype=torch.float64, device="cuda")
+    d_nl = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    morph = [(_vp.MORPH_OPEN, 5, 5), (_vp.MORPH_CLOSE, 5, 5)]
+    desc = _vp.make_chain_desc(W, H, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), morph, ccl=1,
+                               numbering=_vp.CCL_BLOCK2X2, max_labels=args.max_labels)
+    bufs = _vp.ChainBuffers()
+    bufs.bgr, bufs.threshed, bufs.cleaned = d_bgr.data_ptr(), d_thr.data_ptr(), d_cln.data_ptr()
+    bufs.labels, bufs.stats, bufs.centroids, bufs.nlabels = d_lab.data_ptr(), d_stats.data_ptr(), d_cent.data_ptr(), d_nl.data_ptr()
+    alg_bytes_step = int(L.vp_chain_algorithmic_bytes(C.byref(desc), C.byref(bufs), B))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.chain_run(desc, bufs, B)
+    ctx.synchronize()
+
+    # ---- timed region: exactly K steps ------------------------------------------------------------
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.chain_run(desc, bufs, B)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel attribution with HIP events on the launch stream (same K steps again) ----------
+    ctx.profile_begin(args.steps * 16)
+    for _ in range(args.steps):
+        ctx.chain_run(desc, bufs, B)
+    prof = ctx.profile_end()
+    n_labels_seen = d_nl.cpu().numpy()
+
+    fps = n_gpus * B * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    roof = None
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        kernels[name] = {"avg_us": 1e3 * ms / cnt, "launches_per_step": cnt / args.steps}
+    if prof:
+        dom = max((k for k in prof if k in KERNEL_BYTES_PER_PX), key=lambda k: prof[k][0] / prof[k][1])
+        avg_s = 1e-3 * prof[dom][0] / prof[dom][1]
+        kb = KERNEL_BYTES_PER_PX[dom] * W * H * B
+        achieved = kb / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(kb), "avg_launch_us": round(1e6 * avg_s, 2),
+                "chain_achieved_GBps": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9, 1),
+                "chain_frac": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.lib()
+        done, t_start = 0, time.perf_counter()
+        while True:
+            f = distinct[done % len(distinct)]
+            orc.chain(f, orc.MODE_LAB, (0, 150, 0), (255, 255, 255), [orc.OPEN, orc.CLOSE], 5, 5, 2, args.max_labels)
+            done += 1
+            if time.perf_counter() - t_start >= args.cpu_seconds:
+                break
+        dt = time.perf_counter() - t_start
+        cpu = {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{done} S1 1080p frames through oracle/vp_oracle.c orc_chain_u8 (scalar C, 1 thread, {dt:.1f} s); "
+                         f"host has {os.cpu_count()} cores; cv2 absent so the reference's own cv2 path cannot be timed"}
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec for color->threshold->morph->CCL at 1080p",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: preprocessor+red_buoy fused chain, S1 synthetic 1080p frames resident in HBM: "
+                                   "BGR->LAB(a) inRange[150,255] -> OPEN 5x5 -> CLOSE 5x5 -> 8-conn CCL + stats",
+                       "width": W, "height": H, "frames_per_step_per_gpu": B, "sharding": "independent frames per rank, no collective",
+                       "outputs": "threshold mask u8, cleaned mask u8, labels i32, stats/centroids", "max_labels": args.max_labels,
+                       "labels_per_frame_seen": [int(n_labels_seen.min()), int(n_labels_seen.max())]},
+            "algorithmic_bytes_per_frame": alg_bytes_step // B,
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Builds the native libraries of this package in-tree (hipcc cross-compiles gfx950 without a GPU).
+
+  lib/libvp.so   HIP kernels + C ABI of include/vp.h (the hot path)
+  lib/libcamera_message_framework.so   shared-memory seqlock IPC (C++, no GPU)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+VP_SOURCES = ["vp_api.hip", "vp_color.hip", "vp_morph.hip", "vp_ccl.hip", "vp_tables.cpp"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_libvp(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "libvp.so")
+    srcs = [os.path.join(CSRC, s) for s in VP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "vp_internal.h"), os.path.join(HERE, "..", "include", "vp.h")]
+    if not force and not _stale(out, deps):
+        return out
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip"] + srcs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_libcmf(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "libcamera_message_framework.so")
+    src = os.path.join(CSRC, "cmf.cpp")
+    if not os.path.exists(src):
+        return None
+    deps = [src, os.path.join(HERE, "..", "include", "camera_message_framework_c.h")]
+    if not force and not _stale(out, deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", src, "-o", out, "-lpthread", "-lrt"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    return [build_libvp(force, verbose), build_libcmf(force, verbose)]
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

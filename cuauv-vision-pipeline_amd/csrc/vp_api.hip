@@ -1,0 +1,740 @@
+// C ABI of libvp.so (see include/vp.h): context, workspace, per-operator host entry points and the
+// batched device-resident chain.  No CPU arithmetic path exists here: every operator stages its
+// operands into HBM and launches the HIP kernels of vp_color / vp_morph / vp_ccl.
+#include "vp_internal.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+static char g_err[256] = "";
+
+int vp_fail(vp_ctx* ctx, int code, const char* what, hipError_t e)
+{
+    char* dst = ctx ? ctx->err : g_err;
+    if (e != hipSuccess) snprintf(dst, 256, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(dst, 256, "%s", what);
+    if (ctx) snprintf(g_err, 256, "%s", dst);
+    return code;
+}
+
+extern "C" {
+
+int vp_version(void) { return 100; }
+
+const char* vp_strerror(int code)
+{
+    switch (code) {
+        case VP_OK: return "ok";
+        case VP_ERR_INVALID: return "invalid argument";
+        case VP_ERR_HIP: return "HIP runtime error";
+        case VP_ERR_NOMEM: return "out of memory";
+        case VP_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown error";
+    }
+}
+
+const char* vp_last_error(const vp_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int vp_get_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* hdiv180, int32_t* lab_coeffs)
+{
+    vp_host_tables(gamma, cbrt_tab, sdiv, hdiv180, lab_coeffs);
+    return VP_OK;
+}
+
+vp_ctx* vp_create(int device)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { vp_fail(nullptr, VP_ERR_HIP, "no HIP device (libvp has no CPU path)", e); return nullptr; }
+    if (device < 0 || device >= ndev) { vp_fail(nullptr, VP_ERR_INVALID, "device index out of range"); return nullptr; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { vp_fail(nullptr, VP_ERR_HIP, "hipSetDevice", e); return nullptr; }
+    vp_ctx* ctx = new (std::nothrow) vp_ctx();
+    if (!ctx) return nullptr;
+    memset(ctx, 0, sizeof *ctx);
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { vp_fail(nullptr, VP_ERR_HIP, "hipGetDeviceProperties", e); delete ctx; return nullptr; }
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) { vp_fail(nullptr, VP_ERR_HIP, "hipStreamCreate", e); delete ctx; return nullptr; }
+    ctx->stream = ctx->own_stream;
+    hipEventCreate(&ctx->ev0);
+    hipEventCreate(&ctx->ev1);
+    // tables: gamma u16[256] | cbrt u16[2048] | sdiv i32[256] | hdiv i32[256]
+    std::vector<uint16_t> gamma(256), cbrt(3072);
+    std::vector<int32_t> sdiv(256), hdiv(256);
+    int32_t labC[9];
+    vp_host_tables(gamma.data(), cbrt.data(), sdiv.data(), hdiv.data(), labC);
+    static const int32_t expectC[9] = {1777, 1541, 778, 871, 2929, 296, 73, 448, 3575};
+    if (memcmp(labC, expectC, sizeof labC) != 0) { vp_fail(nullptr, VP_ERR_INVALID, "Lab coefficient table mismatch"); delete ctx; return nullptr; }
+    const size_t bytes = 512 + 4096 + 1024 + 1024;
+    if ((e = hipMalloc(&ctx->d_tables, bytes)) != hipSuccess) { vp_fail(nullptr, VP_ERR_NOMEM, "hipMalloc tables", e); delete ctx; return nullptr; }
+    uint8_t* base = (uint8_t*)ctx->d_tables;
+    hipMemcpy(base, gamma.data(), 512, hipMemcpyHostToDevice);
+    hipMemcpy(base + 512, cbrt.data(), 4096, hipMemcpyHostToDevice);
+    hipMemcpy(base + 512 + 4096, sdiv.data(), 1024, hipMemcpyHostToDevice);
+    e = hipMemcpy(base + 512 + 4096 + 1024, hdiv.data(), 1024, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { vp_fail(nullptr, VP_ERR_HIP, "table upload", e); hipFree(ctx->d_tables); delete ctx; return nullptr; }
+    ctx->tab.gamma = (const uint16_t*)base;
+    ctx->tab.cbrt = (const uint16_t*)(base + 512);
+    ctx->tab.sdiv = (const int32_t*)(base + 512 + 4096);
+    ctx->tab.hdiv = (const int32_t*)(base + 512 + 4096 + 1024);
+    return ctx;
+}
+
+int vp_destroy(vp_ctx* ctx)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->d_tables) hipFree(ctx->d_tables);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return VP_OK;
+}
+
+int vp_set_stream(vp_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return VP_OK;
+}
+void* vp_get_stream(vp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int vp_synchronize(vp_ctx* ctx)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VP_OK;
+}
+
+int vp_timer_start(vp_ctx* ctx)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return VP_OK;
+}
+int vp_timer_stop(vp_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    VP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    VP_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VP_OK;
+}
+
+int vp_profile_begin(vp_ctx* ctx, int max_records)
+{
+    if (!ctx || max_records <= 0) return VP_ERR_INVALID;
+    vp_prof& P = ctx->prof;
+    if (P.cap < max_records) {
+        for (int i = 0; i < 2 * P.cap; i++) (void)hipEventDestroy(P.ev[i]);
+        free(P.ev);
+        free(P.ids);
+        P.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * max_records);
+        P.ids = (int*)malloc(sizeof(int) * max_records);
+        if (!P.ev || !P.ids) { P.cap = 0; return vp_fail(ctx, VP_ERR_NOMEM, "profile records"); }
+        for (int i = 0; i < 2 * max_records; i++) VP_HIP(ctx, hipEventCreate(&P.ev[i]));
+        P.cap = max_records;
+    }
+    P.used = 0;
+    P.on = true;
+    return VP_OK;
+}
+
+int vp_profile_end(vp_ctx* ctx, double* total_ms, int32_t* launches)
+{
+    if (!ctx || !total_ms || !launches) return VP_ERR_INVALID;
+    vp_prof& P = ctx->prof;
+    P.on = false;
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < VP_PROF_KERNELS; k++) { total_ms[k] = 0; launches[k] = 0; }
+    for (int r = 0; r < P.used; r++) {
+        float ms = 0;
+        VP_HIP(ctx, hipEventElapsedTime(&ms, P.ev[2 * r], P.ev[2 * r + 1]));
+        total_ms[P.ids[r]] += ms;
+        launches[P.ids[r]]++;
+    }
+    return VP_OK;
+}
+
+const char* vp_profile_kernel_name(int id)
+{
+    static const char* names[VP_PROF_KERNELS] = {"k_color_thresh", "k_morph_bits", "k_ccl_init", "k_ccl_link", "k_ccl_flatten",
+                                                  "k_ccl_rank", "k_ccl_stats", "k_ccl_final", "k_ccl_write", "other"};
+    return (id >= 0 && id < VP_PROF_KERNELS) ? names[id] : "?";
+}
+
+int vp_dev_alloc(vp_ctx* ctx, size_t bytes, void** p)
+{
+    if (!ctx || !p) return VP_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    if (e != hipSuccess) return vp_fail(ctx, VP_ERR_NOMEM, "hipMalloc", e);
+    return VP_OK;
+}
+int vp_dev_free(vp_ctx* ctx, void* p)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipFree(p));
+    return VP_OK;
+}
+int vp_memcpy_h2d(vp_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VP_OK;
+}
+int vp_memcpy_d2h(vp_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VP_OK;
+}
+
+}  // extern "C"
+
+// ---- workspace ------------------------------------------------------------------------------------
+
+int vp_ws_reserve(vp_ctx* ctx, size_t bytes)
+{
+    ctx->ws_off = 0;
+    if (bytes <= ctx->ws_cap) return VP_OK;
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) { hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_cap = 0; }
+    const size_t want = vp_align(bytes + bytes / 8, 1 << 20);
+    hipError_t e = hipMalloc((void**)&ctx->ws, want);
+    if (e != hipSuccess) return vp_fail(ctx, VP_ERR_NOMEM, "workspace hipMalloc", e);
+    ctx->ws_cap = want;
+    return VP_OK;
+}
+
+void* vp_ws_take(vp_ctx* ctx, size_t bytes)
+{
+    const size_t off = vp_align(ctx->ws_off);
+    if (off + bytes > ctx->ws_cap) return nullptr;
+    ctx->ws_off = off + bytes;
+    return ctx->ws + off;
+}
+
+#define TAKE(var, type, bytes)                                                   \
+    type var = (type)vp_ws_take(ctx, (bytes));                                   \
+    if (!var) return vp_fail(ctx, VP_ERR_NOMEM, "workspace exhausted: " #var)
+
+static int h2d(vp_ctx* ctx, void* d, const void* h, size_t n)
+{
+    VP_HIP(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
+    return VP_OK;
+}
+static int d2h(vp_ctx* ctx, void* h, const void* d, size_t n)
+{
+    VP_HIP(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream));
+    return VP_OK;
+}
+static int h2d_rows(vp_ctx* ctx, void* d, size_t dpitch, const void* h, size_t spitch, size_t rowbytes, size_t rows)
+{
+    if (spitch == rowbytes && dpitch == rowbytes) return h2d(ctx, d, h, rowbytes * rows);
+    VP_HIP(ctx, hipMemcpy2DAsync(d, dpitch, h, spitch, rowbytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    return VP_OK;
+}
+#define VP_TRY(x) do { int rc__ = (x); if (rc__ != VP_OK) return rc__; } while (0)
+
+static int check_ctx(vp_ctx* ctx)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipSetDevice", e);
+    return VP_OK;
+}
+
+// cv2.inRange bound normalisation (arithm.cpp): empty when lo > hi, lo > 255 or hi < 0
+static void norm_range(int cn, const int32_t* lo, const int32_t* hi, vp_range3* q)
+{
+    for (int c = 0; c < 3; c++) {
+        if (c >= cn) { q->lo[c] = 0; q->hi[c] = 255; continue; }
+        int l = lo[c], u = hi[c];
+        if (l > u || l > 255 || u < 0) { l = 1; u = 0; }
+        else { if (l < 0) l = 0; if (u > 255) u = 255; }
+        q->lo[c] = l;
+        q->hi[c] = u;
+    }
+}
+
+// ---- morphology planning ---------------------------------------------------------------------------
+
+struct rect_se { int kw, kh, ax, ay; };
+
+// Adds one rect erode/dilate to a stage list, split so that every stage has extents <= 32.
+static void push_rect_stage(std::vector<vp_bitstage>& v, int dilate, const rect_se& k)
+{
+    int l = k.ax, r = k.kw - 1 - k.ax, u = k.ay, d = k.kh - 1 - k.ay;
+    // merge with the previous stage of the same kind (erode∘erode / dilate∘dilate with cv2's border
+    // rule equal one pass with summed extents: the image is a box, clamping an intermediate sample
+    // into it never increases a coordinate distance)
+    if (!v.empty() && v.back().dilate == dilate) {
+        l += v.back().l; r += v.back().r; u += v.back().u; d += v.back().d;
+        v.pop_back();
+    }
+    do {
+        vp_bitstage s;
+        s.dilate = dilate;
+        s.l = l > 32 ? 32 : l; s.r = r > 32 ? 32 : r; s.u = u > 32 ? 32 : u; s.d = d > 32 ? 32 : d;
+        l -= s.l; r -= s.r; u -= s.u; d -= s.d;
+        v.push_back(s);
+    } while (l | r | u | d);
+}
+
+// Runs a stage list over bit images, grouping stages into launches whose halo fits LDS.
+// bits_a holds the input; bits_b is scratch of equal size.  The final launch writes out_bits /
+// out_mask (either may be NULL).  With an empty list the input is forwarded.
+static int run_bit_stages(vp_ctx* ctx, const std::vector<vp_bitstage>& st, u64* bits_a, u64* bits_b, int w, int h, int n,
+                          u64* out_bits, uint8_t* out_mask)
+{
+    const size_t words = (size_t)n * h * vp_ww(w);
+    if (st.empty()) {
+        if (out_bits && out_bits != bits_a) VP_HIP(ctx, hipMemcpyAsync(out_bits, bits_a, words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (out_mask) VP_TRY(vpk_unpack_bits(ctx, bits_a, w, h, n, out_mask));
+        return VP_OK;
+    }
+    const size_t lds_limit = 150 * 1024;
+    const int ww = vp_ww(w);
+    size_t i = 0;
+    u64* cur = bits_a;
+    u64* other = bits_b;
+    while (i < st.size()) {
+        vp_bitplan plan;
+        plan.n = 0;
+        int halo = 0;
+        while (i < st.size() && plan.n < VP_MAX_STAGES) {
+            const int nh = halo + st[i].u + st[i].d;
+            const size_t lds = (size_t)2 * (32 + nh) * ww * 8;
+            if (plan.n > 0 && lds > lds_limit) break;
+            if (plan.n == 0 && lds > lds_limit) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "image too wide for the LDS bit-morphology strip");
+            plan.s[plan.n++] = st[i++];
+            halo = nh;
+        }
+        const bool last = i == st.size();
+        u64* dst_bits = last ? out_bits : other;
+        VP_TRY(vpk_morph_bits(ctx, plan, cur, w, h, n, dst_bits, last ? out_mask : nullptr));
+        if (!last) { u64* t = cur; cur = other; other = t; }
+    }
+    return VP_OK;
+}
+
+static int stages_for_op(std::vector<vp_bitstage>& v, int op, const rect_se& k)
+{
+    switch (op) {
+        case VP_MORPH_ERODE: push_rect_stage(v, 0, k); break;
+        case VP_MORPH_DILATE: push_rect_stage(v, 1, k); break;
+        case VP_MORPH_OPEN: push_rect_stage(v, 0, k); push_rect_stage(v, 1, k); break;
+        case VP_MORPH_CLOSE: push_rect_stage(v, 1, k); push_rect_stage(v, 0, k); break;
+        default: return VP_ERR_INVALID;
+    }
+    return VP_OK;
+}
+
+// cv2 morphOp() normalisation of (kernel, anchor, iterations).  Returns 1 when the op degenerates to a copy.
+struct norm_se { std::vector<uint8_t> k; int kw, kh, ax, ay, iterations; bool allones; };
+static int normalise_se(const uint8_t* kernel, int kw, int kh, int ax, int ay, int iterations, norm_se* o)
+{
+    if (iterations < 0) return VP_ERR_INVALID;
+    if (!kernel || kw * kh == 0) {
+        kw = kh = 1 + iterations * 2;
+        ax = ay = iterations;
+        iterations = 1;
+        o->k.assign((size_t)kw * kh, 1);
+    } else {
+        if (kw <= 0 || kh <= 0) return VP_ERR_INVALID;
+        o->k.assign(kernel, kernel + (size_t)kw * kh);
+    }
+    if (ax < 0) ax = kw / 2;
+    if (ay < 0) ay = kh / 2;
+    if (ax >= kw || ay >= kh) return VP_ERR_INVALID;
+    bool allones = true;
+    for (uint8_t b : o->k) allones = allones && b != 0;
+    if (iterations > 1 && allones) {
+        ax *= iterations;
+        ay *= iterations;
+        kw = kw + (iterations - 1) * (kw - 1);
+        kh = kh + (iterations - 1) * (kh - 1);
+        iterations = 1;
+        o->k.assign((size_t)kw * kh, 1);
+    }
+    o->kw = kw; o->kh = kh; o->ax = ax; o->ay = ay; o->iterations = iterations; o->allones = allones;
+    return VP_OK;
+}
+
+extern "C" {
+
+int vp_structuring_element(int shape, int kw, int kh, uint8_t* out)
+{
+    // imgproc getStructuringElement(): integer geometry, anchor at the centre
+    if (!out || kw <= 0 || kh <= 0 || shape < 0 || shape > 2) return VP_ERR_INVALID;
+    if (kw == 1 && kh == 1) shape = VP_SHAPE_RECT;
+    const int r = kh / 2, c = kw / 2;
+    const double inv_r2 = (shape == VP_SHAPE_ELLIPSE && r) ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < kh; i++) {
+        int j1 = 0, j2 = 0;
+        if (shape == VP_SHAPE_RECT || (shape == VP_SHAPE_CROSS && i == r)) j2 = kw;
+        else if (shape == VP_SHAPE_CROSS) { j1 = c; j2 = c + 1; }
+        else {
+            const int dy = i - r;
+            if (abs(dy) <= r) {
+                const int dx = (int)__builtin_nearbyint(c * __builtin_sqrt((r * r - dy * dy) * inv_r2));
+                j1 = c - dx > 0 ? c - dx : 0;
+                j2 = c + dx + 1 < kw ? c + dx + 1 : kw;
+            }
+        }
+        for (int j = 0; j < kw; j++) out[i * kw + j] = (j >= j1 && j < j2) ? 1 : 0;
+    }
+    return VP_OK;
+}
+
+int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src, size_t src_stride, int w, int h, uint8_t* dst_i,
+                    uint8_t* const* planes)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || w <= 0 || h <= 0 || h > 65535) return vp_fail(ctx, VP_ERR_INVALID, "vp_cvt_color_u8 arguments");
+    if (code < VP_BGR2LAB || code > VP_GRAY2BGR) return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
+    const int scn = code == VP_GRAY2BGR ? 1 : 3, dcn = code == VP_BGR2GRAY ? 1 : 3;
+    if (src_stride < (size_t)w * scn) return vp_fail(ctx, VP_ERR_INVALID, "src_stride");
+    const size_t npx = (size_t)w * h;
+    uint8_t* hp[3] = {nullptr, nullptr, nullptr};
+    if (planes)
+        for (int c = 0; c < dcn; c++) hp[c] = planes[c];
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx * scn) + vp_align(npx * dcn) + 3 * vp_align(npx) + 4096));
+    TAKE(d_src, uint8_t*, npx * scn);
+    TAKE(d_dst, uint8_t*, npx * dcn);
+    uint8_t* dp[3] = {nullptr, nullptr, nullptr};
+    for (int c = 0; c < 3; c++)
+        if (hp[c]) { dp[c] = (uint8_t*)vp_ws_take(ctx, npx); if (!dp[c]) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+    VP_TRY(h2d_rows(ctx, d_src, (size_t)w * scn, src, src_stride, (size_t)w * scn, h));
+    VP_TRY(vpk_cvt_color(ctx, code, d_src, (size_t)w * scn, w, h, dst_i ? d_dst : nullptr, dp[0], dp[1], dp[2]));
+    if (dst_i) VP_TRY(d2h(ctx, dst_i, d_dst, npx * dcn));
+    for (int c = 0; c < 3; c++)
+        if (hp[c]) VP_TRY(d2h(ctx, hp[c], dp[c], npx));
+    return vp_synchronize(ctx);
+}
+
+int vp_inrange_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, int cn, const int32_t* lo, const int32_t* hi,
+                  uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || !lo || !hi || w <= 0 || h <= 0 || h > 65535 || (cn != 1 && cn != 3) || src_stride < (size_t)w * cn)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_inrange_u8 arguments");
+    vp_range3 q;
+    norm_range(cn, lo, hi, &q);
+    const size_t npx = (size_t)w * h;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx * cn) + vp_align(npx) + 1024));
+    TAKE(d_src, uint8_t*, npx * cn);
+    TAKE(d_dst, uint8_t*, npx);
+    VP_TRY(h2d_rows(ctx, d_src, (size_t)w * cn, src, src_stride, (size_t)w * cn, h));
+    VP_TRY(vpk_inrange_u8(ctx, d_src, (size_t)w * cn, w, h, cn, q, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, npx));
+    return vp_synchronize(ctx);
+}
+
+int vp_inrange_f32(vp_ctx* ctx, const float* src, size_t src_stride_bytes, int w, int h, float lo, float hi, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || h > 65535 || src_stride_bytes < (size_t)w * 4)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_inrange_f32 arguments");
+    const size_t npx = (size_t)w * h;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx * 4) + vp_align(npx) + 1024));
+    TAKE(d_src, float*, npx * 4);
+    TAKE(d_dst, uint8_t*, npx);
+    VP_TRY(h2d_rows(ctx, d_src, (size_t)w * 4, src, src_stride_bytes, (size_t)w * 4, h));
+    VP_TRY(vpk_inrange_f32(ctx, d_src, (size_t)w * 4, w, h, lo, hi, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, npx));
+    return vp_synchronize(ctx);
+}
+
+int vp_color_distance_u8(vp_ctx* ctx, const uint8_t* const* planes, int w, int h, const float* color, const float* wts, int skipmask,
+                         float* dist2_out, uint8_t* sqrt_out)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!planes || !color || !wts || w <= 0 || h <= 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_color_distance_u8 arguments");
+    for (int c = 0; c < 3; c++)
+        if (!(skipmask & (1 << c)) && !planes[c]) return vp_fail(ctx, VP_ERR_INVALID, "missing plane");
+    const size_t npx = (size_t)w * h;
+    VP_TRY(vp_ws_reserve(ctx, 3 * vp_align(npx) + vp_align(npx * 4) + vp_align(npx) + 2048));
+    uint8_t* dp[3] = {nullptr, nullptr, nullptr};
+    for (int c = 0; c < 3; c++) {
+        if (skipmask & (1 << c)) continue;
+        dp[c] = (uint8_t*)vp_ws_take(ctx, npx);
+        if (!dp[c]) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
+        VP_TRY(h2d(ctx, dp[c], planes[c], npx));
+    }
+    TAKE(d_d2, float*, npx * 4);
+    TAKE(d_sq, uint8_t*, npx);
+    VP_TRY(vpk_color_distance(ctx, dp[0], dp[1], dp[2], npx, color, wts, skipmask, d_d2, d_sq));
+    if (dist2_out) VP_TRY(d2h(ctx, dist2_out, d_d2, npx * 4));
+    if (sqrt_out) VP_TRY(d2h(ctx, sqrt_out, d_sq, npx));
+    return vp_synchronize(ctx);
+}
+
+// one erode or dilate (after cv2 normalisation) on a device image; result in d_out
+static int morph_basic_dev(vp_ctx* ctx, int dilate, const norm_se& se, const uint8_t* d_in, int w, int h, int cn, bool binary,
+                           uint8_t* d_out, uint8_t* d_tmp, u64* bits_a, u64* bits_b, int16_t* d_offs)
+{
+    const size_t nbytes = (size_t)w * h * cn;
+    if (se.iterations == 0 || se.kw * se.kh == 1) {
+        VP_HIP(ctx, hipMemcpyAsync(d_out, d_in, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return VP_OK;
+    }
+    if (se.allones && cn == 1 && binary) {
+        std::vector<vp_bitstage> st;
+        rect_se k = {se.kw, se.kh, se.ax, se.ay};
+        push_rect_stage(st, dilate, k);
+        VP_TRY(vpk_pack_bits(ctx, d_in, (size_t)w, w, h, 1, bits_a, nullptr));
+        return run_bit_stages(ctx, st, bits_a, bits_b, w, h, 1, nullptr, d_out);
+    }
+    // generic: offsets of the structuring element (all-ones kernels are applied separably)
+    std::vector<int16_t> offs;
+    int passes_first = 0;
+    if (se.allones) {
+        for (int j = 0; j < se.kw; j++) { offs.push_back((int16_t)(j - se.ax)); offs.push_back(0); }
+        passes_first = se.kw;
+        for (int i = 0; i < se.kh; i++) { offs.push_back(0); offs.push_back((int16_t)(i - se.ay)); }
+    } else {
+        for (int i = 0; i < se.kh; i++)
+            for (int j = 0; j < se.kw; j++)
+                if (se.k[(size_t)i * se.kw + j]) { offs.push_back((int16_t)(j - se.ax)); offs.push_back((int16_t)(i - se.ay)); }
+    }
+    VP_HIP(ctx, hipMemcpyAsync(d_offs, offs.data(), offs.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // offs is a local vector
+    if (se.allones) {
+        VP_TRY(vpk_morph_generic(ctx, dilate, d_in, w, h, cn, d_offs, passes_first, d_tmp));
+        VP_TRY(vpk_morph_generic(ctx, dilate, d_tmp, w, h, cn, d_offs + 2 * passes_first, se.kh, d_out));
+        return VP_OK;
+    }
+    const int noffs = (int)(offs.size() / 2);
+    const uint8_t* cur = d_in;
+    uint8_t* bufs[2] = {d_out, d_tmp};
+    // arrange so that the last pass lands in d_out
+    int which = (se.iterations % 2 == 1) ? 0 : 1;
+    for (int it = 0; it < se.iterations; it++) {
+        VP_TRY(vpk_morph_generic(ctx, dilate, cur, w, h, cn, d_offs, noffs, bufs[which]));
+        cur = bufs[which];
+        which ^= 1;
+    }
+    return VP_OK;
+}
+
+int vp_morph_u8(vp_ctx* ctx, int op, const uint8_t* src, int w, int h, int cn, const uint8_t* kernel, int kw, int kh, int ax, int ay,
+                int iterations, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || h > 65535 || cn < 1 || cn > 4 || op < VP_MORPH_ERODE || op > VP_MORPH_GRADIENT)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_morph_u8 arguments");
+    norm_se se;
+    if (normalise_se(kernel, kw, kh, ax, ay, iterations, &se) != VP_OK) return vp_fail(ctx, VP_ERR_INVALID, "structuring element");
+    const size_t nbytes = (size_t)w * h * cn;
+    const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
+    const size_t offbytes = ((size_t)se.kw * se.kh + se.kw + se.kh) * 4 + 64;
+    VP_TRY(vp_ws_reserve(ctx, 5 * vp_align(nbytes) + 2 * vp_align(bitbytes) + vp_align(offbytes) + 4096));
+    TAKE(d_src, uint8_t*, nbytes);
+    TAKE(d_a, uint8_t*, nbytes);
+    TAKE(d_b, uint8_t*, nbytes);
+    TAKE(d_c, uint8_t*, nbytes);
+    TAKE(d_tmp, uint8_t*, nbytes);
+    TAKE(bits_a, u64*, bitbytes);
+    TAKE(bits_b, u64*, bitbytes);
+    TAKE(d_offs, int16_t*, offbytes);
+    TAKE(d_flag, int*, 4);
+    VP_TRY(h2d(ctx, d_src, src, nbytes));
+    bool binary = false;
+    if (cn == 1 && se.allones) {
+        // a 0/255 mask can take the bit-plane path; anything else is grey-level
+        VP_HIP(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+        VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, bits_a, d_flag));
+        int flag = 1;
+        VP_TRY(d2h(ctx, &flag, d_flag, 4));
+        VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        binary = flag == 0;
+    }
+    uint8_t* result = d_a;
+    if (binary && op != VP_MORPH_GRADIENT) {
+        // whole op (incl. OPEN/CLOSE) as one fused bit-plane launch
+        std::vector<vp_bitstage> st;
+        rect_se k = {se.kw, se.kh, se.ax, se.ay};
+        if (!(se.iterations == 0 || se.kw * se.kh == 1)) stages_for_op(st, op, k);
+        VP_TRY(run_bit_stages(ctx, st, bits_a, bits_b, w, h, 1, nullptr, d_a));
+    } else if (op == VP_MORPH_ERODE || op == VP_MORPH_DILATE) {
+        VP_TRY(morph_basic_dev(ctx, op == VP_MORPH_DILATE, se, d_src, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs));
+    } else if (op == VP_MORPH_OPEN || op == VP_MORPH_CLOSE) {
+        const int first = op == VP_MORPH_CLOSE;
+        VP_TRY(morph_basic_dev(ctx, first, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs));
+        VP_TRY(morph_basic_dev(ctx, !first, se, d_b, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs));
+    } else {  // GRADIENT = dilate - erode
+        VP_TRY(morph_basic_dev(ctx, 1, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs));
+        VP_TRY(morph_basic_dev(ctx, 0, se, d_src, w, h, cn, binary, d_c, d_tmp, bits_a, bits_b, d_offs));
+        VP_TRY(vpk_absdiff_sub_u8(ctx, d_b, d_c, nbytes, d_a));
+    }
+    VP_TRY(d2h(ctx, dst, result, nbytes));
+    return vp_synchronize(ctx);
+}
+
+int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, int numbering, int32_t* labels, int32_t* stats,
+              double* centroids, int max_labels, int32_t* nlabels)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || w <= 0 || h <= 0 || src_stride < (size_t)w || max_labels < 1 || !nlabels)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_ccl_u8 arguments");
+    if (numbering != VP_CCL_BLOCK2X2 && numbering != VP_CCL_PIXEL) return vp_fail(ctx, VP_ERR_INVALID, "numbering");
+    const size_t npx = (size_t)w * h;
+    const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx) + vp_align(bitbytes) + vp_align(npx * 4) + vp_align((size_t)max_labels * 20) +
+                                  vp_align((size_t)max_labels * 16) + vp_ccl_ws_bytes(w, h, 1, max_labels) + 8192));
+    TAKE(d_src, uint8_t*, npx);
+    TAKE(d_bits, u64*, bitbytes);
+    TAKE(d_labels, int32_t*, npx * 4);
+    TAKE(d_stats, int32_t*, (size_t)max_labels * 20);
+    TAKE(d_cent, double*, (size_t)max_labels * 16);
+    TAKE(d_nl, int32_t*, 4);
+    vp_ccl_ws ws;
+    vp_ccl_ws_carve(ctx, w, h, 1, max_labels, &ws);
+    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+    VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
+    VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
+    VP_TRY(vpk_ccl(ctx, d_bits, w, h, 1, numbering, ws, labels ? d_labels : nullptr, d_stats, d_cent, max_labels, d_nl));
+    VP_TRY(d2h(ctx, nlabels, d_nl, 4));
+    if (labels) VP_TRY(d2h(ctx, labels, d_labels, npx * 4));
+    if (stats) VP_TRY(d2h(ctx, stats, d_stats, (size_t)max_labels * 20));
+    if (centroids) VP_TRY(d2h(ctx, centroids, d_cent, (size_t)max_labels * 16));
+    return vp_synchronize(ctx);
+}
+
+// ---- chain -------------------------------------------------------------------------------------------
+
+static int check_desc(vp_ctx* ctx, const vp_chain_desc* d, int n)
+{
+    if (!d || n <= 0 || d->width <= 0 || d->height <= 0) return vp_fail(ctx, VP_ERR_INVALID, "chain: size");
+    if (d->color_mode != VP_BGR2LAB && d->color_mode != VP_BGR2HSV && d->color_mode != VP_BGR2GRAY)
+        return vp_fail(ctx, VP_ERR_INVALID, "chain: color_mode");
+    if (d->n_morph < 0 || d->n_morph > VP_CHAIN_MAX_MORPH) return vp_fail(ctx, VP_ERR_INVALID, "chain: n_morph");
+    for (int i = 0; i < d->n_morph; i++)
+        if (d->morph_op[i] < VP_MORPH_ERODE || d->morph_op[i] > VP_MORPH_CLOSE || d->morph_kw[i] <= 0 || d->morph_kh[i] <= 0 ||
+            d->morph_iter[i] < 0)
+            return vp_fail(ctx, VP_ERR_INVALID, "chain: morph op");
+    if (d->ccl < 0 || d->ccl > 2) return vp_fail(ctx, VP_ERR_INVALID, "chain: ccl");
+    if (d->ccl && d->numbering != VP_CCL_BLOCK2X2 && d->numbering != VP_CCL_PIXEL) return vp_fail(ctx, VP_ERR_INVALID, "chain: numbering");
+    if (d->ccl && d->max_labels < 1) return vp_fail(ctx, VP_ERR_INVALID, "chain: max_labels");
+    return VP_OK;
+}
+
+static size_t chain_ws_bytes(const vp_chain_desc* d, int n)
+{
+    const size_t bitbytes = (size_t)n * d->height * vp_ww(d->width) * 8;
+    size_t need = 3 * vp_align(bitbytes) + vp_align((size_t)n * 4) + 8192;
+    if (d->ccl) need += vp_ccl_ws_bytes(d->width, d->height, n, d->max_labels);
+    return need;
+}
+
+// core: all pointers device; workspace already reserved and not yet carved past `ctx->ws_off`
+static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffers* b, int n)
+{
+    const int w = d->width, h = d->height;
+    const size_t bitbytes = (size_t)n * h * vp_ww(w) * 8;
+    TAKE(bits_t, u64*, bitbytes);   // threshold bits
+    TAKE(bits_a, u64*, bitbytes);
+    TAKE(bits_b, u64*, bitbytes);
+    TAKE(d_nl, int32_t*, (size_t)n * 4);
+    vp_range3 q;
+    norm_range(d->color_mode == VP_BGR2GRAY ? 1 : 3, d->lo, d->hi, &q);
+    VP_TRY(vpk_color_thresh(ctx, d->color_mode, b->bgr, (size_t)w * 3, w, h, n, q, b->threshed, bits_t));
+
+    std::vector<vp_bitstage> st;
+    for (int i = 0; i < d->n_morph; i++) {
+        norm_se se;
+        // rect kernel kw x kh, centre anchor, cv2 iteration collapse for all-ones kernels
+        std::vector<uint8_t> ones((size_t)d->morph_kw[i] * d->morph_kh[i], 1);
+        if (normalise_se(ones.data(), d->morph_kw[i], d->morph_kh[i], -1, -1, d->morph_iter[i], &se) != VP_OK)
+            return vp_fail(ctx, VP_ERR_INVALID, "chain: kernel");
+        if (se.iterations == 0 || se.kw * se.kh == 1) continue;
+        rect_se k = {se.kw, se.kh, se.ax, se.ay};
+        if (stages_for_op(st, d->morph_op[i], k) != VP_OK) return vp_fail(ctx, VP_ERR_INVALID, "chain: op");
+    }
+    const bool need_clean_bits = d->ccl == 1;
+    const u64* ccl_bits = bits_t;
+    if ((!st.empty() && (need_clean_bits || b->cleaned)) || (st.empty() && b->cleaned)) {
+        if (st.empty()) {
+            VP_TRY(vpk_unpack_bits(ctx, bits_t, w, h, n, b->cleaned));
+        } else {
+            // bits_t must survive when CCL labels the threshold mask; run_bit_stages only reads its input
+            VP_TRY(run_bit_stages(ctx, st, bits_t, bits_b, w, h, n, need_clean_bits ? bits_a : nullptr, b->cleaned));
+            if (need_clean_bits) ccl_bits = bits_a;
+        }
+    }
+    if (d->ccl) {
+        vp_ccl_ws ws;
+        vp_ccl_ws_carve(ctx, w, h, n, d->max_labels, &ws);
+        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+        VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
+                       b->nlabels ? b->nlabels : d_nl));
+    }
+    return VP_OK;
+}
+
+int vp_chain_run(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* dev, int n_frames)
+{
+    VP_TRY(check_ctx(ctx));
+    VP_TRY(check_desc(ctx, desc, n_frames));
+    if (!dev || !dev->bgr) return vp_fail(ctx, VP_ERR_INVALID, "chain: bgr");
+    VP_TRY(vp_ws_reserve(ctx, chain_ws_bytes(desc, n_frames)));
+    return chain_core(ctx, desc, dev, n_frames);
+}
+
+int vp_chain_run_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* host, int n)
+{
+    VP_TRY(check_ctx(ctx));
+    VP_TRY(check_desc(ctx, desc, n));
+    if (!host || !host->bgr) return vp_fail(ctx, VP_ERR_INVALID, "chain: bgr");
+    const size_t npx = (size_t)n * desc->width * desc->height;
+    const size_t ml = (size_t)(desc->ccl ? desc->max_labels : 1);
+    VP_TRY(vp_ws_reserve(ctx, chain_ws_bytes(desc, n) + vp_align(npx * 3) + 2 * vp_align(npx) + vp_align(npx * 4) +
+                                  vp_align(n * ml * 20) + vp_align(n * ml * 16) + vp_align((size_t)n * 4) + 8192));
+    vp_chain_buffers d;
+    memset(&d, 0, sizeof d);
+    TAKE(d_bgr, uint8_t*, npx * 3);
+    d.bgr = d_bgr;
+    if (host->threshed) { d.threshed = (uint8_t*)vp_ws_take(ctx, npx); if (!d.threshed) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+    if (host->cleaned) { d.cleaned = (uint8_t*)vp_ws_take(ctx, npx); if (!d.cleaned) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+    if (desc->ccl) {
+        if (host->labels) { d.labels = (int32_t*)vp_ws_take(ctx, npx * 4); if (!d.labels) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+        if (host->stats) { d.stats = (int32_t*)vp_ws_take(ctx, n * ml * 20); if (!d.stats) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+        if (host->centroids) { d.centroids = (double*)vp_ws_take(ctx, n * ml * 16); if (!d.centroids) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+        d.nlabels = (int32_t*)vp_ws_take(ctx, (size_t)n * 4);
+        if (!d.nlabels) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
+    }
+    VP_TRY(h2d(ctx, d_bgr, host->bgr, npx * 3));
+    VP_TRY(chain_core(ctx, desc, &d, n));
+    if (host->threshed) VP_TRY(d2h(ctx, host->threshed, d.threshed, npx));
+    if (host->cleaned) VP_TRY(d2h(ctx, host->cleaned, d.cleaned, npx));
+    if (desc->ccl) {
+        if (host->labels) VP_TRY(d2h(ctx, host->labels, d.labels, npx * 4));
+        if (host->stats) VP_TRY(d2h(ctx, host->stats, d.stats, n * ml * 20));
+        if (host->centroids) VP_TRY(d2h(ctx, host->centroids, d.centroids, n * ml * 16));
+        if (host->nlabels) VP_TRY(d2h(ctx, host->nlabels, d.nlabels, (size_t)n * 4));
+    }
+    return vp_synchronize(ctx);
+}
+
+uint64_t vp_chain_algorithmic_bytes(const vp_chain_desc* desc, const vp_chain_buffers* bufs, int n)
+{
+    if (!desc || !bufs || n <= 0) return 0;
+    const uint64_t npx = (uint64_t)n * desc->width * desc->height;
+    uint64_t per = 3;
+    if (bufs->threshed) per += 1;
+    if (bufs->cleaned) per += 1;
+    if (desc->ccl && bufs->labels) per += 4;
+    return npx * per;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// Colour conversion + inRange kernels for gfx950.
+//
+// Replaces (reference, via cv2): utils/color.py:11-32 (cvtColor + split), :105-121 (inRange),
+// :66-103 (colour distance); modules/bins.py:13-16; modules/red_buoy.py:21-28.
+//
+// The chain kernel k_color_thresh_* fuses cvtColor + split + inRange: it reads packed BGR once
+// (3 B/px), evaluates only the converted channels whose range is not trivially [0,255], and
+// writes the 0/255 mask (1 B/px) plus a bit-packed copy (1/8 B/px) that the morphology and CCL
+// kernels consume.  The arithmetic is OpenCV's 8-bit fixed point; the
+// LUTs live in LDS.  HBM-bound: 4.125 B/px.
+#include "vp_internal.h"
+
+#define LAB_LSHIFT (-1336934)  // -((16*255*32768 + 50)/100)
+
+struct LabLds { uint16_t gamma[256]; uint16_t cbrt[2048]; };
+struct HsvLds { int32_t sdiv[256]; int32_t hdiv[256]; };
+
+__device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// NEED bit0 = L, bit1 = a, bit2 = b
+template <int NEED>
+__device__ __forceinline__ void lab_px(const LabLds& t, int b, int g, int r, int& L, int& A, int& Bc)
+{
+    const int R = t.gamma[r], G = t.gamma[g], B = t.gamma[b];
+    const int fY = t.cbrt[(R * 871 + G * 2929 + B * 296 + 2048) >> 12];
+    if (NEED & 1) L = clamp255((296 * fY + LAB_LSHIFT + 16384) >> 15);
+    if (NEED & 2) {
+        const int fX = t.cbrt[(R * 1777 + G * 1541 + B * 778 + 2048) >> 12];
+        A = clamp255((500 * (fX - fY) + (128 << 15) + 16384) >> 15);
+    }
+    if (NEED & 4) {
+        const int fZ = t.cbrt[(R * 73 + G * 448 + B * 3575 + 2048) >> 12];
+        Bc = clamp255((200 * (fY - fZ) + (128 << 15) + 16384) >> 15);
+    }
+}
+
+__device__ __forceinline__ void hsv_px(const HsvLds& t, int b, int g, int r, int& H, int& S, int& V)
+{
+    int v = max(max(b, g), r);
+    int vmin = min(min(b, g), r);
+    int diff = v - vmin;
+    S = (diff * t.sdiv[v] + 2048) >> 12;
+    int hh = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    hh = (hh * t.hdiv[diff] + 2048) >> 12;
+    hh += hh < 0 ? 180 : 0;
+    H = clamp255(hh);
+    V = v;
+}
+
+__device__ __forceinline__ int gray_px(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14; }
+
+__device__ __forceinline__ bool in3(const vp_range3& q, int c0, int c1, int c2)
+{
+    return (c0 >= q.lo[0]) & (c0 <= q.hi[0]) & (c1 >= q.lo[1]) & (c1 <= q.hi[1]) & (c2 >= q.lo[2]) & (c2 <= q.hi[2]);
+}
+
+template <int MODE>
+struct ModeLds;
+template <>
+struct ModeLds<VP_BGR2LAB> { typedef LabLds type; };
+template <>
+struct ModeLds<VP_BGR2HSV> { typedef HsvLds type; };
+template <>
+struct ModeLds<VP_BGR2GRAY> { typedef int type; };
+
+template <int MODE>
+__device__ __forceinline__ void load_lds(typename ModeLds<MODE>::type& s, const vp_tables& tab)
+{
+    if constexpr (MODE == VP_BGR2LAB) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) s.gamma[i] = tab.gamma[i];
+        for (int i = threadIdx.x; i < 2048; i += blockDim.x) s.cbrt[i] = tab.cbrt[i];
+    } else if constexpr (MODE == VP_BGR2HSV) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) { s.sdiv[i] = tab.sdiv[i]; s.hdiv[i] = tab.hdiv[i]; }
+    }
+    __syncthreads();
+}
+
+// predicate for one pixel
+template <int MODE, int NEED>
+__device__ __forceinline__ bool px_pred(const typename ModeLds<MODE>::type& s, const vp_range3& q, int b, int g, int r)
+{
+    if constexpr (MODE == VP_BGR2LAB) {
+        int L = 0, A = 0, Bc = 0;
+        lab_px<NEED>(s, b, g, r, L, A, Bc);
+        bool ok = true;
+        if (NEED & 1) ok = ok & (L >= q.lo[0]) & (L <= q.hi[0]);
+        if (NEED & 2) ok = ok & (A >= q.lo[1]) & (A <= q.hi[1]);
+        if (NEED & 4) ok = ok & (Bc >= q.lo[2]) & (Bc <= q.hi[2]);
+        return ok;
+    } else if constexpr (MODE == VP_BGR2HSV) {
+        int H, S, V;
+        hsv_px(s, b, g, r, H, S, V);
+        return in3(q, H, S, V);
+    } else {
+        int y = gray_px(b, g, r);
+        return (y >= q.lo[0]) & (y <= q.hi[0]);
+    }
+}
+
+#define BYTE_OF(arr, i) (((arr)[(i) >> 2] >> (8 * ((i)&3))) & 0xffu)
+
+__device__ __forceinline__ u32 expand4(u32 nib)  // 4 bits -> 4 bytes of 0x00/0xFF
+{
+    return (((nib & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+}
+
+// Flat fast path: frames contiguous, w % 64 == 0, base 16-B aligned.  One lane = 16 px = 48 B.
+template <int MODE, int NEED, bool WMASK, bool WBITS>
+__global__ __launch_bounds__(256) void k_color_thresh_flat(const uint8_t* __restrict__ src, size_t ngroups,
+                                                           vp_tables tab, vp_range3 q, uint8_t* __restrict__ mask,
+                                                           u64* __restrict__ bits)
+{
+    __shared__ typename ModeLds<MODE>::type s;
+    load_lds<MODE>(s, tab);
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += stride) {
+        const uint4* p = reinterpret_cast<const uint4*>(src + g * 48);
+        const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+        const u32 in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        u32 m = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int b = BYTE_OF(in, 3 * k), gg = BYTE_OF(in, 3 * k + 1), r = BYTE_OF(in, 3 * k + 2);
+            m |= (u32)px_pred<MODE, NEED>(s, q, b, gg, r) << k;
+        }
+        if (WMASK) {
+            uint4 o;
+            o.x = expand4(m);
+            o.y = expand4(m >> 4);
+            o.z = expand4(m >> 8);
+            o.w = expand4(m >> 12);
+            reinterpret_cast<uint4*>(mask)[g] = o;
+        }
+        if (WBITS) {
+            // ngroups % 4 == 0, so the 4 lanes of a word are active together
+            u64 wv = (u64)m << (16 * (threadIdx.x & 3));
+            wv |= __shfl_xor(wv, 1);
+            wv |= __shfl_xor(wv, 2);
+            if ((threadIdx.x & 3) == 0) bits[g >> 2] = wv;
+        }
+    }
+}
+
+// Generic path: any w / stride / alignment.  grid.x = n*h rows; thread = 16-px group in the row.
+template <int MODE, int NEED>
+__global__ __launch_bounds__(256) void k_color_thresh_rows(const uint8_t* __restrict__ src, size_t stride, int w, int ww,
+                                                           vp_tables tab, vp_range3 q, uint8_t* __restrict__ mask,
+                                                           u64* __restrict__ bits)
+{
+    __shared__ typename ModeLds<MODE>::type s;
+    load_lds<MODE>(s, tab);
+    const size_t row = blockIdx.x;
+    const int grp = blockIdx.y * 256 + threadIdx.x;  // 16-px group, 4 per word
+    const bool live = grp < ww * 4;
+    const uint8_t* p = src + row * stride;
+    u32 m = 0;
+    if (live) {
+#pragma unroll 4
+        for (int k = 0; k < 16; k++) {
+            const int x = grp * 16 + k;
+            if (x < w) {
+                const int b = p[3 * x], gg = p[3 * x + 1], r = p[3 * x + 2];
+                const bool ok = px_pred<MODE, NEED>(s, q, b, gg, r);
+                m |= (u32)ok << k;
+                if (mask) mask[row * (size_t)w + x] = ok ? 255 : 0;
+            }
+        }
+    }
+    if (bits) {
+        u64 wv = (u64)m << (16 * (threadIdx.x & 3));
+        wv |= __shfl_xor(wv, 1);
+        wv |= __shfl_xor(wv, 2);
+        if (live && (threadIdx.x & 3) == 0) bits[row * (size_t)ww + (grp >> 2)] = wv;
+    }
+}
+
+template <int MODE, int NEED>
+static int launch_thresh(vp_ctx* ctx, const uint8_t* d_bgr, size_t stride, int w, int h, int n, const vp_range3& q,
+                         uint8_t* d_mask, u64* d_bits)
+{
+    const int ww = vp_ww(w);
+    vp_prof_scope prof(ctx, VPK_COLOR);
+    const bool flat = (w % 64 == 0) && stride == (size_t)w * 3 && ((uintptr_t)d_bgr % 16 == 0) &&
+                      (d_mask == nullptr || (uintptr_t)d_mask % 16 == 0);
+    if (flat) {
+        const size_t ngroups = (size_t)n * h * w / 16;
+        size_t blocks = (ngroups + 255) / 256;
+        const size_t cap = (size_t)ctx->num_cu * 8;
+        if (blocks > cap) blocks = cap;
+        dim3 grid((unsigned)blocks);
+        if (d_mask && d_bits)
+            hipLaunchKernelGGL((k_color_thresh_flat<MODE, NEED, true, true>), grid, dim3(256), 0, ctx->stream, d_bgr, ngroups, ctx->tab, q, d_mask, d_bits);
+        else if (d_mask)
+            hipLaunchKernelGGL((k_color_thresh_flat<MODE, NEED, true, false>), grid, dim3(256), 0, ctx->stream, d_bgr, ngroups, ctx->tab, q, d_mask, d_bits);
+        else
+            hipLaunchKernelGGL((k_color_thresh_flat<MODE, NEED, false, true>), grid, dim3(256), 0, ctx->stream, d_bgr, ngroups, ctx->tab, q, d_mask, d_bits);
+    } else {
+        dim3 grid((unsigned)((size_t)n * h), (unsigned)((ww * 4 + 255) / 256));
+        hipLaunchKernelGGL((k_color_thresh_rows<MODE, NEED>), grid, dim3(256), 0, ctx->stream, d_bgr, stride, w, ww, ctx->tab, q, d_mask, d_bits);
+    }
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride, int w, int h, int n, const vp_range3& q,
+                     uint8_t* d_mask, u64* d_bits)
+{
+    if (!d_mask && !d_bits) return VP_OK;
+    if ((size_t)n * h > 0x7fffffffULL) return vp_fail(ctx, VP_ERR_INVALID, "batch too large");
+    if (mode == VP_BGR2LAB) {
+        int need = 0;
+        for (int c = 0; c < 3; c++)
+            if (!(q.lo[c] <= 0 && q.hi[c] >= 255)) need |= 1 << c;
+        switch (need) {
+            case 0: need = 1;  // everything passes; evaluate L so that the kernel stays generic
+            case 1: return launch_thresh<VP_BGR2LAB, 1>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+            case 2: return launch_thresh<VP_BGR2LAB, 2>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+            case 4: return launch_thresh<VP_BGR2LAB, 4>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+            default: return launch_thresh<VP_BGR2LAB, 7>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+        }
+    }
+    if (mode == VP_BGR2HSV) return launch_thresh<VP_BGR2HSV, 7>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+    if (mode == VP_BGR2GRAY) return launch_thresh<VP_BGR2GRAY, 1>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+    return vp_fail(ctx, VP_ERR_INVALID, "color mode");
+}
+
+// ---- standalone conversions (operator API) ----------------------------------------------------
+
+template <int CODE>
+__global__ __launch_bounds__(256) void k_cvt_color(const uint8_t* __restrict__ src, size_t stride, int w, int h, vp_tables tab,
+                                                   uint8_t* __restrict__ dst, uint8_t* __restrict__ p0,
+                                                   uint8_t* __restrict__ p1, uint8_t* __restrict__ p2)
+{
+    __shared__ typename ModeLds<CODE>::type s;
+    load_lds<CODE>(s, tab);
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* p = src + (size_t)y * stride + 3 * (size_t)x;
+    const int b = p[0], g = p[1], r = p[2];
+    const size_t o = (size_t)y * w + x;
+    if constexpr (CODE == VP_BGR2GRAY) {
+        const uint8_t v = (uint8_t)gray_px(b, g, r);
+        if (dst) dst[o] = v;
+        if (p0) p0[o] = v;
+    } else {
+        int c0 = 0, c1 = 0, c2 = 0;
+        if constexpr (CODE == VP_BGR2LAB) lab_px<7>(s, b, g, r, c0, c1, c2);
+        else hsv_px(s, b, g, r, c0, c1, c2);
+        if (dst) { dst[3 * o] = (uint8_t)c0; dst[3 * o + 1] = (uint8_t)c1; dst[3 * o + 2] = (uint8_t)c2; }
+        if (p0) p0[o] = (uint8_t)c0;
+        if (p1) p1[o] = (uint8_t)c1;
+        if (p2) p2[o] = (uint8_t)c2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gray2bgr(const uint8_t* __restrict__ src, size_t stride, int w, int h,
+                                                  uint8_t* __restrict__ dst, uint8_t* p0, uint8_t* p1, uint8_t* p2)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t v = src[(size_t)y * stride + x];
+    const size_t o = (size_t)y * w + x;
+    if (dst) { dst[3 * o] = v; dst[3 * o + 1] = v; dst[3 * o + 2] = v; }
+    if (p0) p0[o] = v;
+    if (p1) p1[o] = v;
+    if (p2) p2[o] = v;
+}
+
+int vpk_cvt_color(vp_ctx* ctx, int code, const uint8_t* d_src, size_t stride, int w, int h, uint8_t* d_dst, uint8_t* d_p0,
+                  uint8_t* d_p1, uint8_t* d_p2)
+{
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    switch (code) {
+        case VP_BGR2LAB: hipLaunchKernelGGL((k_cvt_color<VP_BGR2LAB>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2HSV: hipLaunchKernelGGL((k_cvt_color<VP_BGR2HSV>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2GRAY: hipLaunchKernelGGL((k_cvt_color<VP_BGR2GRAY>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_GRAY2BGR: hipLaunchKernelGGL(k_gray2bgr, grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
+        default: return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
+    }
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+// ---- standalone inRange -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_inrange_u8(const uint8_t* __restrict__ src, size_t stride, int w, int h, int cn,
+                                                    vp_range3 q, uint8_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* p = src + (size_t)y * stride + (size_t)x * cn;
+    bool ok = true;
+    for (int c = 0; c < cn; c++) ok = ok & (p[c] >= q.lo[c]) & (p[c] <= q.hi[c]);
+    dst[(size_t)y * w + x] = ok ? 255 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_inrange_f32(const float* __restrict__ src, size_t stride_bytes, int w, int h, float lo,
+                                                     float hi, uint8_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const float v = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(src) + (size_t)y * stride_bytes)[x];
+    dst[(size_t)y * w + x] = (v >= lo && v <= hi) ? 255 : 0;
+}
+
+int vpk_inrange_u8(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int cn, const vp_range3& q, uint8_t* d_dst)
+{
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    hipLaunchKernelGGL(k_inrange_u8, grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, cn, q, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+int vpk_inrange_f32(vp_ctx* ctx, const float* d_src, size_t stride_bytes, int w, int h, float lo, float hi, uint8_t* d_dst)
+{
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    hipLaunchKernelGGL(k_inrange_f32, grid, dim3(256), 0, ctx->stream, d_src, stride_bytes, w, h, lo, hi, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+// ---- colour distance (float32, numpy order of operations; built with -ffp-contract=off) ---------
+
+struct cd_params { float color[3]; float wts[3]; int skipmask; };
+
+__global__ __launch_bounds__(256) void k_color_distance(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
+                                                        const uint8_t* __restrict__ p2, size_t npx, cd_params prm,
+                                                        float* __restrict__ d2, uint8_t* __restrict__ sq)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const uint8_t* p[3] = {p0, p1, p2};
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        if (prm.skipmask & (1 << c)) continue;
+        const float t = __fsub_rn((float)p[c][i], prm.color[c]);
+        const float s2 = __fmul_rn(t, t);
+        const float term = __fmul_rn(prm.wts[c], s2);
+        acc = __fadd_rn(acc, term);
+    }
+    if (d2) d2[i] = acc;
+    if (sq) sq[i] = (uint8_t)(int)__fsqrt_rn(acc);
+}
+
+int vpk_color_distance(vp_ctx* ctx, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, size_t npx, const float* color,
+                       const float* wts, int skipmask, float* d2, uint8_t* sq)
+{
+    cd_params prm;
+    for (int c = 0; c < 3; c++) { prm.color[c] = color[c]; prm.wts[c] = wts[c]; }
+    prm.skipmask = skipmask;
+    // a skipped channel may carry a NULL plane; point it somewhere valid (never dereferenced)
+    const uint8_t* any = p0 ? p0 : (p1 ? p1 : p2);
+    hipLaunchKernelGGL(k_color_distance, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, p0 ? p0 : any,
+                       p1 ? p1 : any, p2 ? p2 : any, npx, prm, d2, sq);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

@@ -1,0 +1,119 @@
+// Internal declarations shared by the libvp translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/vp.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct vp_tables {          // device copies of the OpenCV integer tables
+    const uint16_t* gamma;  // [256]  sRGBGammaTab_b
+    const uint16_t* cbrt;   // [2048] LabCbrtTab_b (indices 0..2040 are reachable)
+    const int32_t* sdiv;    // [256]
+    const int32_t* hdiv;    // [256]  hdiv_table180
+};
+
+enum { VPK_COLOR = 0, VPK_MORPH, VPK_CCL_INIT, VPK_CCL_LINK, VPK_CCL_FLATTEN, VPK_CCL_RANK, VPK_CCL_STATS, VPK_CCL_FINAL,
+       VPK_CCL_WRITE, VPK_OTHER };
+
+struct vp_prof {
+    bool on;
+    int cap, used;          // records
+    hipEvent_t* ev;         // 2 per record
+    int* ids;
+};
+
+struct vp_ctx {
+    int device;
+    hipStream_t stream;
+    hipStream_t own_stream;
+    hipEvent_t ev0, ev1;
+    void* d_tables;
+    vp_tables tab;
+    uint8_t* ws;      // grow-only device workspace, carved per call
+    size_t ws_cap;
+    size_t ws_off;
+    int num_cu;
+    vp_prof prof;
+    char err[256];
+};
+
+// brackets one kernel launch with events when profiling is on
+struct vp_prof_scope {
+    vp_ctx* c;
+    int rec;
+    vp_prof_scope(vp_ctx* ctx, int id) : c(ctx), rec(-1)
+    {
+        if (c->prof.on && c->prof.used < c->prof.cap) {
+            rec = c->prof.used++;
+            c->prof.ids[rec] = id;
+            (void)hipEventRecord(c->prof.ev[2 * rec], c->stream);
+        }
+    }
+    ~vp_prof_scope()
+    {
+        if (rec >= 0) (void)hipEventRecord(c->prof.ev[2 * rec + 1], c->stream);
+    }
+};
+
+// ---- workspace ---------------------------------------------------------------------------
+int vp_ws_reserve(vp_ctx* ctx, size_t bytes);               // may reallocate (synchronises)
+void* vp_ws_take(vp_ctx* ctx, size_t bytes);                // 256-B aligned carve; NULL if exhausted
+static inline size_t vp_align(size_t n, size_t a = 256) { return (n + a - 1) / a * a; }
+int vp_fail(vp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
+#define VP_HIP(ctx, call)                                                   \
+    do {                                                                    \
+        hipError_t e__ = (call);                                            \
+        if (e__ != hipSuccess) return vp_fail((ctx), VP_ERR_HIP, #call, e__); \
+    } while (0)
+
+// ---- host-side table generation (vp_tables.cpp) ------------------------------------------
+void vp_host_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* hdiv180, int32_t* labC);
+
+// ---- colour kernels (vp_color.hip) ---------------------------------------------------------
+struct vp_range3 { int lo[3], hi[3]; };
+// fused convert + inRange (+ optional u8 mask, + optional bit-packed mask) over n frames
+int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride, int w, int h, int n,
+                     const vp_range3& r, uint8_t* d_mask /*nullable*/, u64* d_bits /*nullable*/);
+int vpk_cvt_color(vp_ctx* ctx, int code, const uint8_t* d_src, size_t stride, int w, int h, uint8_t* d_dst,
+                  uint8_t* d_p0, uint8_t* d_p1, uint8_t* d_p2);
+int vpk_inrange_u8(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int cn, const vp_range3& r,
+                   uint8_t* d_dst);
+int vpk_inrange_f32(vp_ctx* ctx, const float* d_src, size_t stride_bytes, int w, int h, float lo, float hi,
+                    uint8_t* d_dst);
+int vpk_color_distance(vp_ctx* ctx, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, size_t npx,
+                       const float* color, const float* wts, int skipmask, float* d2, uint8_t* sq);
+
+// ---- morphology (vp_morph.hip) ---------------------------------------------------------------
+struct vp_bitstage { int dilate; int l, r, u, d; };  // window [-l, r] x [-u, d]
+#define VP_MAX_STAGES 32
+struct vp_bitplan { int n; vp_bitstage s[VP_MAX_STAGES]; };
+// words per row of a bit image
+static inline int vp_ww(int w) { return (w + 63) / 64; }
+// u8 (non-zero = 1) -> bits; d_flags[0] |= 1 if any byte is neither 0 nor 255
+int vpk_pack_bits(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int n, u64* d_bits,
+                  int* d_flags /*nullable*/);
+int vpk_unpack_bits(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, uint8_t* d_dst);
+// runs the stage plan on bit images; outputs (each nullable): bits, u8 mask
+int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits,
+                   uint8_t* d_out_mask);
+// generic u8 morphology, arbitrary structuring element, cn channels, one pass
+int vpk_morph_generic(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int h, int cn, const int16_t* d_offs,
+                      int noffs, uint8_t* d_dst);
+int vpk_absdiff_sub_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* dst);  // a - b saturating
+
+// ---- CCL (vp_ccl.hip) ----------------------------------------------------------------------------
+struct vp_ccl_ws {           // per-batch scratch, all device pointers
+    u32* parent;             // [n][nids]
+    u32* seglabel;           // [n][nids]
+    u32* flags;              // [n][nids/32]   root bitmap
+    u32* prefix;             // [n][nids/32]   exclusive popcount prefix
+    void* acc;               // [n][max_labels] accumulators
+};
+size_t vp_ccl_nids(int w, int h);   // multiple of 32
+size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels);
+void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out);
+int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
+            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels);

@@ -1,0 +1,285 @@
+// Morphology kernels for gfx950.
+//
+// Replaces (reference, via cv2): utils/transform.py:80-164 erode / dilate / morph_remove_noise /
+// morph_close_holes / morph_borders, modules/preprocessor.py:120-129.
+//
+// Binary masks with all-ones (rect) kernels — the red_buoy / bins chains — run on bit-packed
+// images: 64 px per u64, a row of 1920 px is 30 words, a whole 1080p mask is 259 KB.  A
+// workgroup stages a strip of rows plus the halo of *all* chained stages in LDS and runs every
+// erode/dilate stage there (shift/AND/OR on words, one barrier between the horizontal and the
+// vertical half of a stage), so OPEN followed by CLOSE (4 stencils) costs one read of the bit
+// image and one write of the 0/255 mask: 1.25 B/px.  Border rule = cv2's default for morphology:
+// samples outside the image never win (treated as 1 for erode, 0 for dilate) at every stage.
+//
+// Everything else (grey-level images, ellipse/cross kernels, multi-channel) goes through the
+// generic kernel: brute-force min/max over the structuring element's offsets.
+#include "vp_internal.h"
+
+#define MB_THREADS 256
+#define MB_STRIP 32
+
+__device__ __forceinline__ u32 expand4m(u32 nib) { return (((nib & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu; }
+
+// ---- pack / unpack ---------------------------------------------------------------------------
+
+// grid.x = n*h rows; thread = 16-px group (4 per word)
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ src, size_t stride, int w, int ww,
+                                                   u64* __restrict__ bits, int* __restrict__ flags)
+{
+    const size_t row = blockIdx.x;
+    const int grp = blockIdx.y * 256 + threadIdx.x;
+    const bool live = grp < ww * 4;
+    const uint8_t* p = src + row * stride;
+    u32 m = 0;
+    bool odd = false;
+    if (live) {
+        const int x0 = grp * 16;
+        if (x0 + 16 <= w && (((uintptr_t)(p + x0)) & 15) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + x0);
+            const u32 in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 b = (in[k >> 2] >> (8 * (k & 3))) & 0xff;
+                m |= (u32)(b != 0) << k;
+                odd |= (b != 0) & (b != 255);
+            }
+        } else {
+            for (int k = 0; k < 16; k++) {
+                const int x = x0 + k;
+                if (x < w) {
+                    const u32 b = p[x];
+                    m |= (u32)(b != 0) << k;
+                    odd |= (b != 0) & (b != 255);
+                }
+            }
+        }
+    }
+    u64 wv = (u64)m << (16 * (threadIdx.x & 3));
+    wv |= __shfl_xor(wv, 1);
+    wv |= __shfl_xor(wv, 2);
+    if (live && (threadIdx.x & 3) == 0) bits[row * (size_t)ww + (grp >> 2)] = wv;
+    if (flags && __any(odd)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(flags, 1);
+    }
+}
+
+__device__ __forceinline__ void store_mask16(uint8_t* __restrict__ dstrow, int x0, int w, u32 m16, bool vec_ok)
+{
+    if (vec_ok && x0 + 16 <= w) {
+        uint4 o;
+        o.x = expand4m(m16);
+        o.y = expand4m(m16 >> 4);
+        o.z = expand4m(m16 >> 8);
+        o.w = expand4m(m16 >> 12);
+        *reinterpret_cast<uint4*>(dstrow + x0) = o;
+    } else {
+        for (int k = 0; k < 16; k++)
+            if (x0 + k < w) dstrow[x0 + k] = ((m16 >> k) & 1) ? 255 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_bits(const u64* __restrict__ bits, int w, int ww, uint8_t* __restrict__ dst)
+{
+    const size_t row = blockIdx.x;
+    const int grp = blockIdx.y * 256 + threadIdx.x;
+    if (grp >= ww * 4) return;
+    const u64 wv = bits[row * (size_t)ww + (grp >> 2)];
+    uint8_t* drow = dst + row * (size_t)w;
+    store_mask16(drow, grp * 16, w, (u32)(wv >> (16 * (grp & 3))) & 0xffffu, (((uintptr_t)drow) & 15) == 0);
+}
+
+int vpk_pack_bits(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int n, u64* d_bits, int* d_flags)
+{
+    const int ww = vp_ww(w);
+    dim3 grid((unsigned)((size_t)n * h), (unsigned)((ww * 4 + 255) / 256));
+    hipLaunchKernelGGL(k_pack_bits, grid, dim3(256), 0, ctx->stream, d_src, stride, w, ww, d_bits, d_flags);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+int vpk_unpack_bits(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, uint8_t* d_dst)
+{
+    const int ww = vp_ww(w);
+    dim3 grid((unsigned)((size_t)n * h), (unsigned)((ww * 4 + 255) / 256));
+    hipLaunchKernelGGL(k_unpack_bits, grid, dim3(256), 0, ctx->stream, d_bits, w, ww, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+// ---- bit-plane morphology, LDS strips -----------------------------------------------------------
+
+struct mb_params {
+    int w, h, ww;
+    int halo_top, halo_bot;   // sum of vertical extents over all stages
+    int rows;                 // MB_STRIP + halo_top + halo_bot (LDS rows)
+    int strips;               // strips per frame
+    vp_bitplan plan;
+};
+
+// dynamic LDS: two buffers of rows*ww u64
+__global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict__ in, mb_params P, u64* __restrict__ out_bits,
+                                                           uint8_t* __restrict__ out_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int ww = P.ww, rows = P.rows;
+    u64* A = lds;
+    u64* B = lds + (size_t)rows * ww;
+    const int frame = blockIdx.x / P.strips;
+    const int strip = blockIdx.x - frame * P.strips;
+    const int y0 = strip * MB_STRIP;          // first output row of this strip
+    const int ybase = y0 - P.halo_top;        // image row of LDS row 0
+    const u64* fin = in + (size_t)frame * P.h * ww;
+    const int nwords = rows * ww;
+    const u64 lastmask = (P.w & 63) ? ((1ull << (P.w & 63)) - 1ull) : ~0ull;  // valid bits of word ww-1
+
+    for (int i = threadIdx.x; i < nwords; i += MB_THREADS) {
+        const int r = i / ww, j = i - r * ww;
+        const int y = ybase + r;
+        A[i] = (y >= 0 && y < P.h) ? fin[(size_t)y * ww + j] : 0ull;
+    }
+    __syncthreads();
+
+    for (int si = 0; si < P.plan.n; si++) {
+        const vp_bitstage st = P.plan.s[si];
+        const u64 neutral = st.dilate ? 0ull : ~0ull;
+        // horizontal half: A -> B
+        for (int i = threadIdx.x; i < nwords; i += MB_THREADS) {
+            const int r = i / ww, j = i - r * ww;
+            const int y = ybase + r;
+            if (y < 0 || y >= P.h) continue;
+            u64 cur = A[i];
+            u64 prev = j > 0 ? A[i - 1] : neutral;
+            u64 next = j + 1 < ww ? A[i + 1] : neutral;
+            if (!st.dilate) {  // out-of-image columns inside the last word count as 1 for erosion
+                if (j == ww - 1) cur |= ~lastmask;
+                if (j + 1 == ww - 1) next |= ~lastmask;
+            }
+            u64 acc = cur;
+            if (st.dilate) {
+                for (int d = 1; d <= st.r; d++) acc |= (cur >> d) | (next << (64 - d));
+                for (int d = 1; d <= st.l; d++) acc |= (cur << d) | (prev >> (64 - d));
+            } else {
+                for (int d = 1; d <= st.r; d++) acc &= (cur >> d) | (next << (64 - d));
+                for (int d = 1; d <= st.l; d++) acc &= (cur << d) | (prev >> (64 - d));
+            }
+            if (j == ww - 1) acc &= lastmask;
+            B[i] = acc;
+        }
+        __syncthreads();
+        // vertical half: B -> A
+        for (int i = threadIdx.x; i < nwords; i += MB_THREADS) {
+            const int r = i / ww;
+            const int y = ybase + r;
+            if (y < 0 || y >= P.h) continue;
+            u64 acc = B[i];
+            // rows outside the image never win; rows outside the staged range only feed halo rows that
+            // are no longer needed
+            int lo = r - st.u, hi = r + st.d;
+            if (lo < 0) lo = 0;
+            if (hi > rows - 1) hi = rows - 1;
+            if (ybase + lo < 0) lo = -ybase;
+            if (ybase + hi > P.h - 1) hi = P.h - 1 - ybase;
+            const int j = i - r * ww;
+            if (st.dilate) {
+                for (int rr = lo; rr <= hi; rr++) acc |= B[rr * ww + j];
+            } else {
+                for (int rr = lo; rr <= hi; rr++) acc &= B[rr * ww + j];
+            }
+            A[i] = acc;
+        }
+        __syncthreads();
+    }
+
+    // epilogue: rows [halo_top, halo_top + MB_STRIP) of A are final
+    const int nout_rows = min(MB_STRIP, P.h - y0);
+    if (out_bits) {
+        u64* fo = out_bits + (size_t)frame * P.h * ww;
+        for (int i = threadIdx.x; i < nout_rows * ww; i += MB_THREADS) {
+            const int r = i / ww, j = i - r * ww;
+            fo[(size_t)(y0 + r) * ww + j] = A[(P.halo_top + r) * ww + j];
+        }
+    }
+    if (out_mask) {
+        uint8_t* fm = out_mask + (size_t)frame * P.h * P.w;
+        const int gpr = ww * 4;  // 16-px groups per row
+        for (int i = threadIdx.x; i < nout_rows * gpr; i += MB_THREADS) {
+            const int r = i / gpr, g = i - r * gpr;
+            const u64 wv = A[(P.halo_top + r) * ww + (g >> 2)];
+            uint8_t* drow = fm + (size_t)(y0 + r) * P.w;
+            store_mask16(drow, g * 16, P.w, (u32)(wv >> (16 * (g & 3))) & 0xffffu, (((uintptr_t)drow) & 15) == 0);
+        }
+    }
+}
+
+int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits,
+                   uint8_t* d_out_mask)
+{
+    mb_params P;
+    P.w = w;
+    P.h = h;
+    P.ww = vp_ww(w);
+    P.plan = plan;
+    P.halo_top = P.halo_bot = 0;
+    for (int i = 0; i < plan.n; i++) {
+        if (plan.s[i].l > 63 || plan.s[i].r > 63 || plan.s[i].l < 0 || plan.s[i].r < 0 || plan.s[i].u < 0 || plan.s[i].d < 0)
+            return vp_fail(ctx, VP_ERR_INVALID, "bit stage extent");
+        P.halo_top += plan.s[i].u;
+        P.halo_bot += plan.s[i].d;
+    }
+    P.rows = MB_STRIP + P.halo_top + P.halo_bot;
+    P.strips = (h + MB_STRIP - 1) / MB_STRIP;
+    const size_t lds = (size_t)2 * P.rows * P.ww * sizeof(u64);
+    if (lds > 160 * 1024) return VP_ERR_UNSUPPORTED;  // caller splits the plan
+    if (lds > 64 * 1024)
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_morph_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    vp_prof_scope prof(ctx, VPK_MORPH);
+    hipLaunchKernelGGL(k_morph_bits, dim3((unsigned)((size_t)n * P.strips)), dim3(MB_THREADS), lds, ctx->stream, d_in, P,
+                       d_out_bits, d_out_mask);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+// ---- generic grey-level morphology: arbitrary structuring element ---------------------------------
+
+// offs: noffs pairs (dx, dy) relative to the anchor.  One thread per (x, y, channel).
+__global__ __launch_bounds__(256) void k_morph_generic(int dilate, const uint8_t* __restrict__ src, int w, int h, int cn,
+                                                       const int16_t* __restrict__ offs, int noffs, uint8_t* __restrict__ dst)
+{
+    const int xc = blockIdx.x * 256 + threadIdx.x;  // x*cn + c
+    const int y = blockIdx.y;
+    if (xc >= w * cn) return;
+    const int x = xc / cn, c = xc - x * cn;
+    int best = dilate ? 0 : 255;
+    for (int k = 0; k < noffs; k++) {
+        const int xx = x + offs[2 * k], yy = y + offs[2 * k + 1];
+        if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;
+        const int v = src[((size_t)yy * w + xx) * cn + c];
+        best = dilate ? max(best, v) : min(best, v);
+    }
+    dst[((size_t)y * w + x) * cn + c] = (uint8_t)best;
+}
+
+int vpk_morph_generic(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int h, int cn, const int16_t* d_offs, int noffs,
+                      uint8_t* d_dst)
+{
+    dim3 grid((unsigned)((w * cn + 255) / 256), (unsigned)h);
+    hipLaunchKernelGGL(k_morph_generic, grid, dim3(256), 0, ctx->stream, dilate, d_src, w, h, cn, d_offs, noffs, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_sub_sat_u8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
+                                                    uint8_t* __restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)a[i] - (int)b[i];
+    dst[i] = (uint8_t)(d < 0 ? 0 : d);
+}
+
+int vpk_absdiff_sub_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* dst)
+{
+    hipLaunchKernelGGL(k_sub_sat_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n, dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

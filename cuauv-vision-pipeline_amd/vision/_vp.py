@@ -1,0 +1,198 @@
+"""ctypes binding of libvp.so (C ABI: include/vp.h).  Thin: argument marshalling only.
+
+The library is built in-tree by `cuauv-vision-pipeline_amd/build.py` (hipcc --offload-arch=gfx950) into
+`cuauv-vision-pipeline_amd/lib/libvp.so`.  If it is missing, or no MI355X is visible, every operator
+raises VpError — the product has no CPU path.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvp.so")
+
+BGR2LAB, BGR2HSV, BGR2GRAY, GRAY2BGR = 0, 1, 2, 3
+MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
+SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
+CCL_PIXEL, CCL_BLOCK2X2 = 1, 2
+CHAIN_MAX_MORPH = 8
+PROF_KERNELS = 10
+
+
+class VpError(RuntimeError):
+    pass
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("color_mode", C.c_int32),
+                ("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3), ("n_morph", C.c_int32),
+                ("morph_op", C.c_int32 * CHAIN_MAX_MORPH), ("morph_kw", C.c_int32 * CHAIN_MAX_MORPH),
+                ("morph_kh", C.c_int32 * CHAIN_MAX_MORPH), ("morph_iter", C.c_int32 * CHAIN_MAX_MORPH),
+                ("ccl", C.c_int32), ("numbering", C.c_int32), ("max_labels", C.c_int32)]
+
+
+class ChainBuffers(C.Structure):
+    _fields_ = [("bgr", C.c_void_p), ("threshed", C.c_void_p), ("cleaned", C.c_void_p), ("labels", C.c_void_p),
+                ("stats", C.c_void_p), ("centroids", C.c_void_p), ("nlabels", C.c_void_p)]
+
+
+_lib = None
+_lock = threading.Lock()
+_ctxs = {}
+
+_SIGS = {
+    "vp_version": (C.c_int, []),
+    "vp_strerror": (C.c_char_p, [C.c_int]),
+    "vp_create": (C.c_void_p, [C.c_int]),
+    "vp_destroy": (C.c_int, [C.c_void_p]),
+    "vp_last_error": (C.c_char_p, [C.c_void_p]),
+    "vp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vp_get_stream": (C.c_void_p, [C.c_void_p]),
+    "vp_synchronize": (C.c_int, [C.c_void_p]),
+    "vp_timer_start": (C.c_int, [C.c_void_p]),
+    "vp_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "vp_get_tables": (C.c_int, [C.c_void_p] * 5),
+    "vp_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "vp_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vp_profile_kernel_name": (C.c_char_p, [C.c_int]),
+    "vp_cvt_color_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vp_inrange_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vp_inrange_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "vp_color_distance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "vp_structuring_element": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vp_morph_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vp_ccl_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vp_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
+    "vp_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
+    "vp_chain_algorithmic_bytes": (C.c_uint64, [C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
+    "vp_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vp_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vp_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+}
+
+
+def lib():
+    """Loads libvp.so (once).  Raises VpError when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise VpError(f"{LIB_PATH} is missing: build it with `python cuauv-vision-pipeline_amd/build.py` "
+                                  "(there is no CPU fallback)")
+                l = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGS.items():
+                    fn = getattr(l, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        l = lib()
+        msg = l.vp_last_error(ctx)
+        raise VpError(f"libvp: {l.vp_strerror(rc).decode()} ({rc}): {msg.decode() if msg else ''}")
+
+
+class Context:
+    """One libvp context = one HIP stream on one device (one per camera direction)."""
+
+    def __init__(self, device=0):
+        l = lib()
+        self.handle = l.vp_create(int(device))
+        if not self.handle:
+            raise VpError("vp_create failed: " + l.vp_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib().vp_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        check(lib().vp_set_stream(self.handle, stream_handle), self.handle)
+
+    def synchronize(self):
+        check(lib().vp_synchronize(self.handle), self.handle)
+
+    def timer_start(self):
+        check(lib().vp_timer_start(self.handle), self.handle)
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().vp_timer_stop(self.handle, C.byref(ms)), self.handle)
+        return ms.value
+
+    def profile_begin(self, max_records):
+        check(lib().vp_profile_begin(self.handle, int(max_records)), self.handle)
+
+    def profile_end(self):
+        """-> {kernel name: (total_ms, launches)}"""
+        ms = np.zeros(PROF_KERNELS, np.float64)
+        cnt = np.zeros(PROF_KERNELS, np.int32)
+        check(lib().vp_profile_end(self.handle, ptr(ms), ptr(cnt)), self.handle)
+        return {lib().vp_profile_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(PROF_KERNELS) if cnt[i]}
+
+    def chain_run(self, desc, bufs, n):
+        check(lib().vp_chain_run(self.handle, C.byref(desc), C.byref(bufs), int(n)), self.handle)
+
+    def chain_run_host(self, desc, bufs, n):
+        check(lib().vp_chain_run_host(self.handle, C.byref(desc), C.byref(bufs), int(n)), self.handle)
+
+
+def default_context(device=0):
+    """Per-(thread, device) context: ModuleBase runs process() on a non-main thread (core/base.py:701-703)."""
+    key = (threading.get_ident(), device)
+    ctx = _ctxs.get(key)
+    if ctx is None:
+        ctx = Context(device)
+        _ctxs[key] = ctx
+    return ctx
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def get_tables():
+    gamma = np.zeros(256, np.uint16)
+    cbrt = np.zeros(3072, np.uint16)
+    sdiv = np.zeros(256, np.int32)
+    hdiv = np.zeros(256, np.int32)
+    labc = np.zeros(9, np.int32)
+    check(lib().vp_get_tables(ptr(gamma), ptr(cbrt), ptr(sdiv), ptr(hdiv), ptr(labc)))
+    return gamma, cbrt, sdiv, hdiv, labc
+
+
+def make_chain_desc(width, height, color_mode, lo, hi, morph=(), ccl=1, numbering=CCL_BLOCK2X2, max_labels=256):
+    """morph: sequence of (op, kw, kh[, iterations])."""
+    d = ChainDesc()
+    d.width, d.height, d.color_mode = int(width), int(height), int(color_mode)
+    lo = list(np.broadcast_to(np.asarray(lo), (3,))) if np.ndim(lo) else [int(lo), 0, 0]
+    hi = list(np.broadcast_to(np.asarray(hi), (3,))) if np.ndim(hi) else [int(hi), 255, 255]
+    for c in range(3):
+        d.lo[c] = int(lo[c])
+        d.hi[c] = int(hi[c])
+    if len(morph) > CHAIN_MAX_MORPH:
+        raise ValueError("too many morphology ops")
+    d.n_morph = len(morph)
+    for i, m in enumerate(morph):
+        d.morph_op[i], d.morph_kw[i], d.morph_kh[i] = int(m[0]), int(m[1]), int(m[2])
+        d.morph_iter[i] = int(m[3]) if len(m) > 3 else 1
+    d.ccl, d.numbering, d.max_labels = int(ccl), int(numbering), int(max_labels)
+    return d

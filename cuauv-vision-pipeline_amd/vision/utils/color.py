@@ -1,0 +1,162 @@
+"""Mirror of the reference utils/color.py for the hot path (same names, arguments, return structure).
+
+Reference: utils/color.py:11-32 (`_convert_colorspace`: cv2.cvtColor + cv2.split), :105-121
+(`range_threshold`: cv2.inRange), :66-103 (`thresh_color_distance`).  The arithmetic runs in libvp's
+HIP kernels (include/vp.h: vp_cvt_color_u8, vp_inrange_u8, vp_inrange_f32, vp_color_distance_u8).
+Returned arrays are fresh, writable, caller-owned numpy arrays, as with cv2.
+"""
+from math import sqrt
+from typing import Callable, List, Tuple
+
+import numpy as np
+
+from vision import _vp
+from vision.utils.helpers import as_mat
+
+
+def _u8_image(mat, channels):
+    mat = as_mat(mat)
+    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
+        raise TypeError("expected a uint8 numpy image")
+    if channels == 3 and not (mat.ndim == 3 and mat.shape[2] == 3):
+        raise ValueError("expected an (h, w, 3) image")
+    if channels == 1:
+        if mat.ndim == 3 and mat.shape[2] == 1:
+            mat = mat[:, :, 0]
+        if mat.ndim != 2:
+            raise ValueError("expected an (h, w) image")
+    if mat.shape[0] == 0 or mat.shape[1] == 0:
+        raise ValueError("empty image")
+    # rows must be dense; a row pitch is fine (views of wider images)
+    if mat.strides[-1] != 1 or (mat.ndim == 3 and mat.strides[1] != mat.shape[2]) or mat.strides[0] < mat.shape[1] * (channels):
+        mat = np.ascontiguousarray(mat)
+    return mat
+
+
+def _convert_colorspace(code: int) -> Callable[[np.ndarray], Tuple[np.ndarray, Tuple[np.ndarray, ...]]]:
+    """utils/color.py:11-23: returns f(mat) -> (converted image, split channels)."""
+    scn = 1 if code == _vp.GRAY2BGR else 3
+    dcn = 1 if code == _vp.BGR2GRAY else 3
+
+    def _inner(mat: np.ndarray):
+        mat = _u8_image(mat, scn)
+        h, w = mat.shape[:2]
+        conv = np.empty((h, w) if dcn == 1 else (h, w, 3), np.uint8)
+        planes = [np.empty((h, w), np.uint8) for _ in range(dcn)] if dcn == 3 else []
+        arr = (_vp.C.c_void_p * 3)(*[p.ctypes.data for p in planes], *([None] * (3 - len(planes))))
+        ctx = _vp.default_context()
+        _vp.check(_vp.lib().vp_cvt_color_u8(ctx.handle, code, _vp.ptr(mat), mat.strides[0], w, h, _vp.ptr(conv),
+                                            arr if planes else None), ctx.handle)
+        # cv2.split of a single-channel image returns a 1-tuple holding a copy
+        return conv, (tuple(planes) if planes else (conv.copy(),))
+    return _inner
+
+
+def _unsupported(name):
+    def _inner(mat):
+        raise NotImplementedError(f"{name}: conversion is outside the accelerated hot path")
+    return _inner
+
+
+bgr_to_lab = _convert_colorspace(_vp.BGR2LAB)
+bgr_to_hsv = _convert_colorspace(_vp.BGR2HSV)
+bgr_to_gray = _convert_colorspace(_vp.BGR2GRAY)
+gray_to_bgr = _convert_colorspace(_vp.GRAY2BGR)
+bgr_to_hls = _unsupported("bgr_to_hls")
+bgr_to_ycrcb = _unsupported("bgr_to_ycrcb")
+bgr_to_luv = _unsupported("bgr_to_luv")
+lab_to_bgr = _unsupported("lab_to_bgr")
+hsv_to_bgr = _unsupported("hsv_to_bgr")
+
+
+def color_dist(c1, c2) -> float:
+    """utils/color.py:35-48."""
+    return sqrt((c1[0] - c2[0])**2 + (c1[1] - c2[1])**2 + (c1[2] - c2[2])**2)
+
+
+def elementwise_color_dist(mat: np.ndarray, c) -> np.ndarray:
+    """utils/color.py:51-63 (plain numpy in the reference too)."""
+    return np.linalg.norm(as_mat(mat) - c, axis=2)
+
+
+def _round_half_even(v):
+    return int(np.rint(v))
+
+
+def range_threshold(mat: np.ndarray, min, max) -> np.ndarray:
+    """utils/color.py:105-121: cv2.inRange(mat, min, max) -> 0/255 mask.
+
+    uint8 input with scalar or per-channel bounds (rounded half-to-even like cv2's scalar
+    conversion), or float32 single-channel input (the `dists` image of thresh_color_distance)."""
+    mat = as_mat(mat)
+    ctx = _vp.default_context()
+    if isinstance(mat, np.ndarray) and mat.dtype == np.float32:
+        if mat.ndim == 3 and mat.shape[2] == 1:
+            mat = mat[:, :, 0]
+        if mat.ndim != 2:
+            raise ValueError("float32 inRange supports single-channel images")
+        if mat.strides[1] != 4:
+            mat = np.ascontiguousarray(mat)
+        h, w = mat.shape
+        out = np.empty((h, w), np.uint8)
+        lo = float(np.float32(np.ravel(min)[0] if np.ndim(min) else min))
+        hi = float(np.float32(np.ravel(max)[0] if np.ndim(max) else max))
+        _vp.check(_vp.lib().vp_inrange_f32(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, lo, hi, _vp.ptr(out)), ctx.handle)
+        return out
+    cn = 3 if (isinstance(mat, np.ndarray) and mat.ndim == 3 and mat.shape[2] == 3) else 1
+    mat = _u8_image(mat, cn)
+    h, w = mat.shape[:2]
+
+    def bounds(b):
+        b = np.atleast_1d(np.asarray(b, dtype=np.float64)).ravel()
+        if b.size == 1 and cn == 3:
+            b = np.array([b[0], 0.0, 0.0])  # cv2 scalar -> (v, 0, 0, 0)
+        if b.size < cn:
+            raise ValueError("bounds need one value per channel")
+        return np.ascontiguousarray(np.clip(np.rint(b[:cn]), -2**31, 2**31 - 1).astype(np.int32))
+    lo, hi = bounds(min), bounds(max)
+    out = np.empty((h, w), np.uint8)
+    _vp.check(_vp.lib().vp_inrange_u8(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, cn, _vp.ptr(lo), _vp.ptr(hi), _vp.ptr(out)), ctx.handle)
+    return out
+
+
+def binary_threshold(mat: np.ndarray, threshold: int) -> np.ndarray:
+    """utils/color.py:124-137 (cv2.threshold THRESH_BINARY on uint8): > threshold -> 255."""
+    return range_threshold(mat, int(np.floor(threshold)) + 1, 255)
+
+
+def binary_threshold_inv(mat: np.ndarray, threshold: int) -> np.ndarray:
+    """utils/color.py:140-153: <= threshold -> 255."""
+    return range_threshold(mat, 0, int(np.floor(threshold)))
+
+
+def thresh_color_distance(split: List[np.ndarray], color, distance: float, auto_distance_percentile: float = None,
+                          ignore_channels: List[int] = [], weights=(1, 1, 1)) -> Tuple[np.ndarray, np.ndarray]:
+    """utils/color.py:66-103.  d2 = sum_i w_i * (float32(split_i) - color_i)^2 in float32 (numpy 1.x
+    scalar semantics: the normalised float64 weight multiplies a float32 array as float32), mask =
+    inRange(d2, 0, distance^2 [or the percentile]), second result uint8(sqrt(d2))."""
+    weights_cp = list(weights)
+    for idx in ignore_channels:
+        weights_cp[idx] = 0
+    weights_cp = np.asarray(weights_cp, dtype=np.float64) / np.linalg.norm(weights)
+    planes = [_u8_image(p, 1) for p in split[:3]]
+    h, w = planes[0].shape
+    planes = [np.ascontiguousarray(p) for p in planes]
+    skip = 0
+    for i in range(3):
+        if i in ignore_channels:
+            skip |= 1 << i
+    col = np.ascontiguousarray(np.asarray([color[0], color[1], color[2]], dtype=np.float32))
+    wts = np.ascontiguousarray(weights_cp.astype(np.float32))
+    d2 = np.empty((h, w), np.float32)
+    sq = np.empty((h, w), np.uint8)
+    arr = (_vp.C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_color_distance_u8(ctx.handle, arr, w, h, _vp.ptr(col), _vp.ptr(wts), skip, _vp.ptr(d2), _vp.ptr(sq)), ctx.handle)
+    if auto_distance_percentile:
+        # the reference takes np.percentile over the whole image (utils/color.py:98); order statistics of
+        # a float image are host-side numpy here, outside the accelerated chain
+        distance = min(np.percentile(d2, auto_distance_percentile), distance**2)
+    else:
+        distance = distance**2
+    return range_threshold(d2, 0, distance), sq

@@ -1,0 +1,96 @@
+"""Mirror of the reference utils/feature.py for the hot path.
+
+`connected_components` is the north-star replacement of the cv2.findContours stage
+(utils/feature.py:5-40, modules/red_buoy.py:38): cv2.connectedComponentsWithStats(mask, 8, CV_32S)
+semantics on the GPU (libvp vp_ccl_u8).  Polygon helpers (`contour_centroid`, `contour_area`,
+utils/feature.py:240-265) are float64 scalar arithmetic on a handful of points and stay on the host.
+"""
+from typing import List, Tuple
+
+import numpy as np
+
+from vision import _vp
+from vision.utils.helpers import as_mat
+
+
+def connected_components(mat: np.ndarray, numbering: int = _vp.CCL_BLOCK2X2, max_labels: int = 4096,
+                         want_labels: bool = True):
+    """Returns (nlabels, labels int32 (h,w) or None, stats int32 (k,5), centroids float64 (k,2)),
+    k = min(nlabels, max_labels); row 0 is the background, like cv2."""
+    mat = as_mat(mat)
+    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
+        raise TypeError("expected a uint8 mask")
+    if mat.ndim == 3 and mat.shape[2] == 1:
+        mat = mat[:, :, 0]
+    if mat.ndim != 2 or mat.size == 0:
+        raise ValueError("expected a non-empty (h, w) mask")
+    if mat.strides[1] != 1:
+        mat = np.ascontiguousarray(mat)
+    h, w = mat.shape
+    labels = np.empty((h, w), np.int32) if want_labels else None
+    stats = np.empty((max_labels, 5), np.int32)
+    cent = np.empty((max_labels, 2), np.float64)
+    n = _vp.C.c_int32(0)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_ccl_u8(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, int(numbering), _vp.ptr(labels), _vp.ptr(stats),
+                                  _vp.ptr(cent), int(max_labels), _vp.C.byref(n)), ctx.handle)
+    k = min(n.value, max_labels)
+    return n.value, labels, stats[:k].copy(), cent[:k].copy()
+
+
+def _polygon_moments(contour: np.ndarray):
+    """cv2.moments on an (N,1,2) int contour (imgproc/src/moments.cpp contourMoments): Green's theorem,
+    float64; m00 made non-negative together with the first moments."""
+    pts = np.asarray(contour).reshape(-1, 2).astype(np.float64)
+    n = len(pts)
+    if n == 0:
+        return 0.0, 0.0, 0.0
+    a00 = a10 = a01 = 0.0
+    xi_1, yi_1 = pts[n - 1]
+    for i in range(n):
+        xi, yi = pts[i]
+        dxy = xi_1 * yi - xi * yi_1
+        a00 += dxy
+        a10 += dxy * (xi_1 + xi)
+        a01 += dxy * (yi_1 + yi)
+        xi_1, yi_1 = xi, yi
+    if abs(a00) > 1.1920929e-07:
+        if a00 > 0:
+            db1_2, db1_6 = 0.5, 1.0 / 6
+        else:
+            db1_2, db1_6 = -0.5, -1.0 / 6
+        return a00 * db1_2, a10 * db1_6, a01 * db1_6
+    return 0.0, 0.0, 0.0
+
+
+def contour_centroid(contour: np.ndarray) -> Tuple[int, int]:
+    """utils/feature.py:240-252."""
+    m00, m10, m01 = _polygon_moments(contour)
+    m00 = max(1e-10, m00)
+    return int(m10 / m00), int(m01 / m00)
+
+
+def contour_area(contour: np.ndarray) -> float:
+    """utils/feature.py:255-265 (cv2.contourArea, oriented=False): |shoelace| / 2."""
+    pts = np.asarray(contour).reshape(-1, 2).astype(np.float64)
+    n = len(pts)
+    if n == 0:
+        return 0.0
+    a00 = 0.0
+    prev = pts[n - 1]
+    for i in range(n):
+        p = pts[i]
+        a00 += prev[0] * p[1] - prev[1] * p[0]
+        prev = p
+    return abs(a00 * 0.5)
+
+
+def outer_contours(mat: np.ndarray) -> List[np.ndarray]:
+    """utils/feature.py:5-21 (cv2.findContours RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)."""
+    raise NotImplementedError("contour extraction is the next row of the scope table (SURVEY §8f rank 1); "
+                              "use connected_components for the accelerated path")
+
+
+def all_contours(mat: np.ndarray) -> List[np.ndarray]:
+    """utils/feature.py:25-40 (cv2.findContours RETR_LIST, CHAIN_APPROX_SIMPLE)."""
+    raise NotImplementedError("contour extraction is the next row of the scope table (SURVEY §8f rank 1)")

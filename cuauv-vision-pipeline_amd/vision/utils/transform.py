@@ -1,0 +1,83 @@
+"""Mirror of the reference utils/transform.py for the hot path.
+
+Reference: utils/transform.py:27-77 (`elliptic_kernel`, `rect_kernel`), :80-112 (`erode`, `dilate`),
+:115-164 (`morph_remove_noise`, `morph_close_holes`, `morph_borders`).  Kernels: libvp vp_morph_u8
+(bit-plane LDS stencils for 0/255 masks with rect kernels, generic kernel otherwise).
+"""
+from typing import Optional
+
+import numpy as np
+
+from vision import _vp
+from vision.utils.helpers import as_mat
+
+
+def _structuring_element(shape, x, y):
+    out = np.empty((y, x), np.uint8)
+    _vp.check(_vp.lib().vp_structuring_element(shape, x, y, _vp.ptr(out)))
+    return out
+
+
+def elliptic_kernel(x: int, y: Optional[int] = None) -> np.ndarray:
+    """utils/transform.py:27-51: odd positive sizes only (ValueError otherwise)."""
+    if y is None:
+        y = x
+    if x % 2 == 0 or y % 2 == 0 or x <= 0 or y <= 0:
+        raise ValueError("x and y must be odd positive integers")
+    return _structuring_element(_vp.SHAPE_ELLIPSE, int(x), int(y))
+
+
+def rect_kernel(x: int, y: Optional[int] = None) -> np.ndarray:
+    """utils/transform.py:54-77."""
+    if y is None:
+        y = x
+    if x <= 0 or y <= 0:
+        raise ValueError("x and y must be positive integers")
+    return _structuring_element(_vp.SHAPE_RECT, int(x), int(y))
+
+
+def _morph(op, mat, kernel, iterations, anchor=(-1, -1)):
+    mat = as_mat(mat)
+    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8 or mat.ndim not in (2, 3):
+        raise TypeError("expected a uint8 (h, w) or (h, w, c) image")
+    src = np.ascontiguousarray(mat)
+    h, w = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    if kernel is None or np.size(kernel) == 0:
+        kp, kw, kh = None, 0, 0
+    else:
+        kernel = np.ascontiguousarray(np.asarray(kernel) != 0, dtype=np.uint8)
+        if kernel.ndim != 2:
+            raise ValueError("kernel must be 2-D")
+        kh, kw = kernel.shape
+        kp = _vp.ptr(kernel)
+    out = np.empty_like(src)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_morph_u8(ctx.handle, op, _vp.ptr(src), w, h, cn, kp, kw, kh, int(anchor[0]), int(anchor[1]),
+                                    int(iterations), _vp.ptr(out)), ctx.handle)
+    return out
+
+
+def erode(mat: np.ndarray, kernel: np.ndarray, iterations: int = 1) -> np.ndarray:
+    """utils/transform.py:80-94 (cv2.erode)."""
+    return _morph(_vp.MORPH_ERODE, mat, kernel, iterations)
+
+
+def dilate(mat: np.ndarray, kernel: np.ndarray, iterations: int = 1) -> np.ndarray:
+    """utils/transform.py:97-112 (cv2.dilate)."""
+    return _morph(_vp.MORPH_DILATE, mat, kernel, iterations)
+
+
+def morph_remove_noise(mat: np.ndarray, kernel: np.ndarray, iterations: int = 1) -> np.ndarray:
+    """utils/transform.py:115-129 (cv2.morphologyEx MORPH_OPEN)."""
+    return _morph(_vp.MORPH_OPEN, mat, kernel, iterations)
+
+
+def morph_close_holes(mat: np.ndarray, kernel: np.ndarray, iterations: int = 1) -> np.ndarray:
+    """utils/transform.py:132-146 (cv2.morphologyEx MORPH_CLOSE)."""
+    return _morph(_vp.MORPH_CLOSE, mat, kernel, iterations)
+
+
+def morph_borders(mat: np.ndarray, kernel: np.ndarray, iterations: int = 1) -> np.ndarray:
+    """utils/transform.py:149-164 (cv2.morphologyEx MORPH_GRADIENT)."""
+    return _morph(_vp.MORPH_GRADIENT, mat, kernel, iterations)

@@ -1,0 +1,160 @@
+/*
+ * vp.h — C ABI of libvp.so, the MI355X (gfx950) implementation of the per-frame detection hot
+ * path of ayf7/cuauv-vision-pipeline: colour convert -> inRange -> erode/dilate -> connected
+ * components.  Everything behind this header is hand-written HIP; there is no CPU fallback:
+ * every compute entry point returns VP_ERR_HIP when no gfx950 device is usable.
+ *
+ * Each entry point names the reference interface it replaces (file:line under the reference
+ * checkout).  The reference implements these by calling cv2 from Python (utils/color.py,
+ * utils/transform.py, utils/feature.py); the Python mirror in
+ * cuauv-vision-pipeline_amd/vision/utils binds this ABI with ctypes.
+ *
+ * Conventions: plain pointers and sizes only.  `_host` pointers are ordinary process memory
+ * (staged through the context's device workspace); pointers inside vp_chain_buffers are device
+ * (HBM) pointers.  Images are row-major, interleaved channels, uint8 unless stated.
+ * All functions return VP_OK (0) or a negative VP_ERR_*; none throws.  A context is
+ * thread-compatible (one caller at a time); use one context per stream / camera direction.
+ */
+#ifndef VP_H
+#define VP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VP_OK 0
+#define VP_ERR_INVALID (-1)     /* bad argument (NULL, size <= 0, unknown enum) */
+#define VP_ERR_HIP (-2)         /* HIP runtime error / no device; see vp_last_error() */
+#define VP_ERR_NOMEM (-3)       /* device or host allocation failed */
+#define VP_ERR_UNSUPPORTED (-4) /* valid request outside what the kernels cover */
+
+typedef struct vp_ctx vp_ctx;
+
+/* colour conversion codes (values are libvp's own, not cv2's) */
+enum { VP_BGR2LAB = 0, VP_BGR2HSV = 1, VP_BGR2GRAY = 2, VP_GRAY2BGR = 3 };
+/* morphology ops — utils/transform.py:80-164 */
+enum { VP_MORPH_ERODE = 0, VP_MORPH_DILATE = 1, VP_MORPH_OPEN = 2, VP_MORPH_CLOSE = 3, VP_MORPH_GRADIENT = 4 };
+/* structuring element shapes — cv2.MORPH_RECT / MORPH_CROSS / MORPH_ELLIPSE */
+enum { VP_SHAPE_RECT = 0, VP_SHAPE_CROSS = 1, VP_SHAPE_ELLIPSE = 2 };
+/* label numbering: VP_CCL_BLOCK2X2 = order of cv2.connectedComponents' default 8-way
+ * algorithm (raster order of each component's first 2x2 block); VP_CCL_PIXEL = raster order of
+ * each component's first pixel (cv2 CCL_WU / SAUF). */
+enum { VP_CCL_PIXEL = 1, VP_CCL_BLOCK2X2 = 2 };
+
+/* ---- context ------------------------------------------------------------------------- */
+int vp_version(void);
+const char* vp_strerror(int code);
+/* Creates a context on HIP device `device` with its own non-blocking stream. NULL on failure
+ * (vp_last_error(NULL) tells why). */
+vp_ctx* vp_create(int device);
+int vp_destroy(vp_ctx* ctx);
+const char* vp_last_error(const vp_ctx* ctx);
+/* Adopt an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL reverts to
+ * the context's own stream. */
+int vp_set_stream(vp_ctx* ctx, void* hip_stream);
+void* vp_get_stream(vp_ctx* ctx);
+int vp_synchronize(vp_ctx* ctx);
+/* HIP-event stopwatch on the context's stream (bench.py: roofline.achieved). */
+int vp_timer_start(vp_ctx* ctx);
+int vp_timer_stop(vp_ctx* ctx, float* elapsed_ms); /* records, synchronises, returns ms */
+/* Per-kernel attribution: between vp_profile_begin and vp_profile_end every kernel the context
+ * launches is bracketed by HIP events on its stream.  vp_profile_end synchronises and fills
+ * total_ms[id] / launches[id] for id < VP_PROF_KERNELS (names: vp_profile_kernel_name). */
+#define VP_PROF_KERNELS 10
+int vp_profile_begin(vp_ctx* ctx, int max_records);
+int vp_profile_end(vp_ctx* ctx, double* total_ms, int32_t* launches);
+const char* vp_profile_kernel_name(int id);
+/* Copies of the integer tables the kernels use (for parity tests against the oracle):
+ * gamma[256] u16, cbrt[3072] u16, sdiv[256] i32, hdiv180[256] i32, lab_coeffs[9] i32. */
+int vp_get_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* hdiv180, int32_t* lab_coeffs);
+
+/* ---- per-operator API, host pointers --------------------------------------------------- */
+
+/* utils/color.py:11-32 `_convert_colorspace` (cv2.cvtColor + cv2.split): bgr_to_lab, bgr_to_hsv,
+ * bgr_to_gray, gray_to_bgr.  src is (h,w,3) (or (h,w) for GRAY2BGR) with `src_stride` bytes per
+ * row.  dst_interleaved (tightly packed, may be NULL) receives the converted image; dst_planes[k]
+ * (each (h,w) tightly packed, each may be NULL, array may be NULL) receive the split channels. */
+int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src_host, size_t src_stride, int w, int h,
+                    uint8_t* dst_interleaved_host, uint8_t* const* dst_planes_host);
+
+/* utils/color.py:105-121 `range_threshold` / modules/bins.py:16 (cv2.inRange): cn = 1 or 3;
+ * lo/hi have cn entries (already rounded to integers); dst is (h,w) 0/255. */
+int vp_inrange_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride, int w, int h, int cn,
+                  const int32_t* lo, const int32_t* hi, uint8_t* dst_host);
+/* cv2.inRange on a CV_32FC1 image (utils/color.py:103 on `dists`). */
+int vp_inrange_f32(vp_ctx* ctx, const float* src_host, size_t src_stride_bytes, int w, int h, float lo,
+                   float hi, uint8_t* dst_host);
+
+/* utils/color.py:66-103 `thresh_color_distance` arithmetic: d2 = sum_c wts[c]*(f32(p_c)-color[c])^2
+ * in float32, channels in order, channel c skipped when bit c of skipmask is set.
+ * dist2_out ((h,w) f32) and sqrt_out ((h,w) u8 = uint8(sqrt(d2))) may each be NULL. */
+int vp_color_distance_u8(vp_ctx* ctx, const uint8_t* const* planes_host, int w, int h, const float* color,
+                         const float* wts, int skipmask, float* dist2_out_host, uint8_t* sqrt_out_host);
+/* utils/transform.py:27-77 `elliptic_kernel` / `rect_kernel` (cv2.getStructuringElement):
+ * out is (kh,kw) 0/1.  Integer geometry on the host, no device needed. */
+int vp_structuring_element(int shape, int kw, int kh, uint8_t* out);
+
+/* utils/transform.py:80-164 erode / dilate / morph_remove_noise / morph_close_holes /
+ * morph_borders and modules/preprocessor.py:120-129 (cv2.erode / dilate / morphologyEx):
+ * src/dst (h,w,cn) tightly packed, cn in 1..4; kernel (kh,kw) non-zero = member, NULL = 3x3 rect;
+ * anchor (-1,-1) = centre; border = cv2 default (outside never wins). */
+int vp_morph_u8(vp_ctx* ctx, int op, const uint8_t* src_host, int w, int h, int cn, const uint8_t* kernel,
+                int kw, int kh, int anchor_x, int anchor_y, int iterations, uint8_t* dst_host);
+
+/* North-star CCL (replaces the cv2.findContours stage of utils/feature.py:5-40 with labels;
+ * semantics of cv2.connectedComponentsWithStats(mask, 8, CV_32S)): non-zero = foreground,
+ * 8-connectivity.  labels (h,w) i32 may be NULL.  stats (max_labels,5) i32 rows
+ * [left, top, width, height, area] and centroids (max_labels,2) f64, row 0 = background; rows
+ * beyond max_labels are dropped but *nlabels is always the true count (incl. background). */
+int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride, int w, int h, int numbering,
+              int32_t* labels_host, int32_t* stats_host, double* centroids_host, int max_labels,
+              int32_t* nlabels);
+
+/* ---- fused, batched, device-resident chain -------------------------------------------- */
+
+#define VP_CHAIN_MAX_MORPH 8
+typedef struct vp_chain_desc {
+    int32_t width, height;
+    int32_t color_mode;            /* VP_BGR2LAB, VP_BGR2HSV or VP_BGR2GRAY */
+    int32_t lo[3], hi[3];          /* inclusive per-channel bounds on the converted image */
+    int32_t n_morph;               /* 0..VP_CHAIN_MAX_MORPH ops applied in order */
+    int32_t morph_op[VP_CHAIN_MAX_MORPH];   /* VP_MORPH_ERODE/DILATE/OPEN/CLOSE */
+    int32_t morph_kw[VP_CHAIN_MAX_MORPH];   /* all-ones (rect) kernels, anchor = centre */
+    int32_t morph_kh[VP_CHAIN_MAX_MORPH];
+    int32_t morph_iter[VP_CHAIN_MAX_MORPH];
+    int32_t ccl;                   /* 0 = none, 1 = label the cleaned mask, 2 = the threshold mask */
+    int32_t numbering;             /* VP_CCL_BLOCK2X2 or VP_CCL_PIXEL */
+    int32_t max_labels;            /* stats/centroid rows per frame, incl. background row 0 */
+} vp_chain_desc;
+
+typedef struct vp_chain_buffers {  /* device pointers; any output may be NULL */
+    const uint8_t* bgr;            /* (n,h,w,3) */
+    uint8_t* threshed;             /* (n,h,w) result of inRange — modules/red_buoy.py:23-28 */
+    uint8_t* cleaned;              /* (n,h,w) after the morphology ops — red_buoy.py:31-34 */
+    int32_t* labels;               /* (n,h,w) */
+    int32_t* stats;                /* (n,max_labels,5) */
+    double* centroids;             /* (n,max_labels,2) */
+    int32_t* nlabels;              /* (n) */
+} vp_chain_buffers;
+
+/* Enqueues the whole chain for n frames on the context's stream and returns without
+ * synchronising.  This is the hot path bench.py times (one call = one "step"). */
+int vp_chain_run(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* dev, int n_frames);
+/* Same with host buffers: H2D, chain, D2H, synchronised on return. */
+int vp_chain_run_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* host, int n_frames);
+/* Algorithmic HBM bytes one vp_chain_run call moves (3 B/px read + 1 B/px per mask
+ * written + 4 B/px labels), for roofline accounting. */
+uint64_t vp_chain_algorithmic_bytes(const vp_chain_desc* desc, const vp_chain_buffers* bufs, int n_frames);
+
+/* ---- device memory helpers (so a host program needs no HIP binding of its own) --------- */
+int vp_dev_alloc(vp_ctx* ctx, size_t bytes, void** dev_ptr);
+int vp_dev_free(vp_ctx* ctx, void* dev_ptr);
+int vp_memcpy_h2d(vp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
+int vp_memcpy_d2h(vp_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP_H */

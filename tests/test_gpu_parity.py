@@ -1,0 +1,322 @@
+"""GPU parity: every operator of the hot path, called through the C ABI (libvp.so via the `vision`
+mirror), bit-exact against the CPU oracle on the same seeded inputs.  Integer / byte / index work
+=> exact equality; the only float op (colour distance, float32) is also compared exactly because
+both sides perform the same IEEE operations in the same order."""
+import numpy as np
+import pytest
+
+import frames as F
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(1, 1), (3, 5), (7, 64), (17, 63), (33, 65), (64, 128), (48, 200), (101, 257)]
+
+
+def _rand_bgr(rng, h, w):
+    return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def test_tables_match_oracle(vp, oracle):
+    g, c, s, hd, lc = vp.get_tables()
+    og, oc, os_, oh, olc = oracle.tables()
+    assert np.array_equal(g, og) and np.array_equal(c, oc)
+    assert np.array_equal(s, os_) and np.array_equal(hd, oh) and np.array_equal(lc, olc)
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_cvt_color(vp, oracle, h, w):
+    from vision.utils import color
+    rng = np.random.default_rng(h * 1000 + w)
+    img = _rand_bgr(rng, h, w)
+    lab, (l, a, b) = color.bgr_to_lab(img)
+    ref = oracle.bgr2lab(img)
+    assert np.array_equal(lab, ref)
+    assert np.array_equal(np.dstack([l, a, b]), ref)
+    hsv, planes = color.bgr_to_hsv(img)
+    ref = oracle.bgr2hsv(img)
+    assert np.array_equal(hsv, ref) and np.array_equal(np.dstack(planes), ref)
+    gray, (g0,) = color.bgr_to_gray(img)
+    assert np.array_equal(gray, oracle.bgr2gray(img)) and np.array_equal(g0, gray)
+    back, _ = color.gray_to_bgr(gray)
+    assert np.array_equal(back, oracle.gray2bgr(gray))
+
+
+def test_cvt_color_exhaustive_slices(vp, oracle):
+    """All 2^24 colours are too many for the oracle in seconds; cover every (b,g) x 8 r-values and the
+    grey axis plus the full gamma / cbrt table index range."""
+    from vision.utils import color
+    b, g = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    for r in (0, 1, 37, 128, 200, 254, 255):
+        img = np.dstack([b, g, np.full_like(b, r)])
+        assert np.array_equal(color.bgr_to_lab(img)[0], oracle.bgr2lab(img))
+        assert np.array_equal(color.bgr_to_hsv(img)[0], oracle.bgr2hsv(img))
+
+
+def test_cvt_color_strided_view(vp, oracle):
+    from vision.utils import color
+    rng = np.random.default_rng(5)
+    big = _rand_bgr(rng, 40, 90)
+    view = big[3:30, 7:71]
+    assert np.array_equal(color.bgr_to_lab(view)[0], oracle.bgr2lab(np.ascontiguousarray(view)))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_inrange(vp, oracle, h, w):
+    from vision.utils import color
+    rng = np.random.default_rng(h * 77 + w)
+    img = _rand_bgr(rng, h, w)
+    for lo, hi in [((10, 20, 60), (30, 100, 255)), ((0, 0, 0), (255, 255, 255)), ((200, 0, 0), (100, 255, 255)),
+                   ((-5, 10, 10), (300, 260, 250))]:
+        assert np.array_equal(color.range_threshold(img, np.array(lo), np.array(hi)), oracle.inrange(img, lo, hi))
+    ch = img[:, :, 1]
+    for lo, hi in [(150, 255), (0, 255), (0, 0), (255, 255), (200, 100), (-3, 90), (90, 1000), (149.5, 150.5)]:
+        exp = oracle.inrange(np.ascontiguousarray(ch), int(np.rint(lo)), int(np.rint(hi)))
+        assert np.array_equal(color.range_threshold(ch, lo, hi), exp)
+    f = rng.normal(0, 100, (h, w)).astype(np.float32)
+    assert np.array_equal(color.range_threshold(f, 0, 55.5), oracle.inrange(f, 0.0, 55.5))
+
+
+@pytest.mark.parametrize("h,w", [(5, 7), (64, 64), (33, 130)])
+def test_thresh_color_distance(vp, oracle, h, w):
+    from vision.utils import color
+    rng = np.random.default_rng(w)
+    img = _rand_bgr(rng, h, w)
+    split = [np.ascontiguousarray(img[:, :, c]) for c in range(3)]
+    for ignore, weights in [([], (1, 1, 1)), ([0], (1, 2, 3)), ([1, 2], (0.5, 1, 1))]:
+        mask, dist = color.thresh_color_distance(split, (100, 150, 60), 70.0, ignore_channels=ignore, weights=weights)
+        wn = np.array([0 if i in ignore else weights[i] for i in range(3)], np.float64) / np.linalg.norm(weights)
+        skip = sum(1 << i for i in ignore)
+        d2, sq = oracle.color_distance(split, (100, 150, 60), wn.astype(np.float32), skip)
+        assert np.array_equal(dist, sq)
+        assert np.array_equal(mask, oracle.inrange(d2, 0.0, float(np.float32(70.0 ** 2))))
+
+
+def test_structuring_elements(vp, oracle):
+    from vision.utils import transform
+    for k in (1, 3, 5, 7, 9, 11, 21, 51, 101):
+        assert np.array_equal(transform.elliptic_kernel(k), oracle.structuring_element(oracle.MORPH_ELLIPSE, k, k))
+    assert np.array_equal(transform.elliptic_kernel(9, 5), oracle.structuring_element(oracle.MORPH_ELLIPSE, 9, 5))
+    assert np.array_equal(transform.rect_kernel(4, 3), np.ones((3, 4), np.uint8))
+    with pytest.raises(ValueError):
+        transform.elliptic_kernel(4)
+    with pytest.raises(ValueError):
+        transform.rect_kernel(0)
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_morph_binary_rect(vp, oracle, h, w):
+    """0/255 masks + rect kernels: the bit-plane LDS path."""
+    from vision.utils import transform as T
+    rng = np.random.default_rng(h * 31 + w)
+    for p in (0.2, 0.5, 0.9):
+        m = F.random_mask(rng, h, w, p)
+        for kx, ky in [(5, 5), (3, 3), (1, 7), (4, 2), (9, 3)]:
+            k = T.rect_kernel(kx, ky)
+            assert np.array_equal(T.erode(m, k), oracle.morph(oracle.ERODE, m, k)), (kx, ky, "erode")
+            assert np.array_equal(T.dilate(m, k), oracle.morph(oracle.DILATE, m, k)), (kx, ky, "dilate")
+            assert np.array_equal(T.morph_remove_noise(m, k), oracle.morph(oracle.OPEN, m, k)), (kx, ky, "open")
+            assert np.array_equal(T.morph_close_holes(m, k), oracle.morph(oracle.CLOSE, m, k)), (kx, ky, "close")
+            assert np.array_equal(T.morph_borders(m, k), oracle.morph(oracle.GRADIENT, m, k)), (kx, ky, "gradient")
+        k = T.rect_kernel(3)
+        assert np.array_equal(T.erode(m, k, iterations=3), oracle.morph(oracle.ERODE, m, k, iterations=3))
+        assert np.array_equal(T.morph_remove_noise(m, k, iterations=2), oracle.morph(oracle.OPEN, m, k, iterations=2))
+
+
+def test_morph_binary_large_kernels(vp, oracle):
+    from vision.utils import transform as T
+    rng = np.random.default_rng(9)
+    m = F.random_mask(rng, 150, 300, 0.97)
+    for kx, ky in [(71, 5), (5, 71), (101, 101), (129, 3)]:
+        k = T.rect_kernel(kx, ky)
+        assert np.array_equal(T.erode(m, k), oracle.morph(oracle.ERODE, m, k, fast=True))
+        assert np.array_equal(T.morph_close_holes(255 - m, k), oracle.morph(oracle.CLOSE, 255 - m, k, fast=True))
+
+
+@pytest.mark.parametrize("h,w", [(9, 11), (40, 70), (64, 64)])
+def test_morph_grey_and_ellipse(vp, oracle, h, w):
+    """grey-level images, ellipse kernels, 3 channels (modules/preprocessor.py:120-129): generic path."""
+    from vision.utils import transform as T
+    rng = np.random.default_rng(h + w)
+    g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    c3 = _rand_bgr(rng, h, w)
+    for img in (g, c3):
+        for k in (T.elliptic_kernel(3), T.elliptic_kernel(7), T.elliptic_kernel(11, 5), T.rect_kernel(5), T.rect_kernel(2, 3)):
+            assert np.array_equal(T.erode(img, k), oracle.morph(oracle.ERODE, img, k))
+            assert np.array_equal(T.dilate(img, k), oracle.morph(oracle.DILATE, img, k))
+        k = T.elliptic_kernel(5)
+        assert np.array_equal(T.erode(img, k, iterations=2), oracle.morph(oracle.ERODE, img, k, iterations=2))
+        assert np.array_equal(T.morph_remove_noise(img, k), oracle.morph(oracle.OPEN, img, k))
+        assert np.array_equal(T.morph_borders(img, k), oracle.morph(oracle.GRADIENT, img, k))
+    assert np.array_equal(T.erode(g, None), oracle.morph(oracle.ERODE, g, None))
+
+
+def _check_ccl(vp, oracle, m, numbering):
+    from vision.utils import feature
+    n, lab, st, ce = feature.connected_components(m, numbering=numbering, max_labels=m.size // 1 + 2)
+    on, olab, ost, oce = oracle.ccl(m, block=numbering)
+    assert n == on
+    assert np.array_equal(lab, olab)
+    assert np.array_equal(st, ost)
+    assert np.array_equal(ce.view(np.uint64), oce.view(np.uint64))  # bitwise, NaN included
+
+
+@pytest.mark.parametrize("h,w", SIZES + [(2, 2), (1, 130), (130, 1), (65, 129)])
+@pytest.mark.parametrize("numbering", [2, 1])
+def test_ccl_random(vp, oracle, h, w, numbering):
+    rng = np.random.default_rng(h * 13 + w + numbering)
+    for p in (0.05, 0.3, 0.5, 0.6, 0.95):
+        _check_ccl(vp, oracle, F.random_mask(rng, h, w, p), numbering)
+
+
+def test_ccl_edge_cases(vp, oracle):
+    for m in (np.zeros((10, 70), np.uint8), np.full((10, 70), 255, np.uint8), np.full((64, 64), 7, np.uint8)):
+        _check_ccl(vp, oracle, m, 2)
+    # checkerboards: the worst case for component count, and diagonal 8-connectivity
+    yy, xx = np.mgrid[0:37, 0:131]
+    _check_ccl(vp, oracle, (((yy + xx) % 2) * 255).astype(np.uint8), 2)
+    _check_ccl(vp, oracle, (((yy % 2 == 0) & (xx % 2 == 0)) * 255).astype(np.uint8), 2)
+    # spiral / U shapes force late merges
+    m = np.zeros((40, 140), np.uint8)
+    m[2:38, 5] = 255; m[2:38, 130] = 255; m[37, 5:131] = 255; m[2, 20:110] = 255; m[2:30, 20] = 255
+    _check_ccl(vp, oracle, m, 2)
+    _check_ccl(vp, oracle, m, 1)
+    # numbering differs between block and pixel order: A first appears at (1,0), B at (0,10)
+    m = np.zeros((4, 16), np.uint8); m[1, 0] = 255; m[0, 10] = 255
+    _check_ccl(vp, oracle, m, 2)
+    _check_ccl(vp, oracle, m, 1)
+
+
+def test_ccl_blobs(vp, oracle):
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:270, 0:480]
+    m = np.zeros((270, 480), np.uint8)
+    for _ in range(25):
+        cx, cy, r = rng.uniform(0, 480), rng.uniform(0, 270), rng.uniform(3, 40)
+        m[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 255
+    _check_ccl(vp, oracle, m, 2)
+
+
+def test_ccl_max_labels_truncation(vp, oracle):
+    from vision.utils import feature
+    rng = np.random.default_rng(4)
+    m = F.random_mask(rng, 50, 90, 0.2)
+    n, lab, st, ce = feature.connected_components(m, max_labels=5)
+    on, olab, ost, oce = oracle.ccl(m, block=2)
+    assert n == on and n > 5 and st.shape == (5, 5)
+    assert np.array_equal(lab, olab) and np.array_equal(st, ost[:5]) and np.array_equal(ce, oce[:5])
+
+
+CHAINS = [
+    ("red_buoy", 0, (0, 150, 0), (255, 255, 255), [(2, 5, 5), (3, 5, 5)]),
+    ("bins", 1, (10, 20, 60), (30, 100, 255), [(2, 5, 5)]),
+    ("gray", 2, (90, 0, 0), (160, 255, 255), [(3, 3, 3), (0, 3, 1)]),
+    ("lab_all", 0, (20, 100, 90), (200, 160, 170), []),
+]
+
+
+def _oracle_chain(oracle, frame, mode, lo, hi, morph, block):
+    th = None
+    conv = {0: oracle.bgr2lab, 1: oracle.bgr2hsv}.get(mode)
+    if mode == 2:
+        th = oracle.inrange(oracle.bgr2gray(frame), lo[0], hi[0])
+    else:
+        th = oracle.inrange(conv(frame), lo, hi)
+    cl = th
+    for op, kw, kh in morph:
+        cl = oracle.morph(op, cl, np.ones((kh, kw), np.uint8), fast=True)
+    n, lab, st, ce = oracle.ccl(cl, block=block)
+    return th, cl, n, lab, st, ce
+
+
+@pytest.mark.parametrize("name,mode,lo,hi,morph", CHAINS)
+@pytest.mark.parametrize("h,w", [(72, 128), (45, 100), (64, 192)])
+def test_chain_small(vp, oracle, name, mode, lo, hi, morph, h, w):
+    """fused batched chain vs the oracle, flat (w % 64 == 0) and generic-row kernels."""
+    from vision.utils.chain import run_chain
+    gen = {"red_buoy": F.s1_buoy, "bins": F.s2_bins}.get(name, F.s3_noise)
+    frames = np.stack([gen(i, w, h) for i in range(3)] + [F.s3_noise(9, w, h)])
+    out = run_chain(frames, mode, lo, hi, morph, ccl=1, numbering=2, max_labels=h * w)
+    for i in range(len(frames)):
+        th, cl, n, lab, st, ce = _oracle_chain(oracle, frames[i], mode, lo, hi, morph, 2)
+        assert np.array_equal(out["threshed"][i], th), (name, i)
+        assert np.array_equal(out["cleaned"][i], cl), (name, i)
+        assert out["nlabels"][i] == n
+        assert np.array_equal(out["labels"][i], lab)
+        assert np.array_equal(out["stats"][i][:n], st)
+        assert np.array_equal(out["centroids"][i][:n].view(np.uint64), ce.view(np.uint64))
+
+
+def test_chain_ccl_on_threshold_mask(vp, oracle):
+    """modules/red_buoy.py:38 runs its contour stage on `threshed`, not `cleaned`: ccl = 2."""
+    from vision.utils.chain import run_chain
+    frames = np.stack([F.s1_buoy(i, 128, 72) for i in range(2)])
+    out = run_chain(frames, 0, (0, 150, 0), (255, 255, 255), [(2, 5, 5), (3, 5, 5)], ccl=2, max_labels=128 * 72)
+    for i in range(2):
+        th, cl, _, _, _, _ = _oracle_chain(oracle, frames[i], 0, (0, 150, 0), (255, 255, 255), [(2, 5, 5), (3, 5, 5)], 2)
+        n, lab, st, ce = oracle.ccl(th, block=2)
+        assert np.array_equal(out["cleaned"][i], cl)
+        assert out["nlabels"][i] == n and np.array_equal(out["labels"][i], lab)
+
+
+def test_chain_full_size_properties(vp, oracle):
+    """1080p (BASELINE config 2): one frame against the oracle end to end, plus size-independent
+    properties on a batch: open/close idempotence, cleaned == operator-API result, label image
+    consistent with stats (areas, bounding boxes), flat frames."""
+    from vision.utils.chain import run_chain
+    from vision.utils import transform as T
+    frames = np.stack([F.s1_buoy(0), F.s1_buoy(1), F.s4_flat(0), F.s4_flat(255)])
+    morph = [(2, 5, 5), (3, 5, 5)]
+    out = run_chain(frames, 0, (0, 150, 0), (255, 255, 255), morph, ccl=1, max_labels=4096)
+    th, cl, n, lab, st, ce = _oracle_chain(oracle, frames[0], 0, (0, 150, 0), (255, 255, 255), morph, 2)
+    assert np.array_equal(out["threshed"][0], th) and np.array_equal(out["cleaned"][0], cl)
+    assert out["nlabels"][0] == n and np.array_equal(out["labels"][0], lab)
+    assert np.array_equal(out["stats"][0][:n], st) and np.array_equal(out["centroids"][0][:n], ce)
+    assert n > 3
+    k = T.rect_kernel(5)
+    for i in range(len(frames)):
+        c = out["cleaned"][i]
+        assert np.array_equal(T.morph_close_holes(c, k), c)          # closing is idempotent
+        l = out["labels"][i]
+        nl = int(out["nlabels"][i])
+        assert np.array_equal(l > 0, c > 0)
+        assert l.max() == nl - 1
+        areas = np.bincount(l.ravel(), minlength=nl)
+        assert np.array_equal(areas, out["stats"][i][:nl, 4])
+    assert out["nlabels"][2] == 1 and out["nlabels"][3] == 1   # all-zero / all-255 LAB-a frames select nothing
+
+
+def test_device_resident_chain_matches_host_chain(vp):
+    """vp_chain_run (device pointers, what bench.py times) == vp_chain_run_host."""
+    import ctypes as C
+    from vision.utils.chain import run_chain
+    frames = np.stack([F.s1_buoy(i, 256, 144) for i in range(5)])
+    n, h, w, _ = frames.shape
+    morph = [(2, 5, 5), (3, 5, 5)]
+    ref = run_chain(frames, 0, (0, 150, 0), (255, 255, 255), morph, max_labels=64)
+    ctx = vp.default_context()
+    L = vp.lib()
+
+    def dev(nbytes):
+        p = C.c_void_p()
+        vp.check(L.vp_dev_alloc(ctx.handle, nbytes, C.byref(p)))
+        return p
+    npx = n * h * w
+    bufs = vp.ChainBuffers()
+    bufs.bgr = dev(npx * 3).value
+    bufs.threshed, bufs.cleaned, bufs.labels = dev(npx).value, dev(npx).value, dev(npx * 4).value
+    bufs.stats, bufs.centroids, bufs.nlabels = dev(n * 64 * 20).value, dev(n * 64 * 16).value, dev(n * 4).value
+    vp.check(L.vp_memcpy_h2d(ctx.handle, bufs.bgr, frames.ctypes.data, npx * 3))
+    desc = vp.make_chain_desc(w, h, 0, (0, 150, 0), (255, 255, 255), morph, 1, 2, 64)
+    for _ in range(2):  # twice: workspace reuse must not leak state between steps
+        ctx.chain_run(desc, bufs, n)
+    ctx.synchronize()
+    lab = np.empty((n, h, w), np.int32)
+    st = np.empty((n, 64, 5), np.int32)
+    cl = np.empty((n, h, w), np.uint8)
+    vp.check(L.vp_memcpy_d2h(ctx.handle, lab.ctypes.data, bufs.labels, npx * 4))
+    vp.check(L.vp_memcpy_d2h(ctx.handle, st.ctypes.data, bufs.stats, n * 64 * 20))
+    vp.check(L.vp_memcpy_d2h(ctx.handle, cl.ctypes.data, bufs.cleaned, npx))
+    assert np.array_equal(lab, ref["labels"]) and np.array_equal(st, ref["stats"]) and np.array_equal(cl, ref["cleaned"])
+    assert L.vp_chain_algorithmic_bytes(C.byref(desc), C.byref(bufs), n) == npx * 9
+    for p in (bufs.bgr, bufs.threshed, bufs.cleaned, bufs.labels, bufs.stats, bufs.centroids, bufs.nlabels):
+        vp.check(L.vp_dev_free(ctx.handle, p))
