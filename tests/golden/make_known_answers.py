@@ -1,0 +1,32 @@
+"""Writes tests/golden/known_answers.json: the published OpenCV input/output pairs quoted in
+SURVEY.md Appendix A (A1 Lab, A2 HSV, A3 grey, A5 ellipse kernels) plus hand-derived morphology /
+CCL cases whose expected values follow from the definitions alone.  No reference code is run (the
+reference has no tests or fixtures and cv2 is absent); this script only records constants."""
+import json
+import os
+
+known = {
+    "source": "SURVEY.md Appendix A (widely published cv2 outputs); hand-derived cases marked 'by definition'",
+    "bgr2lab": [  # (B,G,R) -> (L,a,b), cv2.cvtColor(COLOR_BGR2LAB) on uint8
+        [[255, 255, 255], [255, 128, 128]], [[0, 0, 0], [0, 128, 128]], [[0, 0, 255], [136, 208, 195]],
+        [[0, 255, 0], [224, 42, 211]], [[255, 0, 0], [82, 207, 20]], [[128, 128, 128], [137, 128, 128]]],
+    "bgr2hsv": [  # (B,G,R) -> (H,S,V), COLOR_BGR2HSV uint8 (H in [0,180))
+        [[0, 0, 255], [0, 255, 255]], [[0, 255, 0], [60, 255, 255]], [[255, 0, 0], [120, 255, 255]],
+        [[255, 255, 255], [0, 0, 255]], [[0, 0, 0], [0, 0, 0]], [[0, 128, 255], [15, 255, 255]],
+        [[255, 0, 128], [135, 255, 255]], [[140, 170, 200], [15, 76, 200]]],
+    "bgr2gray": [[[255, 255, 255], 255], [[0, 0, 255], 76], [[0, 255, 0], 150], [[255, 0, 0], 29], [[0, 0, 0], 0]],
+    "lab_coeffs": [1777, 1541, 778, 871, 2929, 296, 73, 448, 3575],
+    "ellipse5": ["00100", "11111", "11111", "11111", "00100"],
+    "ellipse7": ["0001000", "0111110", "1111111", "1111111", "1111111", "0111110", "0001000"],
+    "ellipse3": ["010", "111", "010"],
+    "inrange": {"values": [0, 1, 149, 150, 151, 254, 255], "lo": 150, "hi": 255, "expect": [0, 0, 0, 255, 255, 255, 255]},
+    # by definition: 7x7 mask with a 3x3 block; erode 3x3 leaves its centre, dilate 3x3 grows it to 5x5,
+    # the image border never wins (a full image stays full under erosion)
+    "morph": {"block": [2, 2, 3, 3], "size": [7, 7]},
+    # by definition (Appendix A8): two single pixels, A at (row 1, col 0), B at (row 0, col 10):
+    # 2x2-block raster order labels A=1, B=2; pixel raster order labels B=1, A=2
+    "ccl_numbering": {"size": [4, 16], "A": [1, 0], "B": [0, 10], "block2x2": {"A": 1, "B": 2}, "pixel": {"A": 2, "B": 1}},
+}
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "known_answers.json"), "w") as f:
+    json.dump(known, f, indent=1)
