@@ -164,8 +164,8 @@ int vp_profile_end(vp_ctx* ctx, double* total_ms, int32_t* launches)
 
 const char* vp_profile_kernel_name(int id)
 {
-    static const char* names[VP_PROF_KERNELS] = {"k_color_thresh", "k_morph_bits", "k_ccl_init", "k_ccl_link", "k_ccl_flatten",
-                                                  "k_ccl_rank", "k_ccl_stats", "k_ccl_final", "k_ccl_write", "other"};
+    static const char* names[VP_PROF_KERNELS] = {"k_color_thresh", "k_morph_bits", "k_ccl_local", "k_ccl_boundary", "k_ccl_flatten", "k_ccl_rank",
+                                                  "k_ccl_bg", "k_ccl_stats", "k_ccl_final", "k_ccl_write", "memset", "other"};
     return (id >= 0 && id < VP_PROF_KERNELS) ? names[id] : "?";
 }
 
@@ -600,7 +600,7 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, 
     TAKE(d_nl, int32_t*, 4);
     vp_ccl_ws ws;
     vp_ccl_ws_carve(ctx, w, h, 1, max_labels, &ws);
-    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
     VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
     VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
     VP_TRY(vpk_ccl(ctx, d_bits, w, h, 1, numbering, ws, labels ? d_labels : nullptr, d_stats, d_cent, max_labels, d_nl));
@@ -675,7 +675,7 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
     if (d->ccl) {
         vp_ccl_ws ws;
         vp_ccl_ws_carve(ctx, w, h, n, d->max_labels, &ws);
-        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
         VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
                        b->nlabels ? b->nlabels : d_nl));
     }

@@ -11,21 +11,26 @@
 // the smaller, so a component's root is its smallest id and cv2's label for the component is
 // simply the rank of that root among all roots.  Ranks come from a bitmap of roots + popcount
 // prefix — no sort.  The label image (4 B/px, the dominant HBM traffic of the whole chain) is
-// written exactly once, by a streaming kernel that looks up one label per segment.
+// written exactly once, by a streaming kernel.
 //
-//   k_ccl_init     parent[id] = id for every segment            (sparse)
-//   k_ccl_link     unions: across word boundaries in a row, and with the row above (8-conn)
-//   k_ccl_flatten  parent[id] = root(id); mark roots in the bitmap
-//   k_ccl_rank     per frame: exclusive popcount prefix over the bitmap, nlabels, zero accumulators
-//   k_ccl_stats    seglabel[id] = rank+1; wave-aggregated atomics into per-label accumulators
+//   k_ccl_local    per 32-row strip, in LDS: segments -> compact ids -> union-find (across word boundaries in a
+//                  row and with the row above, 8-conn) -> parent[id] = smallest id of the strip-local component;
+//                  clears the strip's slice of the root bitmap and marks the strip-local representatives
+//   k_ccl_boundary unions between the first row of a strip and the row above it (global CAS union-find);
+//                  a root that gets linked loses its bit in the bitmap, so the bitmap ends up = exact roots
+//   (k_ccl_init + k_ccl_link: the same in global memory only, fallback for very wide images)
+//   k_ccl_rank     per frame: exclusive popcount prefix over the bitmap, nlabels, zero accumulators; extra blocks
+//                  of the same launch reduce the background row (label 0) without atomics
+//   k_ccl_stats    label = rank(root)+1 per segment -> seglabel[id], wordlabel[word]; per-block LDS aggregation,
+//                  then one set of global atomics per (block, label)
 //   k_ccl_final    accumulators -> stats (i32 x5) + centroids (f64 x2)
-//   k_ccl_write    bits + seglabel -> int32 label image (coalesced 16-B stores)
+//   k_ccl_write    bits + wordlabel (+ seglabel for words holding several segments) -> int32 label image
 #include "vp_internal.h"
 #include <limits.h>
 
 struct ccl_geom {
     int w, h, ww, wb, numbering;
-    u32 nids;   // multiple of 32
+    u32 nids;   // multiple of 128
     u32 nw32;   // nids / 32
 };
 
@@ -36,16 +41,22 @@ struct ccl_acc {   // 48 B
     u64 sx, sy;
 };
 
+struct contrib { u32 area; int minx, maxx, miny, maxy; u32 pad; u64 sx, sy; };
+
+#define RK_PARTS 8
+#define BG_PARTS 8
+
 size_t vp_ccl_nids(int w, int h)
 {
     const size_t wb = (size_t)(w + 1) / 2, hb = (size_t)(h + 1) / 2;
-    return (2 * hb * wb + 31) / 32 * 32;
+    return (2 * hb * wb + 127) / 128 * 128;
 }
 
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
 {
     const size_t nids = vp_ccl_nids(w, h);
-    return vp_align(nids * 4 * n) * 2 + vp_align(nids / 8 * n) * 2 + vp_align(sizeof(ccl_acc) * (size_t)max_labels * n) + 1024;
+    return vp_align(nids * 4 * n) * 2 + vp_align(nids / 8 * n) * 2 + vp_align(sizeof(ccl_acc) * (size_t)max_labels * n) +
+           vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) + 2048;
 }
 
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out)
@@ -56,6 +67,8 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
     out->prefix = (u32*)vp_ws_take(ctx, nids / 8 * n);
     out->acc = vp_ws_take(ctx, sizeof(ccl_acc) * (size_t)max_labels * n);
+    out->wordlabel = (u32*)vp_ws_take(ctx, (size_t)n * h * vp_ww(w) * 4);
+    out->bgpart = vp_ws_take(ctx, sizeof(contrib) * BG_PARTS * (size_t)n);
 }
 
 __device__ __forceinline__ u32 seg_id(const ccl_geom& G, int y, int x)
@@ -80,6 +93,7 @@ __device__ __forceinline__ int run_end(u64 w, int b)
     const u64 t = ~(w >> b);  // bit 0 is clear
     return t ? b + (__ffsll((long long)t) - 1) - 1 : 63;
 }
+__device__ __forceinline__ u32 nstarts(u64 w) { return (u32)__popcll(w & ~(w << 1)); }
 
 __device__ __forceinline__ u32 ld_rlx(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_rlx(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -97,59 +111,32 @@ __device__ __forceinline__ u32 uf_find_halve(u32* p, u32 x)
         x = g;
     }
 }
-__device__ __forceinline__ u32 uf_find_ro(const u32* p, u32 x)
-{
-    for (;;) {
-        const u32 q = ld_rlx(p + x);
-        if (q == x) return x;
-        x = q;
-    }
-}
-__device__ __forceinline__ void uf_unite(u32* p, u32 a, u32 b)
+// links the larger root under the smaller; the absorbed root loses its bit in the root bitmap
+__device__ __forceinline__ void uf_unite(u32* p, u32* flags, u32 a, u32 b)
 {
     for (;;) {
         a = uf_find_halve(p, a);
         b = uf_find_halve(p, b);
         if (a == b) return;
         if (a < b) { const u32 t = a; a = b; b = t; }
-        const u32 old = atomicCAS(p + a, a, b);   // link the larger root under the smaller
-        if (old == a) return;
+        const u32 old = atomicCAS(p + a, a, b);
+        if (old == a) { atomicAnd(flags + (a >> 5), ~(1u << (a & 31))); return; }
         a = old;
     }
 }
 
-// grid: (ceil(h*ww/256), n)
-__global__ __launch_bounds__(256) void k_ccl_init(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent)
+// Unions of the segments of word (y, j) in global memory.  horiz: with the segment ending the previous
+// word of the row; vert: with the 8-connected segments of row y-1.  A contact through the left/right
+// neighbour word of the row above is skipped when the word straight above already bridges it (that
+// row's own horizontal union connects them).
+__device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, const ccl_geom& G, u32* p, u32* flags, int y, int j,
+                                                 int idx, u64 w, bool horiz, bool vert)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= G.h * G.ww) return;
-    const u64 w = bits[(size_t)blockIdx.y * G.h * G.ww + idx];
-    if (!w) return;
-    const int y = idx / G.ww, j = idx - y * G.ww;
-    u32* p = parent + (size_t)blockIdx.y * G.nids;
-    u64 starts = w & ~(w << 1);
-    while (starts) {
-        const int s = __ffsll((long long)starts) - 1;
-        starts &= starts - 1;
-        const u32 id = seg_id(G, y, 64 * j + s);
-        p[id] = id;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= G.h * G.ww) return;
-    const u64* fb = bits + (size_t)blockIdx.y * G.h * G.ww;
-    const u64 w = fb[idx];
-    if (!w) return;
-    const int y = idx / G.ww, j = idx - y * G.ww;
-    u32* p = parent + (size_t)blockIdx.y * G.nids;
-    if ((w & 1ull) && j > 0) {
+    if (horiz && (w & 1ull) && j > 0) {
         const u64 prev = fb[idx - 1];
-        if (prev >> 63) uf_unite(p, seg_id(G, y, 64 * j), seg_id(G, y, 64 * (j - 1) + run_start(prev, 63)));
+        if (prev >> 63) uf_unite(p, flags, seg_id(G, y, 64 * j), seg_id(G, y, 64 * (j - 1) + run_start(prev, 63)));
     }
-    if (y == 0) return;
+    if (!vert || y == 0) return;
     const u64 um = fb[idx - G.ww];
     const u64 ul = j > 0 ? fb[idx - G.ww - 1] : 0ull;
     const u64 ur = j + 1 < G.ww ? fb[idx - G.ww + 1] : 0ull;
@@ -165,16 +152,17 @@ __global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, 
         while (c) {
             const int b = __ffsll((long long)c) - 1;
             const int st = run_start(um, b), en = run_end(um, b);
-            uf_unite(p, me, seg_id(G, y - 1, 64 * j + st));
+            uf_unite(p, flags, me, seg_id(G, y - 1, 64 * j + st));
             c &= ~bit_range(st, en);
         }
-        if ((S & 1ull) && (ul >> 63)) uf_unite(p, me, seg_id(G, y - 1, 64 * (j - 1) + run_start(ul, 63)));
-        if ((S >> 63) && (ur & 1ull)) uf_unite(p, me, seg_id(G, y - 1, 64 * (j + 1)));
+        if ((S & 1ull) && (ul >> 63) && !(um & 1ull)) uf_unite(p, flags, me, seg_id(G, y - 1, 64 * (j - 1) + run_start(ul, 63)));
+        if ((S >> 63) && (ur & 1ull) && !(um >> 63)) uf_unite(p, flags, me, seg_id(G, y - 1, 64 * (j + 1)));
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_flatten(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
-                                                     u32* __restrict__ flags)
+// ---- whole-image global-memory path (fallback for images too wide for the LDS strip kernel) ---------------
+// grid: (ceil(h*ww/256), n); flags zeroed by a memset before k_ccl_init
+__global__ __launch_bounds__(256) void k_ccl_init(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent, u32* __restrict__ flags)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= G.h * G.ww) return;
@@ -188,54 +176,194 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(const u64* __restrict__ bit
         const int s = __ffsll((long long)starts) - 1;
         starts &= starts - 1;
         const u32 id = seg_id(G, y, 64 * j + s);
-        const u32 r = uf_find_ro(p, id);   // read-only walk: nobody else writes p[id] in this kernel
-        if (r == id) atomicOr(f + (r >> 5), 1u << (r & 31));
-        else st_rlx(p + id, r);
+        p[id] = id;
+        atomicOr(f + (id >> 5), 1u << (id & 31));
     }
 }
 
-// one block of 1024 threads per frame
-__global__ __launch_bounds__(1024) void k_ccl_rank(ccl_geom G, const u32* __restrict__ flags, u32* __restrict__ prefix,
-                                                   int32_t* __restrict__ nlabels, ccl_acc* __restrict__ acc, int max_labels)
+__global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent, u32* __restrict__ flags)
 {
-    __shared__ u32 wsum[16];
-    __shared__ u32 total;
-    const int f = blockIdx.x;
-    const u32* fl = flags + (size_t)f * G.nw32;
-    u32* pf = prefix + (size_t)f * G.nw32;
-    const u32 chunk = (G.nw32 + 1023u) / 1024u;
-    const u32 lo = threadIdx.x * chunk;
-    const u32 hi = min(lo + chunk, G.nw32);
-    u32 s = 0;
-    for (u32 i = lo; i < hi; i++) s += __popc(fl[i]);
-    // block exclusive scan of s
-    u32 inc = s;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 t = __shfl_up(inc, d);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 run = 0;
-        for (int k = 0; k < 16; k++) { const u32 t = wsum[k]; wsum[k] = run; run += t; }
-        total = run;
-    }
-    __syncthreads();
-    u32 run = wsum[wv] + inc - s;
-    for (u32 i = lo; i < hi; i++) { pf[i] = run; run += __popc(fl[i]); }
-    const int nl = (int)total + 1;
-    if (threadIdx.x == 0 && nlabels) nlabels[f] = nl;
-    ccl_acc* a = acc + (size_t)f * max_labels;
-    const int nz = min(nl, max_labels);
-    for (int i = threadIdx.x; i < nz; i += 1024) {
-        ccl_acc z;
-        z.area = 0; z.minx = INT_MAX; z.miny = INT_MAX; z.maxx = INT_MIN; z.maxy = INT_MIN; z.pad = 0; z.sx = 0; z.sy = 0;
-        a[i] = z;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= G.h * G.ww) return;
+    const u64* fb = bits + (size_t)blockIdx.y * G.h * G.ww;
+    const u64 w = fb[idx];
+    if (!w) return;
+    const int y = idx / G.ww, j = idx - y * G.ww;
+    global_link_word(fb, G, parent + (size_t)blockIdx.y * G.nids, flags + (size_t)blockIdx.y * G.nw32, y, j, idx, w, true, true);
+}
+
+// ---- strip-local union-find in LDS ------------------------------------------------------------------
+#define CL_ROWS 32
+#define CL_CAP 2048   // segments per strip handled in LDS; denser strips fall back to global memory
+
+__device__ __forceinline__ u32 lds_find(volatile u32* p, u32 x)
+{
+    for (;;) {
+        const u32 q = p[x];
+        if (q == x) return x;
+        const u32 g = p[q];
+        if (g == q) return q;
+        p[x] = g;
+        x = g;
     }
 }
+__device__ __forceinline__ void lds_unite(u32* p, u32 a, u32 b)
+{
+    for (;;) {
+        a = lds_find(p, a);
+        b = lds_find(p, b);
+        if (a == b) return;
+        if (a < b) { const u32 t = a; a = b; b = t; }
+        const u32 old = atomicCAS(p + a, a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// iterate the words of the strip with a division-free (row, column) mapping: 8 rows x 32 columns per pass
+#define CL_FOR_WORDS(r, j, i)                                   \
+    for (int r = threadIdx.x >> 5; r < nrows; r += 8)           \
+        for (int j = threadIdx.x & 31, i = r * ww + j; j < ww; j += 32, i += 32)
+
+// One block per (frame, strip of CL_ROWS rows).
+// dynamic LDS: lbits[nw] u64 | wbase[nw] u32 | lparent[CAP] | lgid[CAP] | lmin[CAP]
+__global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
+                                                   u32* __restrict__ flags, int strips)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 cl_lds[];
+    __shared__ u32 wsum[4];
+    __shared__ u32 total_s;
+    const int ww = G.ww;
+    const int frame = blockIdx.x / strips, strip = blockIdx.x - frame * strips;
+    const int y0 = strip * CL_ROWS;
+    const int nrows = min(CL_ROWS, G.h - y0);
+    const int nwmax = CL_ROWS * ww;
+    u64* lbits = cl_lds;
+    u32* wbase = reinterpret_cast<u32*>(cl_lds + nwmax);
+    u32* lparent = wbase + (nwmax + 2);
+    u32* lgid = lparent + CL_CAP;
+    u32* lmin = lgid + CL_CAP;
+    const u64* fb = bits + (size_t)frame * G.h * ww;
+    u32* gp = parent + (size_t)frame * G.nids;
+    u32* gf = flags + (size_t)frame * G.nw32;
+    const int tid = threadIdx.x;
+
+    // this strip's slice of the root bitmap (ids of 32 rows = a multiple of 32 ids, so slices never share a word)
+    {
+        const u32 rows_ids = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;   // ids per row pair / per row
+        const u32 lo = (G.numbering == VP_CCL_BLOCK2X2) ? (u32)(y0 >> 1) * rows_ids : (u32)y0 * rows_ids;
+        const u32 w0 = lo >> 5;
+        const u32 w1 = (strip == strips - 1) ? G.nw32 : ((G.numbering == VP_CCL_BLOCK2X2) ? ((u32)((y0 + CL_ROWS) >> 1) * rows_ids) >> 5
+                                                                                         : ((u32)(y0 + CL_ROWS) * rows_ids) >> 5);
+        for (u32 i = w0 + tid; i < w1; i += 256) gf[i] = 0u;
+    }
+    u32 cnt = 0;
+    CL_FOR_WORDS(r, j, i) { const u64 w = fb[(size_t)(y0 + r) * ww + j]; lbits[i] = w; cnt += nstarts(w); }
+    // block exclusive scan of the per-thread segment counts
+    u32 inc = cnt;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    if (tid == 0) { u32 run = 0; for (int k = 0; k < 4; k++) { const u32 t = wsum[k]; wsum[k] = run; run += t; } total_s = run; }
+    __syncthreads();
+    const u32 S = total_s;
+    if (S == 0) return;
+    if (S > CL_CAP) {
+        // dense strip: same algorithm in global memory, restricted to this strip's rows
+        CL_FOR_WORDS(r, j, i) {
+            u64 st = lbits[i] & ~(lbits[i] << 1);
+            while (st) {
+                const int s = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                const u32 id = seg_id(G, y0 + r, 64 * j + s);
+                st_rlx(gp + id, id);
+                atomicOr(gf + (id >> 5), 1u << (id & 31));
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        CL_FOR_WORDS(r, j, i) {
+            const u64 w = lbits[i];
+            if (w) global_link_word(fb, G, gp, gf, y0 + r, j, (y0 + r) * ww + j, w, true, r > 0);
+        }
+        return;
+    }
+    {
+        u32 run = wsum[wv] + inc - cnt;
+        CL_FOR_WORDS(r, j, i) {
+            const u64 w = lbits[i];
+            wbase[i] = run;
+            u64 st = w & ~(w << 1);
+            while (st) {
+                const int s = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                lparent[run] = run;
+                lgid[run] = seg_id(G, y0 + r, 64 * j + s);
+                lmin[run] = 0xffffffffu;
+                run++;
+            }
+        }
+    }
+    __syncthreads();
+    CL_FOR_WORDS(r, j, i) {
+        const u64 w = lbits[i];
+        if (!w) continue;
+        const u32 base = wbase[i];
+        if ((w & 1ull) && j > 0 && (lbits[i - 1] >> 63)) lds_unite(lparent, base, wbase[i - 1] + nstarts(lbits[i - 1]) - 1u);
+        if (r == 0) continue;
+        const u64 um = lbits[i - ww];
+        const u64 ul = j > 0 ? lbits[i - ww - 1] : 0ull;
+        const u64 ur = j + 1 < ww ? lbits[i - ww + 1] : 0ull;
+        if (!(um | (ul >> 63) | (ur & 1ull))) continue;
+        const u32 ubase = wbase[i - ww];
+        const u64 ustarts = um & ~(um << 1);
+        u64 rem = w;
+        u32 me = base;
+        while (rem) {
+            const int s = __ffsll((long long)rem) - 1;
+            const int e = run_end(rem, s);
+            const u64 Sg = bit_range(s, e);
+            rem &= ~Sg;
+            u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
+            while (c) {
+                const int b = __ffsll((long long)c) - 1;
+                const int st = run_start(um, b), en = run_end(um, b);
+                lds_unite(lparent, me, ubase + (u32)__popcll(ustarts & ((1ull << st) - 1ull)));
+                c &= ~bit_range(st, en);
+            }
+            if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) lds_unite(lparent, me, wbase[i - ww - 1] + nstarts(ul) - 1u);
+            if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) lds_unite(lparent, me, wbase[i - ww + 1]);
+            me++;
+        }
+    }
+    __syncthreads();
+    for (u32 ci = tid; ci < S; ci += 256) atomicMin(lmin + lds_find(lparent, ci), lgid[ci]);
+    __syncthreads();
+    for (u32 ci = tid; ci < S; ci += 256) {
+        const u32 id = lgid[ci];
+        const u32 m = lmin[lds_find(lparent, ci)];
+        gp[id] = m;
+        if (m == id) atomicOr(gf + (id >> 5), 1u << (id & 31));   // strip-local representative = root candidate
+    }
+}
+
+// vertical unions across strip boundaries: grid (strips - 1, n), block = 64 threads over the words of the row
+__global__ __launch_bounds__(64) void k_ccl_boundary(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent, u32* __restrict__ flags)
+{
+    const int y = (blockIdx.x + 1) * CL_ROWS;
+    const u64* fb = bits + (size_t)blockIdx.y * G.h * G.ww;
+    u32* p = parent + (size_t)blockIdx.y * G.nids;
+    u32* f = flags + (size_t)blockIdx.y * G.nw32;
+    for (int j = threadIdx.x; j < G.ww; j += 64) {
+        const int idx = y * G.ww + j;
+        const u64 w = fb[idx];
+        if (w) global_link_word(fb, G, p, f, y, j, idx, w, false, true);
+    }
+}
+
+// ---- ranks + background -----------------------------------------------------------------------------------
 
 __device__ __forceinline__ u32 sum_bitpos(u64 z)  // sum of the positions of the set bits
 {
@@ -244,8 +372,15 @@ __device__ __forceinline__ u32 sum_bitpos(u64 z)  // sum of the positions of the
            ((u32)__popcll(z & 0xFFFF0000FFFF0000ull) << 4) + ((u32)__popcll(z & 0xFFFFFFFF00000000ull) << 5);
 }
 
-struct contrib { u32 area; u64 sx, sy; int minx, maxx, miny, maxy; };
-
+__device__ __forceinline__ void contrib_zero(contrib& c)
+{
+    c.area = 0; c.sx = 0; c.sy = 0; c.minx = INT_MAX; c.maxx = INT_MIN; c.miny = INT_MAX; c.maxy = INT_MIN; c.pad = 0;
+}
+__device__ __forceinline__ void contrib_merge(contrib& c, const contrib& o)
+{
+    c.area += o.area; c.sx += o.sx; c.sy += o.sy;
+    c.minx = min(c.minx, o.minx); c.maxx = max(c.maxx, o.maxx); c.miny = min(c.miny, o.miny); c.maxy = max(c.maxy, o.maxy);
+}
 __device__ __forceinline__ void wave_combine(contrib& c)
 {
 #pragma unroll
@@ -260,6 +395,103 @@ __device__ __forceinline__ void wave_combine(contrib& c)
     }
 }
 
+// grid (RK_PARTS + BG_PARTS, n), 256 threads.
+// blocks [0, RK_PARTS): exclusive popcount prefix over the root bitmap of one frame — part p first counts the bits
+//   of parts < p (the bitmap is 130 KB per 1080p frame, L2-resident), then scans its own slice; the last part also
+//   publishes nlabels and zeroes the accumulators.
+// blocks [RK_PARTS, RK_PARTS + BG_PARTS): background pixels of a slice of the frame reduced to one record.
+__global__ __launch_bounds__(256) void k_ccl_rank(ccl_geom G, const u32* __restrict__ flags, u32* __restrict__ prefix,
+                                                  int32_t* __restrict__ nlabels, ccl_acc* __restrict__ acc, int max_labels,
+                                                  const u64* __restrict__ bits, contrib* __restrict__ bgpart)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 bcast;
+    __shared__ contrib part[4];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x >= RK_PARTS) {
+        const int bp = blockIdx.x - RK_PARTS;
+        const int rper = (G.h + BG_PARTS - 1) / BG_PARTS;
+        const int r0 = bp * rper, r1 = min(r0 + rper, G.h);
+        const u64* fb = bits + (size_t)f * G.h * G.ww;
+        const u64 lastmask = (G.w & 63) ? ((1ull << (G.w & 63)) - 1ull) : ~0ull;
+        contrib c;
+        contrib_zero(c);
+        for (int y = r0 + (tid >> 5); y < r1; y += 8)
+            for (int j = tid & 31; j < G.ww; j += 32) {
+                u64 z = ~fb[(size_t)y * G.ww + j];
+                if (j == G.ww - 1) z &= lastmask;
+                if (!z) continue;
+                const u32 cnt = (u32)__popcll(z);
+                c.area += cnt;
+                c.sx += (u64)cnt * (u64)(64 * j) + sum_bitpos(z);
+                c.sy += (u64)cnt * (u64)y;
+                c.minx = min(c.minx, 64 * j + (__ffsll((long long)z) - 1));
+                c.maxx = max(c.maxx, 64 * j + 63 - __clzll(z));
+                c.miny = min(c.miny, y);
+                c.maxy = max(c.maxy, y);
+            }
+        wave_combine(c);
+        if (lane == 0) part[wv] = c;
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < 4; k++) contrib_merge(c, part[k]);
+            bgpart[(size_t)f * BG_PARTS + bp] = c;
+        }
+        return;
+    }
+    const int partno = blockIdx.x;
+    const u32 nq = G.nw32 / 4;                               // uint4 words per frame
+    const u32 qper = (nq + RK_PARTS - 1) / RK_PARTS;
+    const u32 q0 = min((u32)partno * qper, nq), q1 = min(q0 + qper, nq);
+    const uint4* fl = reinterpret_cast<const uint4*>(flags + (size_t)f * G.nw32);
+    uint4* pf = reinterpret_cast<uint4*>(prefix + (size_t)f * G.nw32);
+    u32 before = 0;
+    for (u32 q = tid; q < q0; q += 256) { const uint4 v = fl[q]; before += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) before += __shfl_xor(before, d);
+    if (lane == 0) wsum[wv] = before;
+    __syncthreads();
+    const u32 base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const u32 per = (q1 - q0 + 255) / 256;
+    const u32 lo = min(q0 + (u32)tid * per, q1), hi = min(lo + per, q1);
+    u32 cnt = 0;
+    for (u32 q = lo; q < hi; q++) { const uint4 v = fl[q]; cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+    u32 inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 woff = 0;
+    for (int k = 0; k < wv; k++) woff += wsum[k];
+    u32 run = base + woff + inc - cnt;
+    for (u32 q = lo; q < hi; q++) {
+        const uint4 v = fl[q];
+        uint4 o;
+        o.x = run; run += __popc(v.x);
+        o.y = run; run += __popc(v.y);
+        o.z = run; run += __popc(v.z);
+        o.w = run; run += __popc(v.w);
+        pf[q] = o;
+    }
+    if (partno == RK_PARTS - 1) {
+        if (tid == 255) bcast = run;   // last thread's running count = all bits of the frame
+        __syncthreads();
+        const int nl = (int)bcast + 1;
+        if (tid == 0 && nlabels) nlabels[f] = nl;
+        ccl_acc* a = acc + (size_t)f * max_labels;
+        const int nz = min(nl, max_labels);
+        for (int i = tid; i < nz; i += 256) {
+            ccl_acc z;
+            z.area = 0; z.minx = INT_MAX; z.miny = INT_MAX; z.maxx = INT_MIN; z.maxy = INT_MIN; z.pad = 0; z.sx = 0; z.sy = 0;
+            a[i] = z;
+        }
+    }
+}
+
+// ---- per-label statistics ----------------------------------------------------------------------------------
+
 __device__ __forceinline__ void acc_commit(ccl_acc* a, const contrib& c)
 {
     atomicAdd(&a->area, c.area);
@@ -271,89 +503,104 @@ __device__ __forceinline__ void acc_commit(ccl_acc* a, const contrib& c)
     atomicMax(&a->maxy, c.maxy);
 }
 
-// grid: (ceil(h*ww/256), n).  No early return: the whole wave takes part in the reductions.
+// grid: (ceil(h*ww/256), n).  Per-segment contributions are first combined per label in a small LDS hash table
+// (a block covers ~8 rows, so it sees a handful of labels), then each occupied slot is flushed with one set of
+// global atomics.
+#define ST_SLOTS 64
+struct st_table {
+    u32 label[ST_SLOTS];
+    u32 area[ST_SLOTS];
+    int minx[ST_SLOTS], maxx[ST_SLOTS], miny[ST_SLOTS], maxy[ST_SLOTS];
+    u64 sx[ST_SLOTS], sy[ST_SLOTS];
+};
 __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent,
                                                    const u32* __restrict__ flags, const u32* __restrict__ prefix,
-                                                   u32* __restrict__ seglabel, ccl_acc* __restrict__ acc, int max_labels)
+                                                   u32* __restrict__ seglabel, u32* __restrict__ wordlabel,
+                                                   ccl_acc* __restrict__ acc, int max_labels)
 {
+    __shared__ st_table T;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < G.h * G.ww;
     const int f = blockIdx.y;
     const u64 w = live ? bits[(size_t)f * G.h * G.ww + idx] : 0ull;
-    const int y = live ? idx / G.ww : 0, j = live ? idx - y * G.ww : 0;
-    const u32* p = parent + (size_t)f * G.nids;
-    const u32* fl = flags + (size_t)f * G.nw32;
-    const u32* pf = prefix + (size_t)f * G.nw32;
-    u32* sl = seglabel + (size_t)f * G.nids;
+    if (!__syncthreads_or(w != 0ull)) return;   // block-uniform
+    if (threadIdx.x < ST_SLOTS) {
+        const int i = threadIdx.x;
+        T.label[i] = 0; T.area[i] = 0; T.sx[i] = 0; T.sy[i] = 0;
+        T.minx[i] = INT_MAX; T.miny[i] = INT_MAX; T.maxx[i] = INT_MIN; T.maxy[i] = INT_MIN;
+    }
+    __syncthreads();
     ccl_acc* a = acc + (size_t)f * max_labels;
-    const int lane = threadIdx.x & 63;
-
-    // background contribution of this word
-    u64 valid = ~0ull;
-    if (j == G.ww - 1 && (G.w & 63)) valid = (1ull << (G.w & 63)) - 1ull;
-    u64 z = live ? (~w & valid) : 0ull;
-    u64 rem = w;
-    bool first = true;
-    for (;;) {
-        // next contribution of this lane: background first, then one segment per round
-        bool has = false;
-        u32 label = 0;
-        contrib c;
-        c.area = 0; c.sx = 0; c.sy = 0; c.minx = INT_MAX; c.maxx = INT_MIN; c.miny = INT_MAX; c.maxy = INT_MIN;
-        if (first) {
-            if (z) {
-                has = true;
-                const u32 cnt = (u32)__popcll(z);
-                c.area = cnt;
-                c.sx = (u64)cnt * (u64)(64 * j) + sum_bitpos(z);
-                c.sy = (u64)cnt * (u64)y;
-                c.minx = 64 * j + (__ffsll((long long)z) - 1);
-                c.maxx = 64 * j + 63 - __clzll(z);
-                c.miny = c.maxy = y;
-            }
-        } else if (rem) {
-            has = true;
+    if (w) {
+        const int y = idx / G.ww, j = idx - y * G.ww;
+        const u32* p = parent + (size_t)f * G.nids;
+        const u32* fl = flags + (size_t)f * G.nw32;
+        const u32* pf = prefix + (size_t)f * G.nw32;
+        u32* sl = seglabel + (size_t)f * G.nids;
+        u64 rem = w;
+        bool first = true;
+        while (rem) {
             const int s = __ffsll((long long)rem) - 1;
             const int e = run_end(rem, s);
             rem &= ~bit_range(s, e);
             const u32 id = seg_id(G, y, 64 * j + s);
-            u32 r = ld_rlx(p + id);
-            label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
+            u32 r = id;
+            for (u32 q = p[r]; q != r; q = p[r]) r = q;   // read-only walk: strip root, then across strips
+            const u32 label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
             sl[id] = label;
+            if (first) { wordlabel[(size_t)f * G.h * G.ww + idx] = label; first = false; }
+            if (label >= (u32)max_labels) continue;
             const u32 len = (u32)(e - s + 1);
-            const u32 xs = (u32)(64 * j + s), xe = (u32)(64 * j + e);
-            c.area = len;
-            c.sx = (u64)len * (u64)(xs + xe) / 2ull;
-            c.sy = (u64)len * (u64)y;
-            c.minx = (int)xs; c.maxx = (int)xe; c.miny = c.maxy = y;
+            const int xs = 64 * j + s, xe = 64 * j + e;
+            const u64 sx = (u64)len * (u64)(xs + xe) / 2ull, sy = (u64)len * (u64)y;
+            u32 slot = (label * 2654435761u) >> 26;   // 6 bits
+            bool done = false;
+            for (int probe = 0; probe < 8 && !done; probe++, slot = (slot + 1) & (ST_SLOTS - 1)) {
+                const u32 cur = atomicCAS(&T.label[slot], 0u, label);
+                if (cur == 0u || cur == label) {
+                    atomicAdd(&T.area[slot], len);
+                    atomicAdd((unsigned long long*)&T.sx[slot], (unsigned long long)sx);
+                    atomicAdd((unsigned long long*)&T.sy[slot], (unsigned long long)sy);
+                    atomicMin(&T.minx[slot], xs);
+                    atomicMax(&T.maxx[slot], xe);
+                    atomicMin(&T.miny[slot], y);
+                    atomicMax(&T.maxy[slot], y);
+                    done = true;
+                }
+            }
+            if (!done) {   // crowded block (noise): straight to global memory
+                contrib c;
+                c.area = len; c.sx = sx; c.sy = sy; c.minx = xs; c.maxx = xe; c.miny = c.maxy = y;
+                acc_commit(a + label, c);
+            }
         }
-        first = false;
-        u64 active = __ballot(has);
-        if (!active && !__any(rem != 0)) break;
-        while (active) {
-            const int leader = __ffsll((long long)active) - 1;
-            const u32 lab = __shfl(label, leader);
-            const bool mine = has && label == lab;
-            const u64 grp = __ballot(mine);
-            contrib g = c;
-            if (!mine) { g.area = 0; g.sx = 0; g.sy = 0; g.minx = INT_MAX; g.maxx = INT_MIN; g.miny = INT_MAX; g.maxy = INT_MIN; }
-            if (__popcll(grp) > 1) wave_combine(g);
-            if (lane == leader && lab < (u32)max_labels) acc_commit(a + lab, g);
-            active &= ~grp;
-        }
+    }
+    __syncthreads();
+    if (threadIdx.x < ST_SLOTS && T.label[threadIdx.x]) {
+        const int i = threadIdx.x;
+        contrib c;
+        c.area = T.area[i]; c.sx = T.sx[i]; c.sy = T.sy[i]; c.minx = T.minx[i]; c.maxx = T.maxx[i]; c.miny = T.miny[i]; c.maxy = T.maxy[i];
+        acc_commit(a + T.label[i], c);
     }
 }
 
 // grid: (ceil(max_labels/256), n)
-__global__ __launch_bounds__(256) void k_ccl_final(const ccl_acc* __restrict__ acc, const int32_t* __restrict__ nlabels,
-                                                   int max_labels, int32_t* __restrict__ stats, double* __restrict__ cent)
+__global__ __launch_bounds__(256) void k_ccl_final(const ccl_acc* __restrict__ acc, const contrib* __restrict__ bgpart,
+                                                   const int32_t* __restrict__ nlabels, int max_labels, int32_t* __restrict__ stats,
+                                                   double* __restrict__ cent)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= max_labels) return;
     const int f = blockIdx.y;
     const size_t o = (size_t)f * max_labels + l;
     if (l < nlabels[f]) {
-        const ccl_acc a = acc[o];
+        ccl_acc a = acc[o];
+        if (l == 0) {   // background: merge the per-slice records
+            contrib c;
+            contrib_zero(c);
+            for (int k = 0; k < BG_PARTS; k++) contrib_merge(c, bgpart[(size_t)f * BG_PARTS + k]);
+            a.area = c.area; a.minx = c.minx; a.maxx = c.maxx; a.miny = c.miny; a.maxy = c.maxy; a.sx = c.sx; a.sy = c.sy;
+        }
         if (stats) {
             int32_t* s = stats + o * 5;
             s[0] = a.minx;
@@ -373,37 +620,86 @@ __global__ __launch_bounds__(256) void k_ccl_final(const ccl_acc* __restrict__ a
     }
 }
 
-// grid: (n*h, ceil(ceil(w/4)/256)).  One lane = 4 px = one 16-B store.
+// ---- label image -------------------------------------------------------------------------------------------
+// One lane = 4 px = one 16-B store.  A block streams WR_ROWS consecutive rows; a thread owns WR_K groups and runs
+// in phases — all bit-word + word-label loads, then the stores — so that no load waits behind a store (vmcnt
+// counts stores too on CDNA4).  A word with a single segment (the common case inside blobs) takes its label from
+// the dense wordlabel array; only words holding several segments go to the sparse seglabel array.
+#define WR_ROWS 8
+#define WR_K 8
 __global__ __launch_bounds__(256) void k_ccl_write(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ seglabel,
-                                                   int32_t* __restrict__ labels)
+                                                   const u32* __restrict__ wordlabel, int32_t* __restrict__ labels, u32 total_rows,
+                                                   u32 gpr, u32 gpr_magic)
 {
-    const int g = blockIdx.y * 256 + threadIdx.x;
-    const int x0 = g * 4;
-    if (x0 >= G.w) return;
-    const u32 row = blockIdx.x;            // frame*h + y
-    const u32 f = row / (u32)G.h;
-    const int y = (int)(row - f * (u32)G.h);
-    const int j = x0 >> 6, sub = x0 & 63;
-    const u64 w = bits[(size_t)row * G.ww + j];
-    const u32 nib = (u32)(w >> sub) & 0xfu;
-    int v[4] = {0, 0, 0, 0};
-    if (nib) {
-        const u32* sl = seglabel + (size_t)f * G.nids;
-        int prev = 0;
+    const u32 row0 = blockIdx.x * WR_ROWS;
+    const u32 nrows = min((u32)WR_ROWS, total_rows - row0);
+    const u32 ngroups = nrows * gpr;
+    const bool vec = (G.w & 3) == 0 && ((((uintptr_t)labels) & 15) == 0);
+    const u64* brow0 = bits + (size_t)row0 * G.ww;
+    const u32* wrow0 = wordlabel + (size_t)row0 * G.ww;
+    int32_t* lrow0 = labels + (size_t)row0 * G.w;
+    const u32 f0 = row0 / (u32)G.h;
+    const u32 y0 = row0 - f0 * (u32)G.h;
+    for (u32 qb = 0; qb < ngroups; qb += 256 * WR_K) {
+        u64 w[WR_K];
+        u32 wl[WR_K], rl[WR_K], g[WR_K];
+        bool live[WR_K];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((nib >> k) & 1u) {
-                if (k == 0 || !((nib >> (k - 1)) & 1u)) prev = (int)sl[seg_id(G, y, 64 * j + run_start(w, sub + k))];
-                v[k] = prev;
+        for (int k = 0; k < WR_K; k++) {
+            const u32 q = qb + (u32)k * 256 + threadIdx.x;
+            live[k] = q < ngroups;
+            const u32 qq = live[k] ? q : 0;
+            rl[k] = gpr == 1 ? qq : __umulhi(qq, gpr_magic);   // qq / gpr (exact for qq < 2^16 * gpr)
+            g[k] = qq - rl[k] * gpr;
+            const u32 wi = rl[k] * (u32)G.ww + (g[k] >> 4);
+            w[k] = brow0[wi];
+            wl[k] = wrow0[wi];
+        }
+        u32 la[WR_K], lb[WR_K], m1[WR_K], m2[WR_K];
+        bool sparse = false;
+#pragma unroll
+        for (int k = 0; k < WR_K; k++) {
+            const u32 nib = (u32)(w[k] >> ((g[k] * 4) & 63)) & 0xfu;
+            m1[k] = nib;
+            m2[k] = 0;
+            la[k] = wl[k];
+            lb[k] = 0;
+            sparse |= nib && (nstarts(w[k]) > 1);
+        }
+        if (__any(sparse)) {   // wave-uniform, rare: some word here holds more than one segment
+#pragma unroll
+            for (int k = 0; k < WR_K; k++) {
+                const u32 nib = m1[k];
+                if (!nib || nstarts(w[k]) <= 1) continue;
+                const int x0 = (int)g[k] * 4, sub = x0 & 63, j = x0 >> 6;
+                u32 y = y0 + rl[k], f = f0;
+                while (y >= (u32)G.h) { y -= (u32)G.h; f++; }
+                const u32* sl = seglabel + (size_t)f * G.nids;
+                // first run of the nibble, and what is left after it (at most one more run)
+                const int tz = __ffs((int)nib) - 1;
+                const u32 t = nib >> tz;
+                const int runlen = __ffs((int)~t) - 1;
+                m1[k] = ((1u << runlen) - 1u) << tz;
+                m2[k] = nib & ~m1[k];
+                la[k] = sl[seg_id(G, (int)y, 64 * j + run_start(w[k], sub + tz))];
+                if (m2[k]) lb[k] = sl[seg_id(G, (int)y, 64 * j + sub + (__ffs((int)m2[k]) - 1))];
             }
         }
-    }
-    int32_t* drow = labels + (size_t)row * G.w;
-    if (x0 + 4 <= G.w && ((((uintptr_t)(drow + x0)) & 15) == 0)) {
-        *reinterpret_cast<int4*>(drow + x0) = make_int4(v[0], v[1], v[2], v[3]);
-    } else {
-        for (int k = 0; k < 4; k++)
-            if (x0 + k < G.w) drow[x0 + k] = v[k];
+#pragma unroll
+        for (int k = 0; k < WR_K; k++) {
+            if (!live[k]) continue;
+            const int x0 = (int)g[k] * 4;
+            int vv[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) vv[b] = ((m1[k] >> b) & 1u) ? (int)la[k] : (((m2[k] >> b) & 1u) ? (int)lb[k] : 0);
+            int32_t* d = lrow0 + (size_t)rl[k] * G.w + x0;
+            if (vec && x0 + 4 <= G.w) {
+                vp_store16(d, (u32)vv[0], (u32)vv[1], (u32)vv[2], (u32)vv[3]);
+            } else {
+                for (int b = 0; b < 4; b++)
+                    if (x0 + b < G.w) d[b] = vv[b];
+            }
+        }
     }
 }
 
@@ -418,21 +714,31 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
     G.nw32 = G.nids / 32;
     const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
     hipStream_t s = ctx->stream;
-    { vp_prof_scope ps(ctx, VPK_OTHER); VP_HIP(ctx, hipMemsetAsync(ws.flags, 0, (size_t)G.nw32 * 4 * n, s)); }
-    { vp_prof_scope ps(ctx, VPK_CCL_INIT); hipLaunchKernelGGL(k_ccl_init, wgrid, dim3(256), 0, s, d_bits, G, ws.parent); }
-    { vp_prof_scope ps(ctx, VPK_CCL_LINK); hipLaunchKernelGGL(k_ccl_link, wgrid, dim3(256), 0, s, d_bits, G, ws.parent); }
-    { vp_prof_scope ps(ctx, VPK_CCL_FLATTEN); hipLaunchKernelGGL(k_ccl_flatten, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags); }
-    { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3((unsigned)n), dim3(1024), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels); }
-    { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, (ccl_acc*)ws.acc, max_labels); }
+    const int strips = (h + CL_ROWS - 1) / CL_ROWS;
+    const size_t nwmax = (size_t)CL_ROWS * G.ww;
+    const size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + (size_t)3 * CL_CAP * 4;
+    if (lds_local <= 64 * 1024) {
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, ws.parent, ws.flags, strips); }
+        if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, ws.parent, ws.flags); }
+    } else {
+        { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(ws.flags, 0, (size_t)G.nw32 * 4 * n, s)); }
+        { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_init, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags); }
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_link, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags); }
+    }
+    { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart); }
+    { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels); }
     if (d_stats || d_centroids) {
         vp_prof_scope ps(ctx, VPK_CCL_FINAL);
         hipLaunchKernelGGL(k_ccl_final, dim3((unsigned)((max_labels + 255) / 256), (unsigned)n), dim3(256), 0, s, (const ccl_acc*)ws.acc,
-                           d_nlabels, max_labels, d_stats, d_centroids);
+                           (const contrib*)ws.bgpart, d_nlabels, max_labels, d_stats, d_centroids);
     }
     if (d_labels) {
         vp_prof_scope ps(ctx, VPK_CCL_WRITE);
-        const dim3 lgrid((unsigned)((size_t)n * h), (unsigned)(((w + 3) / 4 + 255) / 256));
-        hipLaunchKernelGGL(k_ccl_write, lgrid, dim3(256), 0, s, d_bits, G, ws.seglabel, d_labels);
+        const u32 total_rows = (u32)((size_t)n * h);
+        const u32 gpr = (u32)((w + 3) / 4);
+        const u32 magic = (u32)((0x100000000ull + gpr - 1) / gpr);
+        hipLaunchKernelGGL(k_ccl_write, dim3((total_rows + WR_ROWS - 1) / WR_ROWS), dim3(256), 0, s, d_bits, G, ws.seglabel, ws.wordlabel, d_labels,
+                           total_rows, gpr, magic);
     }
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;

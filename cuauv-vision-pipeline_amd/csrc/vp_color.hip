@@ -113,9 +113,20 @@ __global__ __launch_bounds__(256) void k_color_thresh_flat(const uint8_t* __rest
     __shared__ typename ModeLds<MODE>::type s;
     load_lds<MODE>(s, tab);
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += stride) {
-        const uint4* p = reinterpret_cast<const uint4*>(src + g * 48);
-        const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;   // ngroups % 4 == 0 and g is quad-aligned: the 4 lanes of a word leave together
+    const uint4* p = reinterpret_cast<const uint4*>(src + g * 48);
+    uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+    for (;;) {
+        // prefetch the next group before this one's stores are issued: on CDNA4 vmcnt counts stores too, so
+        // a load issued after a store would wait for the store's completion
+        const size_t gn = g + stride;
+        const bool more = gn < ngroups;
+        uint4 n0 = v0, n1 = v1, n2 = v2;
+        if (more) {
+            const uint4* pn = reinterpret_cast<const uint4*>(src + gn * 48);
+            n0 = pn[0]; n1 = pn[1]; n2 = pn[2];
+        }
         const u32 in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
         u32 m = 0;
 #pragma unroll
@@ -124,20 +135,17 @@ __global__ __launch_bounds__(256) void k_color_thresh_flat(const uint8_t* __rest
             m |= (u32)px_pred<MODE, NEED>(s, q, b, gg, r) << k;
         }
         if (WMASK) {
-            uint4 o;
-            o.x = expand4(m);
-            o.y = expand4(m >> 4);
-            o.z = expand4(m >> 8);
-            o.w = expand4(m >> 12);
-            reinterpret_cast<uint4*>(mask)[g] = o;
+            vp_store16(mask + g * 16, expand4(m), expand4(m >> 4), expand4(m >> 8), expand4(m >> 12));
         }
         if (WBITS) {
-            // ngroups % 4 == 0, so the 4 lanes of a word are active together
             u64 wv = (u64)m << (16 * (threadIdx.x & 3));
             wv |= __shfl_xor(wv, 1);
             wv |= __shfl_xor(wv, 2);
             if ((threadIdx.x & 3) == 0) bits[g >> 2] = wv;
         }
+        if (!more) break;
+        v0 = n0; v1 = n1; v2 = n2;
+        g = gn;
     }
 }
 
@@ -185,7 +193,7 @@ static int launch_thresh(vp_ctx* ctx, const uint8_t* d_bgr, size_t stride, int w
     if (flat) {
         const size_t ngroups = (size_t)n * h * w / 16;
         size_t blocks = (ngroups + 255) / 256;
-        const size_t cap = (size_t)ctx->num_cu * 8;
+        const size_t cap = (size_t)ctx->num_cu * 12;
         if (blocks > cap) blocks = cap;
         dim3 grid((unsigned)blocks);
         if (d_mask && d_bits)

@@ -15,8 +15,8 @@ struct vp_tables {          // device copies of the OpenCV integer tables
     const int32_t* hdiv;    // [256]  hdiv_table180
 };
 
-enum { VPK_COLOR = 0, VPK_MORPH, VPK_CCL_INIT, VPK_CCL_LINK, VPK_CCL_FLATTEN, VPK_CCL_RANK, VPK_CCL_STATS, VPK_CCL_FINAL,
-       VPK_CCL_WRITE, VPK_OTHER };
+enum { VPK_COLOR = 0, VPK_MORPH, VPK_CCL_LOCAL, VPK_CCL_BOUNDARY, VPK_CCL_FLATTEN, VPK_CCL_RANK, VPK_CCL_BG, VPK_CCL_STATS,
+       VPK_CCL_FINAL, VPK_CCL_WRITE, VPK_MEMSET, VPK_OTHER };
 
 struct vp_prof {
     bool on;
@@ -111,9 +111,26 @@ struct vp_ccl_ws {           // per-batch scratch, all device pointers
     u32* flags;              // [n][nids/32]   root bitmap
     u32* prefix;             // [n][nids/32]   exclusive popcount prefix
     void* acc;               // [n][max_labels] accumulators
+    u32* wordlabel;          // [n][h*ww]      label of the first segment of each word
+    void* bgpart;            // [n][8]         background partial records
 };
 size_t vp_ccl_nids(int w, int h);   // multiple of 32
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels);
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out);
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
             int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels);
+
+// 16-byte streaming store for write-once outputs (masks, labels).  VP_NT_STORES selects the nontemporal form.
+#ifndef VP_NT_STORES
+#define VP_NT_STORES 1
+#endif
+typedef int vp_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vp_store16(void* dst, u32 a, u32 b, u32 c, u32 d)
+{
+    vp_v4i v = {(int)a, (int)b, (int)c, (int)d};
+#if VP_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<vp_v4i*>(dst));
+#else
+    *reinterpret_cast<vp_v4i*>(dst) = v;
+#endif
+}

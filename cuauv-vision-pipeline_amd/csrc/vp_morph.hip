@@ -66,12 +66,7 @@ __global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ s
 __device__ __forceinline__ void store_mask16(uint8_t* __restrict__ dstrow, int x0, int w, u32 m16, bool vec_ok)
 {
     if (vec_ok && x0 + 16 <= w) {
-        uint4 o;
-        o.x = expand4m(m16);
-        o.y = expand4m(m16 >> 4);
-        o.z = expand4m(m16 >> 8);
-        o.w = expand4m(m16 >> 12);
-        *reinterpret_cast<uint4*>(dstrow + x0) = o;
+        vp_store16(dstrow + x0, expand4m(m16), expand4m(m16 >> 4), expand4m(m16 >> 8), expand4m(m16 >> 12));
     } else {
         for (int k = 0; k < 16; k++)
             if (x0 + k < w) dstrow[x0 + k] = ((m16 >> k) & 1) ? 255 : 0;

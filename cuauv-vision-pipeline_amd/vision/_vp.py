@@ -18,7 +18,7 @@ MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3,
 SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
 CCL_PIXEL, CCL_BLOCK2X2 = 1, 2
 CHAIN_MAX_MORPH = 8
-PROF_KERNELS = 10
+PROF_KERNELS = 12
 
 
 class VpError(RuntimeError):

@@ -62,7 +62,7 @@ int vp_timer_stop(vp_ctx* ctx, float* elapsed_ms); /* records, synchronises, ret
 /* Per-kernel attribution: between vp_profile_begin and vp_profile_end every kernel the context
  * launches is bracketed by HIP events on its stream.  vp_profile_end synchronises and fills
  * total_ms[id] / launches[id] for id < VP_PROF_KERNELS (names: vp_profile_kernel_name). */
-#define VP_PROF_KERNELS 10
+#define VP_PROF_KERNELS 12
 int vp_profile_begin(vp_ctx* ctx, int max_records);
 int vp_profile_end(vp_ctx* ctx, double* total_ms, int32_t* launches);
 const char* vp_profile_kernel_name(int id);
