@@ -129,6 +129,18 @@ def main():
     fps = n_gpus * B * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # HBM-side bytes per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
+    # separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py); collected at batch 64
+    traffic_tab = {}
+    if args.batch == 64:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*traffic.json")))
+        if cands:
+            try:
+                traffic_tab = json.load(open(cands[-1]))
+            except Exception:
+                traffic_tab = {}
+
     roof = None
     kernels = {}
     for name, (ms, cnt) in prof.items():
@@ -139,7 +151,8 @@ def main():
         kb = KERNEL_BYTES_PER_PX[dom] * W * H * B
         achieved = kb / avg_s / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": next((v["traffic_bytes_per_launch"] for k, v in traffic_tab.items() if k.startswith(dom)), None),
                 "bytes_per_launch": int(kb), "avg_launch_us": round(1e6 * avg_s, 2),
                 "chain_achieved_GBps": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9, 1),
                 "chain_frac": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS, 4)}

@@ -61,6 +61,13 @@ vp_ctx* vp_create(int device)
     ctx->stream = ctx->own_stream;
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
+    ctx->chain_streams = 1;
+    if (const char* env = getenv("VP_CHAIN_STREAMS")) { const int v = atoi(env); if (v >= 1 && v <= 4) ctx->chain_streams = v; }
+    for (int i = 0; i < 4; i++) {
+        if (hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) != hipSuccess) { vp_fail(nullptr, VP_ERR_HIP, "aux stream"); delete ctx; return nullptr; }
+        hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
+    }
+    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     // tables: gamma u16[256] | cbrt u16[2048] | sdiv i32[256] | hdiv i32[256]
     std::vector<uint16_t> gamma(256), cbrt(3072);
     std::vector<int32_t> sdiv(256), hdiv(256);
@@ -92,6 +99,8 @@ int vp_destroy(vp_ctx* ctx)
     if (ctx->d_tables) hipFree(ctx->d_tables);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < 4; i++) { hipStreamDestroy(ctx->aux[i]); hipEventDestroy(ctx->ev_join[i]); }
+    hipEventDestroy(ctx->ev_fork);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VP_OK;
@@ -104,6 +113,13 @@ int vp_set_stream(vp_ctx* ctx, void* hip_stream)
     return VP_OK;
 }
 void* vp_get_stream(vp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int vp_set_option(vp_ctx* ctx, int option, int value)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    if (option == VP_OPT_CHAIN_STREAMS && value >= 1 && value <= 4) { ctx->chain_streams = value; return VP_OK; }
+    return vp_fail(ctx, VP_ERR_INVALID, "vp_set_option");
+}
 
 int vp_synchronize(vp_ctx* ctx)
 {
@@ -632,7 +648,7 @@ static int check_desc(vp_ctx* ctx, const vp_chain_desc* d, int n)
 static size_t chain_ws_bytes(const vp_chain_desc* d, int n)
 {
     const size_t bitbytes = (size_t)n * d->height * vp_ww(d->width) * 8;
-    size_t need = 3 * vp_align(bitbytes) + vp_align((size_t)n * 4) + 8192;
+    size_t need = 3 * vp_align(bitbytes) + vp_align((size_t)n * 4) + 8192 + 4 * 16384;
     if (d->ccl) need += vp_ccl_ws_bytes(d->width, d->height, n, d->max_labels);
     return need;
 }
@@ -682,13 +698,50 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
     return VP_OK;
 }
 
+// Runs the chain for n frames, split into sub-batches on the context's internal streams (fork/join around the
+// caller-visible stream).  Frames are independent, so the split changes scheduling only.
+static int chain_split(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffers* b, int n)
+{
+    int S = ctx->chain_streams;
+    if (S > n / 4) S = n / 4;      // keep sub-batches worth a launch
+    if (S <= 1) return chain_core(ctx, d, b, n);
+    const size_t npx = (size_t)d->width * d->height;
+    const size_t ml = (size_t)(d->ccl ? d->max_labels : 0);
+    hipStream_t user = ctx->stream;
+    VP_HIP(ctx, hipEventRecord(ctx->ev_fork, user));
+    int rc = VP_OK;
+    int f0 = 0;
+    for (int s = 0; s < S && rc == VP_OK; s++) {
+        const int cnt = n / S + (s < n % S ? 1 : 0);
+        vp_chain_buffers sb = *b;
+        sb.bgr = b->bgr + (size_t)f0 * npx * 3;
+        if (b->threshed) sb.threshed = b->threshed + (size_t)f0 * npx;
+        if (b->cleaned) sb.cleaned = b->cleaned + (size_t)f0 * npx;
+        if (b->labels) sb.labels = b->labels + (size_t)f0 * npx;
+        if (b->stats) sb.stats = b->stats + (size_t)f0 * ml * 5;
+        if (b->centroids) sb.centroids = b->centroids + (size_t)f0 * ml * 2;
+        if (b->nlabels) sb.nlabels = b->nlabels + f0;
+        hipError_t e = hipStreamWaitEvent(ctx->aux[s], ctx->ev_fork, 0);
+        if (e != hipSuccess) { rc = vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", e); break; }
+        ctx->stream = ctx->aux[s];
+        rc = chain_core(ctx, d, &sb, cnt);
+        ctx->stream = user;
+        if (rc != VP_OK) break;
+        if ((e = hipEventRecord(ctx->ev_join[s], ctx->aux[s])) != hipSuccess) { rc = vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", e); break; }
+        if ((e = hipStreamWaitEvent(user, ctx->ev_join[s], 0)) != hipSuccess) { rc = vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", e); break; }
+        f0 += cnt;
+    }
+    ctx->stream = user;
+    return rc;
+}
+
 int vp_chain_run(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* dev, int n_frames)
 {
     VP_TRY(check_ctx(ctx));
     VP_TRY(check_desc(ctx, desc, n_frames));
     if (!dev || !dev->bgr) return vp_fail(ctx, VP_ERR_INVALID, "chain: bgr");
-    VP_TRY(vp_ws_reserve(ctx, chain_ws_bytes(desc, n_frames)));
-    return chain_core(ctx, desc, dev, n_frames);
+    VP_TRY(vp_ws_reserve(ctx, chain_ws_bytes(desc, n_frames) + 4 * 65536));
+    return chain_split(ctx, desc, dev, n_frames);
 }
 
 int vp_chain_run_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* host, int n)
@@ -714,7 +767,7 @@ int vp_chain_run_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buf
         if (!d.nlabels) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
     }
     VP_TRY(h2d(ctx, d_bgr, host->bgr, npx * 3));
-    VP_TRY(chain_core(ctx, desc, &d, n));
+    VP_TRY(chain_split(ctx, desc, &d, n));
     if (host->threshed) VP_TRY(d2h(ctx, host->threshed, d.threshed, npx));
     if (host->cleaned) VP_TRY(d2h(ctx, host->cleaned, d.cleaned, npx));
     if (desc->ccl) {

@@ -9,6 +9,7 @@
 // kernels consume.  The arithmetic is OpenCV's 8-bit fixed point; the
 // LUTs live in LDS.  HBM-bound: 4.125 B/px.
 #include "vp_internal.h"
+#include <cstdlib>
 
 #define LAB_LSHIFT (-1336934)  // -((16*255*32768 + 50)/100)
 
@@ -193,7 +194,8 @@ static int launch_thresh(vp_ctx* ctx, const uint8_t* d_bgr, size_t stride, int w
     if (flat) {
         const size_t ngroups = (size_t)n * h * w / 16;
         size_t blocks = (ngroups + 255) / 256;
-        const size_t cap = (size_t)ctx->num_cu * 12;
+        static const int bpc = getenv("VP_COLOR_BPC") ? atoi(getenv("VP_COLOR_BPC")) : 32;
+        const size_t cap = (size_t)ctx->num_cu * (bpc > 0 ? bpc : 32);
         if (blocks > cap) blocks = cap;
         dim3 grid((unsigned)blocks);
         if (d_mask && d_bits)

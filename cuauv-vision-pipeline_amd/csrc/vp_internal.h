@@ -36,6 +36,9 @@ struct vp_ctx {
     size_t ws_cap;
     size_t ws_off;
     int num_cu;
+    int chain_streams;            // sub-batches of a chain run on this many internal streams (>= 1)
+    hipStream_t aux[4];
+    hipEvent_t ev_fork, ev_join[4];
     vp_prof prof;
     char err[256];
 };

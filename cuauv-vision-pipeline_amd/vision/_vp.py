@@ -18,6 +18,7 @@ MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3,
 SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
 CCL_PIXEL, CCL_BLOCK2X2 = 1, 2
 CHAIN_MAX_MORPH = 8
+OPT_CHAIN_STREAMS = 1
 PROF_KERNELS = 12
 
 
@@ -51,6 +52,7 @@ _SIGS = {
     "vp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_get_stream": (C.c_void_p, [C.c_void_p]),
     "vp_synchronize": (C.c_int, [C.c_void_p]),
+    "vp_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "vp_timer_start": (C.c_int, [C.c_void_p]),
     "vp_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "vp_get_tables": (C.c_int, [C.c_void_p] * 5),
@@ -126,6 +128,9 @@ class Context:
 
     def set_stream(self, stream_handle):
         check(lib().vp_set_stream(self.handle, stream_handle), self.handle)
+
+    def set_option(self, option, value):
+        check(lib().vp_set_option(self.handle, int(option), int(value)), self.handle)
 
     def synchronize(self):
         check(lib().vp_synchronize(self.handle), self.handle)

@@ -56,6 +56,11 @@ const char* vp_last_error(const vp_ctx* ctx);
 int vp_set_stream(vp_ctx* ctx, void* hip_stream);
 void* vp_get_stream(vp_ctx* ctx);
 int vp_synchronize(vp_ctx* ctx);
+/* Options.  VP_OPT_CHAIN_STREAMS (1..4, default 1): vp_chain_run splits a batch into that many sub-batches
+ * on internal streams (fork/join around the context's stream); results are identical for every value.
+ * Measured on MI355X: no gain over 1 (the kernels of the two halves slow each other down), hence the default. */
+enum { VP_OPT_CHAIN_STREAMS = 1 };
+int vp_set_option(vp_ctx* ctx, int option, int value);
 /* HIP-event stopwatch on the context's stream (bench.py: roofline.achieved). */
 int vp_timer_start(vp_ctx* ctx);
 int vp_timer_stop(vp_ctx* ctx, float* elapsed_ms); /* records, synchronises, returns ms */

@@ -9,6 +9,7 @@ from vision import _vp
 W, H = 1920, 1080
 B = int(os.environ.get("B", "64")); K = int(os.environ.get("K", "30"))
 ctx = _vp.Context(0)
+if os.environ.get("S"): ctx.set_option(_vp.OPT_CHAIN_STREAMS, int(os.environ["S"]))
 distinct = [F.s1_buoy(i, W, H) for i in range(8)]
 host = np.stack([distinct[i % 8] for i in range(B)])
 d_bgr = torch.from_numpy(host).cuda()
