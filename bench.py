@@ -50,6 +50,52 @@ def parse():
     return ap.parse_args()
 
 
+def init_distributed(backend):
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  The process group is
+    used only for barriers and the MAX over ranks of the timed region: frames are independent, no data-path collective."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
+        dist = dist_mod
+    return rank, local_rank, world, dist
+
+
+def shard_of(n_items, rank, world):
+    """Contiguous slice of n_items owned by `rank` (config 4: frames [lo, hi) of every batch go to GPU `rank`)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def timed_steps(step_fn, sync_fn, steps, dist, device=None):
+    """Exactly `steps` calls of step_fn between barrier + device sync on both sides; returns the MAX over ranks (s)."""
+    import torch
+    if dist is not None:
+        dist.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -63,12 +109,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libvp has no CPU path")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    _, _, _, dist = init_distributed("nccl")
 
     import frames as F
     from vision import _vp
@@ -96,28 +137,15 @@ def main():
     bufs.labels, bufs.stats, bufs.centroids, bufs.nlabels = d_lab.data_ptr(), d_stats.data_ptr(), d_cent.data_ptr(), d_nl.data_ptr()
     alg_bytes_step = int(L.vp_chain_algorithmic_bytes(C.byref(desc), C.byref(bufs), B))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
     for _ in range(args.warmup):
         ctx.chain_run(desc, bufs, B)
     ctx.synchronize()
 
-    # ---- timed region: exactly K steps ------------------------------------------------------------
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.chain_run(desc, bufs, B)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks ------------
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+    elapsed = timed_steps(lambda: ctx.chain_run(desc, bufs, B), sync, args.steps, dist, device="cuda")
 
     # ---- per-kernel attribution with HIP events on the launch stream (same K steps again) ----------
     ctx.profile_begin(args.steps * 16)

@@ -1,0 +1,377 @@
+// libcamera_message_framework.so — shared-memory latest-wins frame ring (see include/camera_message_framework_c.h).
+//
+// File layout of /dev/shm/auv_visiond_<direction> (must match the reference so mixed processes interoperate;
+// offsets from lib/camera_message_framework.cpp:27-54 compiled for x86-64 / glibc):
+//     0  uid                  u64, atomic: number of frames ever written
+//     8  max_entry_size_bytes u64
+//    16  deleted              u8
+//    24  slots[3]             360 B each: seq_begin u64 | seq_end u64 | acquisition_time | total_size | width |
+//                             height | depth | type_size | plane_count | planes[4] x {w,h,d,type_size,offset,name[32]}
+//  1104  pthread_cond_t       process-shared
+//  1152  pthread_mutex_t      process-shared, robust
+//  1216  payload              3 x max_entry_size_bytes, planes of a frame back to back
+//
+// Protocol (single writer per block): slot = (uid + 1) % 3; seq_begin += 1; copy payload + metadata;
+// seq_end = seq_begin; uid += 1; broadcast.  A reader takes slot uid % 3 and retries until it saw
+// seq_end == seq_begin around its copy.
+#include "../../include/camera_message_framework_c.h"
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <pthread.h>
+#include <string>
+#include <sys/file.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+namespace {
+
+constexpr const char* kStub = "/dev/shm/auv_visiond_";
+constexpr const char* kLockFile = "/dev/shm/auv_visiond.lock";
+
+struct ShmPlane { uint64_t width, height, depth, type_size, offset; char name[CMF_PLANE_NAME_MAX_LEN]; };
+struct ShmSlot {
+    uint64_t seq_begin, seq_end;
+    uint64_t acquisition_time, total_size, width, height, depth, type_size, plane_count;
+    ShmPlane planes[CMF_MAX_PLANE_CNT];
+};
+struct ShmHeader {
+    uint64_t uid;
+    uint64_t max_entry_size_bytes;
+    uint8_t deleted;
+    ShmSlot slots[CMF_BUFFER_CNT];
+    pthread_cond_t cond;
+    pthread_mutex_t mutex;
+    alignas(64) unsigned char payload[1];
+};
+static_assert(sizeof(ShmPlane) == 72, "plane layout");
+static_assert(sizeof(ShmSlot) == 360, "slot layout");
+static_assert(offsetof(ShmHeader, slots) == 24, "slots offset");
+static_assert(offsetof(ShmHeader, cond) == 1104, "cond offset");
+static_assert(offsetof(ShmHeader, mutex) == 1152, "mutex offset");
+static_assert(offsetof(ShmHeader, payload) == 1216, "payload offset");
+static_assert(sizeof(FramePlane) == 72 && sizeof(Frame) == 360 && sizeof(FramePlaneWrite) == 48, "ABI structs");
+
+thread_local char t_err[256] = "";
+void set_err(const char* what, const std::string& detail = "")
+{
+    snprintf(t_err, sizeof t_err, "%s%s%s", what, detail.empty() ? "" : ": ", detail.c_str());
+}
+
+// RAII exclusive flock on the global lock file (reference: lib/filelock.cpp:11-31)
+struct GlobalLock {
+    int fd;
+    GlobalLock() : fd(open(kLockFile, O_RDWR | O_CREAT, 0666))
+    {
+        if (fd >= 0) flock(fd, LOCK_EX);
+    }
+    ~GlobalLock()
+    {
+        if (fd >= 0) { flock(fd, LOCK_UN); close(fd); }
+    }
+};
+
+inline uint64_t load_acq(const uint64_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void store_rel(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+
+struct PrivFrame {   // what create_frame really allocates: the public Frame first, bookkeeping after
+    Frame pub;
+    size_t capacity;
+};
+
+}  // namespace
+
+struct Block {
+    std::string direction, filename;
+    bool creator = false;
+    ShmHeader* shm = nullptr;
+    size_t mapped = 0;
+    int refs = 0;   // handles given out by create_block / open_block in this process
+
+    size_t shm_size() const { return offsetof(ShmHeader, payload) + shm->max_entry_size_bytes * CMF_BUFFER_CNT; }
+    ~Block()
+    {
+        if (!shm) return;
+        if (creator) {
+            __atomic_store_n(&shm->deleted, (uint8_t)1, __ATOMIC_RELEASE);
+            unlink(filename.c_str());
+        }
+        munmap(shm, mapped);
+    }
+};
+
+namespace {
+
+std::mutex g_registry_mutex;
+std::map<std::string, std::unique_ptr<Block>> g_registry;
+
+bool valid_direction(const char* direction)
+{
+    if (!direction || !*direction) { set_err("empty block name"); return false; }
+    if (strchr(direction, '/')) { set_err("block name contains '/'", direction); return false; }
+    return true;
+}
+
+ShmHeader* map_file(int fd, size_t* mapped)
+{
+    const off_t len = lseek(fd, 0, SEEK_END);
+    if (len < (off_t)offsetof(ShmHeader, payload)) { errno = EINVAL; return nullptr; }
+    void* mem = mmap(nullptr, (size_t)len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (mem == MAP_FAILED) return nullptr;
+    *mapped = (size_t)len;
+    return static_cast<ShmHeader*>(mem);
+}
+
+void init_header(ShmHeader* h, size_t max_entry)
+{
+    memset(h, 0, offsetof(ShmHeader, payload));
+    h->max_entry_size_bytes = max_entry;
+    pthread_condattr_t ca;
+    pthread_condattr_init(&ca);
+    pthread_condattr_setpshared(&ca, PTHREAD_PROCESS_SHARED);
+    pthread_cond_init(&h->cond, &ca);
+    pthread_condattr_destroy(&ca);
+    pthread_mutexattr_t ma;
+    pthread_mutexattr_init(&ma);
+    pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
+    pthread_mutexattr_setrobust(&ma, PTHREAD_MUTEX_ROBUST);
+    pthread_mutex_init(&h->mutex, &ma);
+    pthread_mutexattr_destroy(&ma);
+}
+
+// creator == true: create the file if missing (the creator later unlinks it); false: attach only.
+std::unique_ptr<Block> attach(const std::string& direction, bool creator, size_t max_entry)
+{
+    GlobalLock lock;
+    auto b = std::make_unique<Block>();
+    b->direction = direction;
+    b->filename = std::string(kStub) + direction;
+    b->creator = creator;
+    const bool existed = access(b->filename.c_str(), F_OK) == 0;
+    if (!creator && !existed) { set_err("block does not exist", b->filename); return nullptr; }
+    const int fd = open(b->filename.c_str(), creator ? (O_RDWR | O_CREAT) : O_RDWR, 0700);
+    if (fd < 0) { set_err("open failed", b->filename + ": " + strerror(errno)); return nullptr; }
+    if (!existed) {
+        const size_t bytes = offsetof(ShmHeader, payload) + max_entry * CMF_BUFFER_CNT;
+        if (ftruncate(fd, (off_t)bytes) != 0) {
+            set_err("ftruncate failed", strerror(errno));
+            close(fd);
+            unlink(b->filename.c_str());
+            return nullptr;
+        }
+    }
+    b->shm = map_file(fd, &b->mapped);
+    close(fd);
+    if (!b->shm) {
+        set_err("mmap failed", strerror(errno));
+        if (!existed) unlink(b->filename.c_str());
+        b->creator = false;
+        return nullptr;
+    }
+    if (!existed) init_header(b->shm, max_entry);
+    if (creator && b->shm->max_entry_size_bytes != max_entry) {
+        // reference: removes the file and throws invalid_argument (lib/camera_message_framework.cpp:171-180)
+        set_err("size mismatch with the existing block", b->filename);
+        unlink(b->filename.c_str());
+        b->creator = false;
+        return nullptr;
+    }
+    return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* BLOCK_STUB_CSTR = kStub;
+const int SUCCESS = 0;
+const int NO_NEW_FRAME = 1;
+const int FRAMEWORK_DELETED = 2;
+
+const char* cmf_last_error(void) { return t_err; }
+
+Block* create_block(const char* direction, size_t max_entry_size_bytes)
+{
+    if (!valid_direction(direction)) return nullptr;
+    if (max_entry_size_bytes == 0) { set_err("max_entry_size_bytes must be positive"); return nullptr; }
+    std::lock_guard<std::mutex> g(g_registry_mutex);
+    auto it = g_registry.find(direction);
+    if (it != g_registry.end()) {
+        if (it->second->shm->max_entry_size_bytes == max_entry_size_bytes) { it->second->refs++; return it->second.get(); }
+        set_err("duplicate allocation with a different size", direction);
+        return nullptr;
+    }
+    auto b = attach(direction, true, max_entry_size_bytes);
+    if (!b) return nullptr;
+    b->refs = 1;
+    Block* raw = b.get();
+    g_registry.emplace(direction, std::move(b));
+    return raw;
+}
+
+Block* open_block(const char* direction)
+{
+    if (!valid_direction(direction)) return nullptr;
+    std::lock_guard<std::mutex> g(g_registry_mutex);
+    auto it = g_registry.find(direction);
+    if (it != g_registry.end()) { it->second->refs++; return it->second.get(); }
+    auto b = attach(direction, false, 0);
+    if (!b) return nullptr;
+    b->refs = 1;
+    Block* raw = b.get();
+    g_registry.emplace(direction, std::move(b));
+    return raw;
+}
+
+void delete_block(Block* block)
+{
+    if (!block) return;
+    std::lock_guard<std::mutex> g(g_registry_mutex);
+    // look the handle up by value: a stale pointer (already released) must not be dereferenced.  The reference
+    // destroys the block on the first delete even when another accessor of the same process still holds it;
+    // here every create/open is matched by one delete and the last one destroys.
+    for (auto it = g_registry.begin(); it != g_registry.end(); ++it) {
+        if (it->second.get() != block) continue;
+        if (--it->second->refs <= 0) {
+            GlobalLock lock;   // destruction is serialised with attach
+            g_registry.erase(it);
+        }
+        return;
+    }
+}
+
+int write_frame_planes(Block* block, uint64_t acquisition_time, const FramePlaneWrite* planes, size_t plane_count)
+{
+    if (!block || !block->shm) { set_err("null block"); return CMF_ERR_INVALID; }
+    ShmHeader* h = block->shm;
+    if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    if (!planes) { set_err("planes pointer cannot be null"); return CMF_ERR_INVALID; }
+    if (plane_count == 0 || plane_count > CMF_MAX_PLANE_CNT) { set_err("invalid plane count"); return CMF_ERR_INVALID; }
+    size_t entry = 0;
+    for (size_t i = 0; i < plane_count; i++) {
+        const FramePlaneWrite& p = planes[i];
+        if (!p.data) { set_err("plane has null data pointer"); return CMF_ERR_INVALID; }
+        if (p.type_size != 1 && p.type_size != 4 && p.type_size != 8) { set_err("unsupported type size (expected 1, 4 or 8)"); return CMF_ERR_INVALID; }
+        entry += p.width * p.height * p.depth * p.type_size;
+    }
+    if (entry > h->max_entry_size_bytes) { set_err("frame larger than the block's max_entry_size_bytes"); return CMF_ERR_TOO_LARGE; }
+
+    const uint64_t uid = load_acq(&h->uid);
+    const size_t idx = (size_t)((uid + 1) % CMF_BUFFER_CNT);
+    ShmSlot& s = h->slots[idx];
+    const uint64_t seq = load_acq(&s.seq_begin) + 1;
+    store_rel(&s.seq_begin, seq);                       // readers of this slot now see begin != end
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    unsigned char* dst = h->payload + idx * h->max_entry_size_bytes;
+    size_t cursor = 0;
+    for (size_t i = 0; i < plane_count; i++) {
+        const FramePlaneWrite& p = planes[i];
+        const size_t bytes = p.width * p.height * p.depth * p.type_size;
+        memcpy(dst + cursor, p.data, bytes);
+        ShmPlane& m = s.planes[i];
+        m.width = p.width; m.height = p.height; m.depth = p.depth; m.type_size = p.type_size; m.offset = cursor;
+        memset(m.name, 0, sizeof m.name);
+        if (p.name) strncpy(m.name, p.name, CMF_PLANE_NAME_MAX_LEN - 1);
+        cursor += bytes;
+    }
+    for (size_t i = plane_count; i < CMF_MAX_PLANE_CNT; i++) memset(&s.planes[i], 0, sizeof(ShmPlane));
+    s.acquisition_time = acquisition_time;
+    s.total_size = entry;
+    s.plane_count = plane_count;
+    s.width = planes[0].width; s.height = planes[0].height; s.depth = planes[0].depth; s.type_size = planes[0].type_size;
+    store_rel(&s.seq_end, seq);                         // frame complete
+    __atomic_fetch_add(&h->uid, 1, __ATOMIC_ACQ_REL);   // publish: slot uid % 3 is the newest
+    pthread_cond_broadcast(&h->cond);
+    return SUCCESS;
+}
+
+int write_frame(Block* block, uint64_t acquisition_time, size_t width, size_t height, size_t depth, size_t type_size,
+                const unsigned char* data)
+{
+    FramePlaneWrite p{width, height, depth, type_size, data, nullptr};
+    return write_frame_planes(block, acquisition_time, &p, 1);
+}
+
+int read_frame(Block* block, Frame* frame, bool block_thread)
+{
+    if (!block || !block->shm || !frame) { set_err("null block or frame"); return CMF_ERR_INVALID; }
+    ShmHeader* h = block->shm;
+    if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    if (block_thread && frame->uid >= load_acq(&h->uid)) {
+        int rc = pthread_mutex_lock(&h->mutex);
+        if (rc == EOWNERDEAD) { pthread_mutex_consistent(&h->mutex); rc = 0; }   // a holder died: repair and carry on
+        if (rc == 0) {
+            if (frame->uid >= load_acq(&h->uid)) {
+                struct timeval now;
+                gettimeofday(&now, nullptr);
+                struct timespec until;
+                until.tv_sec = now.tv_sec + 1;
+                until.tv_nsec = now.tv_usec * 1000L;
+                pthread_cond_timedwait(&h->cond, &h->mutex, &until);
+            }
+            pthread_mutex_unlock(&h->mutex);
+        }
+        if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    }
+    if (frame->uid >= load_acq(&h->uid)) return NO_NEW_FRAME;
+
+    PrivFrame* pf = reinterpret_cast<PrivFrame*>(frame);
+    if (pf->capacity < h->max_entry_size_bytes) {
+        void* grown = realloc(frame->data, h->max_entry_size_bytes);
+        if (!grown) { set_err("out of memory"); return CMF_ERR_INVALID; }
+        frame->data = grown;
+        pf->capacity = h->max_entry_size_bytes;
+    }
+    for (;;) {
+        const uint64_t uid = load_acq(&h->uid);
+        const ShmSlot& s = h->slots[uid % CMF_BUFFER_CNT];
+        const uint64_t end = load_acq(&s.seq_end);
+        frame->width = s.width; frame->height = s.height; frame->depth = s.depth; frame->type_size = s.type_size;
+        frame->acquisition_time = s.acquisition_time;
+        frame->uid = uid;
+        size_t total = s.total_size;
+        if (total > h->max_entry_size_bytes) total = h->max_entry_size_bytes;   // torn metadata: retry below
+        frame->total_size = total;
+        frame->plane_count = (size_t)s.plane_count <= CMF_MAX_PLANE_CNT ? (size_t)s.plane_count : 0;
+        for (size_t i = 0; i < CMF_MAX_PLANE_CNT; i++) {
+            const ShmPlane& m = s.planes[i];
+            FramePlane& o = frame->planes[i];
+            o.width = m.width; o.height = m.height; o.depth = m.depth; o.type_size = m.type_size; o.offset = m.offset;
+            memcpy(o.name, m.name, CMF_PLANE_NAME_MAX_LEN);
+            o.name[CMF_PLANE_NAME_MAX_LEN - 1] = '\0';
+        }
+        memcpy(frame->data, h->payload + (uid % CMF_BUFFER_CNT) * h->max_entry_size_bytes, total);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        const uint64_t begin = load_acq(&s.seq_begin);
+        if (begin == end) return SUCCESS;
+        if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    }
+}
+
+Frame* create_frame(void)
+{
+    PrivFrame* pf = static_cast<PrivFrame*>(calloc(1, sizeof(PrivFrame)));
+    if (!pf) return nullptr;
+    pf->pub.data = malloc(64);
+    pf->capacity = pf->pub.data ? 64 : 0;
+    return &pf->pub;
+}
+
+void delete_frame(Frame* frame)
+{
+    if (!frame) return;
+    free(frame->data);
+    free(reinterpret_cast<PrivFrame*>(frame));
+}
+
+uint64_t frame_size(Frame* frame) { return frame ? frame->total_size : 0; }
+
+}  // extern "C"

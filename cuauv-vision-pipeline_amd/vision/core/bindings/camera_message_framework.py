@@ -1,0 +1,260 @@
+"""ctypes binding of libcamera_message_framework.so (C ABI: include/camera_message_framework_c.h).
+
+Mirror of the reference's cffi binding (core/bindings/camera_message_framework.py:70-441): same public names
+(`BlockAccessor`, `ReadStatus`, `WriteStatus`, `BLOCK_STUB`, `encode_str`, `decode_str`), same constructor
+arguments, same return structure of `read_frame` / `write_frame`, same exceptions.  cffi is not available in
+the target image, so the ABI is bound with ctypes; the native side never throws — negative statuses are
+turned into the RuntimeError / ValueError the reference's library would have produced by throwing.
+"""
+import ctypes as C
+import enum
+import os
+import sys
+import time
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))),
+                         "lib", "libcamera_message_framework.so")
+MAX_PLANES = 4
+
+
+class _FramePlane(C.Structure):
+    _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("depth", C.c_size_t), ("type_size", C.c_size_t),
+                ("offset", C.c_size_t), ("name", C.c_char * 32)]
+
+
+class _Frame(C.Structure):
+    _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("depth", C.c_size_t), ("type_size", C.c_size_t),
+                ("acquisition_time", C.c_uint64), ("uid", C.c_uint64), ("data", C.c_void_p),
+                ("total_size", C.c_size_t), ("plane_count", C.c_size_t), ("planes", _FramePlane * MAX_PLANES)]
+
+
+class _FramePlaneWrite(C.Structure):
+    _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("depth", C.c_size_t), ("type_size", C.c_size_t),
+                ("data", C.c_void_p), ("name", C.c_char_p)]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} is missing: build it with `python cuauv-vision-pipeline_amd/build.py`")
+    lib = C.CDLL(_LIB_PATH)
+    lib.create_block.restype = C.c_void_p
+    lib.create_block.argtypes = [C.c_char_p, C.c_size_t]
+    lib.open_block.restype = C.c_void_p
+    lib.open_block.argtypes = [C.c_char_p]
+    lib.delete_block.restype = None
+    lib.delete_block.argtypes = [C.c_void_p]
+    lib.write_frame.restype = C.c_int
+    lib.write_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.write_frame_planes.restype = C.c_int
+    lib.write_frame_planes.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_FramePlaneWrite), C.c_size_t]
+    lib.read_frame.restype = C.c_int
+    lib.read_frame.argtypes = [C.c_void_p, C.POINTER(_Frame), C.c_bool]
+    lib.create_frame.restype = C.POINTER(_Frame)
+    lib.create_frame.argtypes = []
+    lib.delete_frame.restype = None
+    lib.delete_frame.argtypes = [C.POINTER(_Frame)]
+    lib.frame_size.restype = C.c_uint64
+    lib.frame_size.argtypes = [C.POINTER(_Frame)]
+    lib.cmf_last_error.restype = C.c_char_p
+    return lib
+
+
+_dllib = _load()
+
+
+def _const_int(name):
+    return C.c_int.in_dll(_dllib, name).value
+
+
+class ReadStatus(enum.Enum):
+    """Status of BlockAccessor.read_frame (include/camera_message_framework.hpp:18-24)."""
+    SUCCESS = _const_int("SUCCESS")
+    NO_NEW_FRAME = _const_int("NO_NEW_FRAME")
+    FRAMEWORK_DELETED = _const_int("FRAMEWORK_DELETED")
+
+
+class WriteStatus(enum.Enum):
+    """Status of BlockAccessor.write_frame."""
+    SUCCESS = _const_int("SUCCESS")
+    FRAMEWORK_DELETED = _const_int("FRAMEWORK_DELETED")
+
+
+BLOCK_STUB = C.c_char_p.in_dll(_dllib, "BLOCK_STUB_CSTR").value.decode()
+
+
+def encode_str(s: str):
+    """str -> uint8 array (reference binding :94-104)."""
+    return np.frombuffer(s.encode("utf-8"), dtype=np.uint8)
+
+
+def decode_str(arr: np.ndarray):
+    """uint8 array -> str (reference binding :107-117)."""
+    return arr.tobytes().decode("utf-8")
+
+
+def _caller_line():
+    return f"{__file__}:{sys._getframe(2).f_lineno}"
+
+
+class BlockAccessor:
+    """Context-managed handle on one shared-memory block (reference binding :120-441).
+
+    With `max_entry_size_bytes` the block is created (and unlinked again on exit); without it the
+    accessor waits, polling once per second, until some other process has created it.  Planes are
+    numpy arrays of 1-3 dimensions whose item size is 1, 4 or 8 bytes."""
+
+    def __init__(self, direction: str, max_entry_size_bytes: Optional[int] = None, byte_type: type = np.uint8,
+                 short_type: type = np.float32, long_type: type = np.float64, block_thread: bool = False):
+        assert max_entry_size_bytes is None or max_entry_size_bytes > 0, \
+            "max_entry_size_bytes, when specified, should be a positive integer"
+        assert np.dtype(byte_type).itemsize == 1, "byte type must be 1 byte wide"
+        assert np.dtype(short_type).itemsize == 4, "short type must be 4 bytes wide"
+        assert np.dtype(long_type).itemsize == 8, "long type must be 8 bytes wide"
+        self._direction = direction
+        self._max_entry_size_bytes = max_entry_size_bytes
+        self._type_lookup = {1: byte_type, 4: short_type, 8: long_type}
+        self._inside_ctx_manager = False
+        self._block_ptr = None
+        self._frame_ptr = None
+        self._frame_data: Optional[Union[np.ndarray, Tuple[np.ndarray, ...]]] = None
+        self._last_plane_names: Tuple[str, ...] = tuple()
+        self._block_thread = block_thread
+        self._acquisition_time = 0
+
+    @property
+    def direction(self) -> str:
+        return self._direction
+
+    def block_thread(self) -> "BlockAccessor":
+        self._block_thread = True
+        return self
+
+    def unblock_thread(self) -> "BlockAccessor":
+        self._block_thread = False
+        return self
+
+    def last_plane_names(self) -> Tuple[str, ...]:
+        return self._last_plane_names
+
+    # -- writing ---------------------------------------------------------------------------------
+    @staticmethod
+    def _split_planes(frame) -> Tuple[List[np.ndarray], List[str]]:
+        if isinstance(frame, np.ndarray):
+            return [frame], [""]
+        if not isinstance(frame, Sequence):
+            raise TypeError("frame must be an ndarray or a sequence of ndarrays")
+        if len(frame) == 0:
+            raise ValueError("empty frame sequence passed to write_frame")
+        planes, names = [], []
+        for idx, item in enumerate(frame):
+            if isinstance(item, np.ndarray):
+                names.append("")
+                planes.append(item)
+            elif isinstance(item, tuple) and len(item) == 2 and isinstance(item[0], str) and isinstance(item[1], np.ndarray):
+                names.append(item[0])
+                planes.append(item[1])
+            else:
+                raise TypeError(f"frame at index {idx} must be an ndarray or (name:str, ndarray)")
+        return planes, names
+
+    def write_frame(self, acquisition_time_ms: int, frame):
+        """Writes one ndarray, a sequence of ndarrays, or a sequence of (name, ndarray) as the planes of one frame."""
+        if not self._inside_ctx_manager:
+            raise RuntimeError(f"Attempted to access block while not in a context manager: {_caller_line()}")
+        planes, names = self._split_planes(frame)
+        keep = []
+        descs = (_FramePlaneWrite * len(planes))()
+        for idx, (plane, name) in enumerate(zip(planes, names)):
+            arr = np.ascontiguousarray(plane)
+            if arr.ndim == 0 or arr.ndim > 3:
+                raise RuntimeError(f"np.ndarray at index {idx} has {arr.ndim} dimensions, expected between 1-3")
+            if arr.itemsize not in self._type_lookup:
+                raise RuntimeError(f"np.ndarray at index {idx} has unsupported dtype width of {arr.itemsize} bytes")
+            keep.append(arr)
+            d = descs[idx]
+            d.height = arr.shape[0]
+            d.width = arr.shape[1] if arr.ndim > 1 else 1
+            d.depth = arr.shape[2] if arr.ndim > 2 else 1
+            d.type_size = arr.itemsize
+            d.data = arr.ctypes.data
+            d.name = name.encode("utf-8")
+        rc = _dllib.write_frame_planes(self._block_ptr, int(acquisition_time_ms), descs, len(planes))
+        if rc < 0:
+            # the reference library throws here (invalid_argument / runtime_error)
+            raise RuntimeError(f"write_frame on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
+        return WriteStatus(rc)
+
+    # -- reading ---------------------------------------------------------------------------------
+    def read_frame(self):
+        """-> (ReadStatus, ndarray | tuple of ndarrays | None, acquisition time).  Arrays are (h, w, d) views of the
+        library's buffer, valid until the next read_frame: copy before keeping them."""
+        if not self._inside_ctx_manager:
+            raise RuntimeError(f"Attempted to access block while not in a context manager: {_caller_line()}")
+        rc = _dllib.read_frame(self._block_ptr, self._frame_ptr, self._block_thread)
+        if rc < 0:
+            raise RuntimeError(f"read_frame on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
+        status = ReadStatus(rc)
+        if status != ReadStatus.SUCCESS:
+            return status, self._frame_data, self._acquisition_time
+        fr = self._frame_ptr.contents
+        self._acquisition_time = int(fr.acquisition_time)
+        total, count = int(fr.total_size), int(fr.plane_count)
+        if count == 0 or total == 0:
+            self._frame_data, self._last_plane_names = None, tuple()
+            return status, None, self._acquisition_time
+        raw = (C.c_ubyte * total).from_address(fr.data)
+        planes, names = [], []
+        for idx in range(count):
+            m = fr.planes[idx]
+            w, h, d, item, off = int(m.width), int(m.height), int(m.depth), int(m.type_size), int(m.offset)
+            dtype = self._type_lookup.get(item)
+            if dtype is None:
+                raise RuntimeError(f"encountered unsupported type size {item} while reading plane {idx}")
+            nbytes = w * h * d * item
+            if off + nbytes > total:
+                raise RuntimeError(f"plane {idx} with size {nbytes} at offset {off} exceeds frame size {total}")
+            planes.append(np.frombuffer(raw, dtype=dtype, count=w * h * d, offset=off).reshape(h, w, d))
+            names.append(m.name.decode())
+        self._frame_data = planes[0] if count == 1 else tuple(planes)
+        self._last_plane_names = tuple(names)
+        return status, self._frame_data, self._acquisition_time
+
+    # -- lifetime --------------------------------------------------------------------------------
+    def __enter__(self):
+        if self._inside_ctx_manager:
+            raise RuntimeError(f"Double dip in context manager: {_caller_line()}")
+        name = self._direction.encode("utf8")
+        if self._max_entry_size_bytes is None:
+            ptr, tries = _dllib.open_block(name), 0
+            while not ptr:
+                tries += 1
+                print(f"trying again to access {self._direction} in 1s, retry count={tries:<2}", end="\r", flush=True)
+                time.sleep(1)
+                ptr = _dllib.open_block(name)
+            if tries:
+                print(f"\nfound {self._direction}!!!", flush=True)
+        else:
+            ptr = _dllib.create_block(name, int(self._max_entry_size_bytes))
+            if not ptr:
+                raise RuntimeError(f"Failed to access {self._direction}: {_dllib.cmf_last_error().decode()}")
+        self._block_ptr = ptr
+        self._frame_ptr = _dllib.create_frame()
+        self._acquisition_time, self._frame_data = 0, None
+        self._inside_ctx_manager = True
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        if self._block_ptr:
+            _dllib.delete_block(self._block_ptr)
+        if self._frame_ptr:
+            _dllib.delete_frame(self._frame_ptr)
+        self._block_ptr = self._frame_ptr = None
+        self._frame_data = None
+        self._inside_ctx_manager = False
+
+    def __str__(self) -> str:
+        kinds = ":".join(f"{size}->{np.dtype(t).name}" for size, t in sorted(self._type_lookup.items()))
+        return f"Accessor(direction={self._direction}, datatypes={kinds})"

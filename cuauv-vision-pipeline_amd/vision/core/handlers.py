@@ -1,0 +1,54 @@
+"""Handlers: post-processing hooks that borrow their parent module's services (mirror of the reference
+core/handlers.py:18-99).  A handler registered through HandlerMixin gets the parent's normalize / normalize_axis /
+post / tuners / get_latency bound onto itself, so handler code reads like module code."""
+from abc import ABC, abstractmethod
+from typing import Dict, List
+
+import numpy as np
+
+_BORROWED = ("normalize_axis", "normalize", "post", "tuners", "get_latency", "_loop")
+
+
+class HandlerBase(ABC):
+    def __init__(self, name: str, parent=None):
+        self._name = name
+        self._parent = parent
+        if parent is not None:
+            self._initialize_methods()
+
+    def register(self, parent):
+        self._parent = parent
+        self._initialize_methods()
+
+    def _initialize_methods(self):
+        for attr in _BORROWED:
+            setattr(self, attr, getattr(self._parent, attr))
+
+    @abstractmethod
+    def process(self, direction: str, image: np.ndarray, *args, **kwargs):
+        raise NotImplementedError("HandlerBase.process")
+
+    @property
+    def name(self):
+        return self._name
+
+
+class HandlerMixin:
+    def __init__(self, handlers: List[HandlerBase] = []):
+        self._handlers: Dict[str, HandlerBase] = {}
+        self._handler_names = set()
+        for handler in handlers:
+            self._handlers[handler.name] = handler
+            if handler.name in self._handler_names:
+                raise KeyError("Duplicate handler names found!")
+            self._handler_names.add(handler.name)
+        for handler in self._handlers.values():
+            handler.register(self)
+
+    @property
+    def handlers(self):
+        return self._handlers
+
+    @property
+    def handler_names(self):
+        return self._handler_names

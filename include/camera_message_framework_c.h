@@ -1,0 +1,86 @@
+/*
+ * camera_message_framework_c.h — C ABI of libcamera_message_framework.so, the shared-memory frame ring
+ * ("CMF") between capture sources, vision modules and the GUI.
+ *
+ * Drop-in for the reference's lib/camera_message_framework_c.cpp:18-103 (cdef mirrored by
+ * core/bindings/camera_message_framework.py:13-68): same 9 functions, same 4 data symbols, same
+ * struct layouts, same file layout of /dev/shm/auv_visiond_<direction>
+ * (lib/camera_message_framework.cpp:27-54, include/camera_message_framework.hpp:9-30), so old and new
+ * processes can share a block.  Differences, all inside what the old ABI allowed:
+ *   - nothing throws across the ABI: failures return NULL / a negative status and cmf_last_error()
+ *     explains (the reference throws C++ exceptions out of `extern "C"`, lib/...cpp:261-304);
+ *   - the writer bumps the slot's first sequence word *before* copying the payload (seqlock
+ *     begin/end), closing the window in which a lapped reader could accept a half-new payload.
+ */
+#ifndef CAMERA_MESSAGE_FRAMEWORK_C_H
+#define CAMERA_MESSAGE_FRAMEWORK_C_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMF_BUFFER_CNT 3          /* include/camera_message_framework.hpp:9  */
+#define CMF_MAX_PLANE_CNT 4       /* :12 */
+#define CMF_PLANE_NAME_MAX_LEN 32 /* :15 */
+
+/* status codes (hpp:18-24) — also exported as data symbols, like the reference */
+extern const char* BLOCK_STUB_CSTR; /* "/dev/shm/auv_visiond_" */
+extern const int SUCCESS;           /* 0 */
+extern const int NO_NEW_FRAME;      /* 1 */
+extern const int FRAMEWORK_DELETED; /* 2 */
+/* additional negative statuses of this implementation (the reference throws instead) */
+#define CMF_ERR_INVALID (-1)   /* null pointer, plane count not in 1..4, type size not 1/4/8 */
+#define CMF_ERR_TOO_LARGE (-2) /* payload larger than the block's max_entry_size_bytes */
+
+typedef struct Block Block; /* opaque; owned by the library's process-global registry */
+
+typedef struct FramePlane { /* 72 bytes (hpp:39-46) */
+    size_t width, height, depth, type_size, offset;
+    char name[CMF_PLANE_NAME_MAX_LEN];
+} FramePlane;
+
+typedef struct Frame { /* 360 bytes (hpp:48-85) */
+    size_t width, height, depth, type_size;
+    uint64_t acquisition_time;
+    uint64_t uid;
+    void* data; /* library-owned; valid until the next read_frame on this Frame */
+    size_t total_size;
+    size_t plane_count;
+    FramePlane planes[CMF_MAX_PLANE_CNT];
+} Frame;
+
+typedef struct FramePlaneWrite { /* 48 bytes (hpp:91-98) */
+    size_t width, height, depth, type_size;
+    const void* data;
+    const char* name; /* may be NULL */
+} FramePlaneWrite;
+
+/* cmf_c.cpp:23-41: create (or attach to) the block of `direction`; the creator unlinks it on
+ * delete_block.  Same direction + same size returns the same pointer; a size mismatch returns NULL. */
+Block* create_block(const char* direction, size_t max_entry_size_bytes);
+/* cmf_c.cpp:43-60: attach to an existing block; NULL when the file does not exist. */
+Block* open_block(const char* direction);
+/* cmf_c.cpp:62-65 */
+void delete_block(Block* block);
+/* cmf_c.cpp:67-77 */
+int write_frame(Block* block, uint64_t acquisition_time, size_t width, size_t height, size_t depth, size_t type_size,
+                const unsigned char* data);
+/* cmf_c.cpp:79-86 */
+int write_frame_planes(Block* block, uint64_t acquisition_time, const FramePlaneWrite* planes, size_t plane_count);
+/* cmf_c.cpp:88-90: latest-wins read; NO_NEW_FRAME when frame->uid is current; block_thread waits <= 1 s. */
+int read_frame(Block* block, Frame* frame, bool block_thread);
+/* cmf_c.cpp:92-102 */
+Frame* create_frame(void);
+void delete_frame(Frame* frame);
+uint64_t frame_size(Frame* frame);
+
+/* not in the reference: text of the last failure on this thread */
+const char* cmf_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,167 @@
+"""CPU suite: the shared-memory frame ring (libcamera_message_framework.so) — file layout, statuses, multi-plane
+frames, error paths, cross-process visibility and the seqlock under a hammering writer.  Behaviours follow the
+reference's lib/camera_message_framework.cpp and its binding (cited in include/camera_message_framework_c.h)."""
+import ctypes as C
+import multiprocessing as mp
+import os
+import re
+import struct
+import time
+
+import numpy as np
+import pytest
+
+from vision.core.bindings import camera_message_framework as cmf
+from vision.core.bindings.camera_message_framework import BLOCK_STUB, BlockAccessor, ReadStatus, WriteStatus
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _name(tag):
+    return f"pytest_{os.getpid()}_{tag}"
+
+
+def test_exports_every_declared_symbol():
+    txt = open(os.path.join(ROOT, "include", "camera_message_framework_c.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    funcs = set(re.findall(r"\b([a-z_]+)\s*\(", " ".join(l for l in txt.splitlines() if not l.strip().startswith("#"))))
+    funcs -= {"defined"}
+    lib = C.CDLL(cmf._LIB_PATH)
+    for n in sorted(funcs) + ["BLOCK_STUB_CSTR", "SUCCESS", "NO_NEW_FRAME", "FRAMEWORK_DELETED"]:
+        assert hasattr(lib, n), n
+    assert {"create_block", "open_block", "delete_block", "write_frame", "write_frame_planes", "read_frame", "create_frame",
+            "delete_frame", "frame_size"} <= funcs
+    assert BLOCK_STUB == "/dev/shm/auv_visiond_"
+    assert (ReadStatus.SUCCESS.value, ReadStatus.NO_NEW_FRAME.value, ReadStatus.FRAMEWORK_DELETED.value) == (0, 1, 2)
+    assert C.sizeof(cmf._FramePlane) == 72 and C.sizeof(cmf._Frame) == 360 and C.sizeof(cmf._FramePlaneWrite) == 48
+
+
+def test_file_layout_and_roundtrip():
+    d = _name("layout")
+    path = BLOCK_STUB + d
+    with BlockAccessor(d, max_entry_size_bytes=60) as w, BlockAccessor(d) as r:
+        assert os.path.getsize(path) == 1216 + 3 * 60          # header + BUFFER_CNT slots
+        assert r.read_frame()[0] == ReadStatus.NO_NEW_FRAME
+        a = np.arange(60, dtype=np.uint8).reshape(4, 5, 3)
+        assert w.write_frame(777, a) == WriteStatus.SUCCESS
+        raw = open(path, "rb").read()
+        uid, max_entry, deleted = struct.unpack_from("<QQB", raw, 0)
+        assert (uid, max_entry, deleted) == (1, 60, 0)
+        # slot (uid % 3) = 1 at 24 + 360: seq_begin, seq_end, acquisition_time, total_size, width, height, depth, type_size, planes
+        seq_b, seq_e, acq, total, wd, ht, dp, ts, pc = struct.unpack_from("<9Q", raw, 24 + 360)
+        assert (seq_b, seq_e, acq, total, wd, ht, dp, ts, pc) == (1, 1, 777, 60, 5, 4, 3, 1, 1)
+        assert raw[1216 + 60: 1216 + 120] == a.tobytes()
+        st, got, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 777 and got.shape == (4, 5, 3) and np.array_equal(got, a)
+        assert r.read_frame()[0] == ReadStatus.NO_NEW_FRAME
+        for k in range(7):                                       # the ring wraps; the reader always gets the newest
+            w.write_frame(k, a + k)
+        st, got, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 6 and np.array_equal(got, a + 6)
+    assert not os.path.exists(path)                              # the creator unlinks on exit
+
+
+def test_planes_names_and_types():
+    d = _name("planes")
+    bgr = np.random.default_rng(0).integers(0, 255, (6, 8, 3), dtype=np.uint8)
+    normal = np.random.default_rng(1).random((6, 8, 3)).astype(np.float32)
+    depth = np.random.default_rng(2).random((6, 8)).astype(np.float64)
+    total = bgr.nbytes + normal.nbytes + depth.nbytes
+    with BlockAccessor(d, max_entry_size_bytes=total) as w, BlockAccessor(d, short_type=np.float32) as r:
+        w.write_frame(1, [("forward", bgr), ("normal", normal), ("a_plane_name_longer_than_thirty_one_chars", depth)])
+        st, planes, _ = r.read_frame()
+        assert st == ReadStatus.SUCCESS and len(planes) == 3
+        assert np.array_equal(planes[0], bgr) and np.array_equal(planes[1], normal)
+        assert planes[2].shape == (6, 8, 1) and np.array_equal(planes[2][:, :, 0], depth)
+        assert r.last_plane_names() == ("forward", "normal", "a_plane_name_longer_than_thirty_one_chars"[:31])
+        w.write_frame(2, np.arange(5, dtype=np.int8))            # 1-D -> (5, 1, 1), unnamed
+        st, one, _ = r.read_frame()
+        assert one.shape == (5, 1, 1) and r.last_plane_names() == ("",)
+    with BlockAccessor(d + "i", max_entry_size_bytes=64) as w, BlockAccessor(d + "i", byte_type=np.int8, short_type=np.int32) as r:
+        w.write_frame(3, np.array([[-1, 2]], dtype=np.int32))
+        assert r.read_frame()[1].dtype == np.int32
+
+
+def test_error_paths():
+    d = _name("errors")
+    acc = BlockAccessor(d, max_entry_size_bytes=16)
+    with pytest.raises(RuntimeError):
+        acc.write_frame(0, np.zeros(4, np.uint8))                 # not inside the context manager
+    with pytest.raises(RuntimeError):
+        acc.read_frame()
+    with acc as w:
+        with pytest.raises(RuntimeError):
+            w.__enter__()                                         # double entry
+        with pytest.raises(RuntimeError):
+            w.write_frame(0, np.zeros(64, np.uint8))              # larger than max_entry_size_bytes
+        with pytest.raises(RuntimeError):
+            w.write_frame(0, np.zeros(4, np.int16))               # 2-byte items are not representable
+        with pytest.raises(RuntimeError):
+            w.write_frame(0, np.zeros((1, 1, 1, 1), np.uint8))    # more than 3 dimensions
+        with pytest.raises(ValueError):
+            w.write_frame(0, [])
+        with pytest.raises(TypeError):
+            w.write_frame(0, [("a", 3)])
+        with pytest.raises(TypeError):
+            w.write_frame(0, "nope")
+        with pytest.raises(RuntimeError):
+            BlockAccessor(d, max_entry_size_bytes=32).__enter__()  # same name, different size
+    lib = cmf._dllib
+    assert not lib.create_block(b"has/slash", 8) and b"/" in lib.cmf_last_error()
+    assert not lib.open_block(b"pytest_surely_missing_block")
+    with pytest.raises(AssertionError):
+        BlockAccessor("x", max_entry_size_bytes=0)
+
+
+def _child_writer(name, n, shape, ready, go):
+    with BlockAccessor(name, max_entry_size_bytes=int(np.prod(shape))) as w:
+        ready.set()
+        go.wait(10)
+        for k in range(1, n + 1):
+            w.write_frame(k, np.full(shape, k % 251, np.uint8))
+        time.sleep(0.3)
+    # leaving the context marks the block deleted and unlinks it
+
+
+def test_cross_process_seqlock_and_deletion():
+    """A writer process hammers a block; every frame the reader accepts must be internally consistent (all bytes equal
+    and matching its acquisition time), sequence never goes backwards, and the reader sees FRAMEWORK_DELETED at the end."""
+    d = _name("xproc")
+    ctx = mp.get_context("fork")
+    ready, go = ctx.Event(), ctx.Event()
+    shape = (64, 64, 3)
+    n = 3000
+    p = ctx.Process(target=_child_writer, args=(d, n, shape, ready, go))
+    p.start()
+    assert ready.wait(10)
+    seen, last_t, deleted = 0, 0, False
+    with BlockAccessor(d) as r:
+        go.set()
+        deadline = time.time() + 30
+        while time.time() < deadline:
+            st, data, t = r.read_frame()
+            if st == ReadStatus.FRAMEWORK_DELETED:
+                deleted = True
+                break
+            if st == ReadStatus.SUCCESS:
+                assert data.min() == data.max() == t % 251, "torn frame accepted"
+                assert t > last_t
+                last_t = t
+                seen += 1
+    p.join(10)
+    assert deleted and seen >= 1 and last_t <= n
+    assert not os.path.exists(BLOCK_STUB + d)
+
+
+def test_blocking_read_wakes_on_write():
+    d = _name("block")
+    import threading
+    with BlockAccessor(d, max_entry_size_bytes=8) as w, BlockAccessor(d, block_thread=True) as r:
+        t0 = time.time()
+        threading.Timer(0.15, lambda: w.write_frame(9, np.ones(8, np.uint8))).start()
+        st, data, t = r.read_frame()
+        waited = time.time() - t0
+        if st == ReadStatus.NO_NEW_FRAME:                       # woken spuriously or timed out: read again
+            st, data, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 9 and 0.05 < waited < 1.5
+        assert r.unblock_thread().read_frame()[0] == ReadStatus.NO_NEW_FRAME
