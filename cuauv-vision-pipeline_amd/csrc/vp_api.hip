@@ -627,6 +627,57 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, 
     return vp_synchronize(ctx);
 }
 
+int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, int mode, int method, int32_t* points,
+                        int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours, int64_t* n_points)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || w <= 0 || h <= 0 || src_stride < (size_t)w || !n_contours || !n_points || max_contours < 0 || max_points < 0)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_find_contours_u8 arguments");
+    const size_t npx = (size_t)w * h;
+    const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
+    const int mc = max_contours > 0 ? max_contours : 1;
+    const long long mp = max_points > 0 ? max_points : 1;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx) + vp_align(bitbytes) + vp_contours_ws_bytes(w, h, 1) + 3 * vp_align((size_t)mc * 4) + vp_align((size_t)mc) +
+                                  vp_align((size_t)mp * 8) + 8192));
+    TAKE(d_src, uint8_t*, npx);
+    TAKE(d_bits, u64*, bitbytes);
+    TAKE(d_counts, int32_t*, (size_t)mc * 4);
+    TAKE(d_offsets, int32_t*, (size_t)mc * 4);
+    TAKE(d_hole, uint8_t*, (size_t)mc);
+    TAKE(d_points, int32_t*, (size_t)mp * 8);
+    TAKE(d_info, int32_t*, 8);
+    VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
+    VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
+    VP_TRY(vpk_find_contours(ctx, d_bits, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info));
+    int32_t info[2] = {0, 0};
+    VP_TRY(d2h(ctx, info, d_info, 8));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_contours = info[0];
+    if (info[0] > max_contours) {   // the point total is only known for the contours that were traced
+        *n_points = (int64_t)info[1] > max_points ? (int64_t)info[1] : max_points;
+        return VP_OK;
+    }
+    *n_points = info[1];
+    if (info[1] > max_points || info[0] == 0) return VP_OK;
+    const int K = info[0];
+    std::vector<int32_t> hc(K), ho(K), hp((size_t)info[1] * 2);
+    std::vector<uint8_t> hh(K);
+    VP_TRY(d2h(ctx, hc.data(), d_counts, (size_t)K * 4));
+    VP_TRY(d2h(ctx, ho.data(), d_offsets, (size_t)K * 4));
+    VP_TRY(d2h(ctx, hh.data(), d_hole, (size_t)K));
+    VP_TRY(d2h(ctx, hp.data(), d_points, (size_t)info[1] * 8));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // device order = discovery order; cv2 hands contours back newest first
+    size_t o = 0;
+    for (int k = K - 1, j = 0; k >= 0; k--, j++) {
+        if (points) memcpy(points + 2 * o, hp.data() + 2 * (size_t)ho[k], (size_t)hc[k] * 8);
+        o += (size_t)hc[k];
+        if (counts) counts[j] = hc[k];
+        if (is_hole) is_hole[j] = hh[k];
+    }
+    return VP_OK;
+}
+
 // ---- chain -------------------------------------------------------------------------------------------
 
 static int check_desc(vp_ctx* ctx, const vp_chain_desc* d, int n)

@@ -32,7 +32,20 @@ struct ccl_geom {
     int w, h, ww, wb, numbering;
     u32 nids;   // multiple of 128
     u32 nw32;   // nids / 32
+    int invert; // label the zero pixels instead (background regions, for hole borders)
+    int conn4;  // 4-connectivity (background of an 8-connected foreground)
 };
+
+// word j of a row as the labelling sees it
+__device__ __forceinline__ u64 ccl_word(const ccl_geom& G, const u64* __restrict__ fb, int idx, int j)
+{
+    u64 w = fb[idx];
+    if (G.invert) {
+        w = ~w;
+        if (j == G.ww - 1 && (G.w & 63)) w &= (1ull << (G.w & 63)) - 1ull;
+    }
+    return w;
+}
 
 struct ccl_acc {   // 48 B
     u32 area;
@@ -133,13 +146,13 @@ __device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, con
                                                  int idx, u64 w, bool horiz, bool vert)
 {
     if (horiz && (w & 1ull) && j > 0) {
-        const u64 prev = fb[idx - 1];
+        const u64 prev = ccl_word(G, fb, idx - 1, j - 1);
         if (prev >> 63) uf_unite(p, flags, seg_id(G, y, 64 * j), seg_id(G, y, 64 * (j - 1) + run_start(prev, 63)));
     }
     if (!vert || y == 0) return;
-    const u64 um = fb[idx - G.ww];
-    const u64 ul = j > 0 ? fb[idx - G.ww - 1] : 0ull;
-    const u64 ur = j + 1 < G.ww ? fb[idx - G.ww + 1] : 0ull;
+    const u64 um = ccl_word(G, fb, idx - G.ww, j);
+    const u64 ul = (j > 0 && !G.conn4) ? ccl_word(G, fb, idx - G.ww - 1, j - 1) : 0ull;
+    const u64 ur = (j + 1 < G.ww && !G.conn4) ? ccl_word(G, fb, idx - G.ww + 1, j + 1) : 0ull;
     if (!(um | (ul >> 63) | (ur & 1ull))) return;
     u64 rem = w;
     while (rem) {
@@ -148,7 +161,7 @@ __device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, con
         const u64 S = bit_range(s, e);
         rem &= ~S;
         const u32 me = seg_id(G, y, 64 * j + s);
-        u64 c = um & (S | (S << 1) | (S >> 1));
+        u64 c = um & (G.conn4 ? S : (S | (S << 1) | (S >> 1)));
         while (c) {
             const int b = __ffsll((long long)c) - 1;
             const int st = run_start(um, b), en = run_end(um, b);
@@ -166,9 +179,9 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u64* __restrict__ bits, 
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= G.h * G.ww) return;
-    const u64 w = bits[(size_t)blockIdx.y * G.h * G.ww + idx];
-    if (!w) return;
     const int y = idx / G.ww, j = idx - y * G.ww;
+    const u64 w = ccl_word(G, bits + (size_t)blockIdx.y * G.h * G.ww, idx, j);
+    if (!w) return;
     u32* p = parent + (size_t)blockIdx.y * G.nids;
     u32* f = flags + (size_t)blockIdx.y * G.nw32;
     u64 starts = w & ~(w << 1);
@@ -186,9 +199,9 @@ __global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, 
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= G.h * G.ww) return;
     const u64* fb = bits + (size_t)blockIdx.y * G.h * G.ww;
-    const u64 w = fb[idx];
-    if (!w) return;
     const int y = idx / G.ww, j = idx - y * G.ww;
+    const u64 w = ccl_word(G, fb, idx, j);
+    if (!w) return;
     global_link_word(fb, G, parent + (size_t)blockIdx.y * G.nids, flags + (size_t)blockIdx.y * G.nw32, y, j, idx, w, true, true);
 }
 
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
         for (u32 i = w0 + tid; i < w1; i += 256) gf[i] = 0u;
     }
     u32 cnt = 0;
-    CL_FOR_WORDS(r, j, i) { const u64 w = fb[(size_t)(y0 + r) * ww + j]; lbits[i] = w; cnt += nstarts(w); }
+    CL_FOR_WORDS(r, j, i) { const u64 w = ccl_word(G, fb, (y0 + r) * ww + j, j); lbits[i] = w; cnt += nstarts(w); }
     // block exclusive scan of the per-thread segment counts
     u32 inc = cnt;
     const int lane = tid & 63, wv = tid >> 6;
@@ -314,8 +327,8 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
         if ((w & 1ull) && j > 0 && (lbits[i - 1] >> 63)) lds_unite(lparent, base, wbase[i - 1] + nstarts(lbits[i - 1]) - 1u);
         if (r == 0) continue;
         const u64 um = lbits[i - ww];
-        const u64 ul = j > 0 ? lbits[i - ww - 1] : 0ull;
-        const u64 ur = j + 1 < ww ? lbits[i - ww + 1] : 0ull;
+        const u64 ul = (j > 0 && !G.conn4) ? lbits[i - ww - 1] : 0ull;
+        const u64 ur = (j + 1 < ww && !G.conn4) ? lbits[i - ww + 1] : 0ull;
         if (!(um | (ul >> 63) | (ur & 1ull))) continue;
         const u32 ubase = wbase[i - ww];
         const u64 ustarts = um & ~(um << 1);
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
             const int e = run_end(rem, s);
             const u64 Sg = bit_range(s, e);
             rem &= ~Sg;
-            u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
+            u64 c = um & (G.conn4 ? Sg : (Sg | (Sg << 1) | (Sg >> 1)));
             while (c) {
                 const int b = __ffsll((long long)c) - 1;
                 const int st = run_start(um, b), en = run_end(um, b);
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(64) void k_ccl_boundary(const u64* __restrict__ bit
     u32* f = flags + (size_t)blockIdx.y * G.nw32;
     for (int j = threadIdx.x; j < G.ww; j += 64) {
         const int idx = y * G.ww + j;
-        const u64 w = fb[idx];
+        const u64 w = ccl_word(G, fb, idx, j);
         if (w) global_link_word(fb, G, p, f, y, j, idx, w, false, true);
     }
 }
@@ -703,28 +716,47 @@ __global__ __launch_bounds__(256) void k_ccl_write(const u64* __restrict__ bits,
     }
 }
 
-int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
-            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels)
+static void ccl_make_geom(ccl_geom& G, int w, int h, int numbering, int invert, int conn4)
 {
-    if (numbering != VP_CCL_BLOCK2X2 && numbering != VP_CCL_PIXEL) return vp_fail(ctx, VP_ERR_INVALID, "numbering");
-    if (max_labels < 1) return vp_fail(ctx, VP_ERR_INVALID, "max_labels");
-    ccl_geom G;
     G.w = w; G.h = h; G.ww = vp_ww(w); G.wb = (w + 1) / 2; G.numbering = numbering;
     G.nids = (u32)vp_ccl_nids(w, h);
     G.nw32 = G.nids / 32;
+    G.invert = invert; G.conn4 = conn4;
+}
+
+// union-find phase only: parent[] (every segment points at a smaller id of its component, roots at themselves)
+// and the exact root bitmap in flags[]
+static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags)
+{
+    const int h = G.h;
     const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
     hipStream_t s = ctx->stream;
     const int strips = (h + CL_ROWS - 1) / CL_ROWS;
     const size_t nwmax = (size_t)CL_ROWS * G.ww;
     const size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + (size_t)3 * CL_CAP * 4;
     if (lds_local <= 64 * 1024) {
-        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, ws.parent, ws.flags, strips); }
-        if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, ws.parent, ws.flags); }
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips); }
+        if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags); }
     } else {
-        { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(ws.flags, 0, (size_t)G.nw32 * 4 * n, s)); }
-        { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_init, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags); }
-        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_link, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags); }
+        { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)G.nw32 * 4 * n, s)); }
+        { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_init, wgrid, dim3(256), 0, s, d_bits, G, parent, flags); }
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_link, wgrid, dim3(256), 0, s, d_bits, G, parent, flags); }
     }
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
+            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels)
+{
+    if (numbering != VP_CCL_BLOCK2X2 && numbering != VP_CCL_PIXEL) return vp_fail(ctx, VP_ERR_INVALID, "numbering");
+    if (max_labels < 1) return vp_fail(ctx, VP_ERR_INVALID, "max_labels");
+    ccl_geom G;
+    ccl_make_geom(G, w, h, numbering, 0, 0);
+    const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
+    hipStream_t s = ctx->stream;
+    int rc = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags);
+    if (rc != VP_OK) return rc;
     { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart); }
     { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels); }
     if (d_stats || d_centroids) {
@@ -743,3 +775,5 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
+
+#include "vp_contours.inl"

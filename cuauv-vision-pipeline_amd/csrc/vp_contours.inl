@@ -1,0 +1,321 @@
+// Contour extraction on the GPU (included by vp_ccl.hip; shares its union-find device code).
+//
+// Replaces utils/feature.py:5-40 `outer_contours` / `all_contours` = cv2.findContours(RETR_EXTERNAL | RETR_LIST,
+// CHAIN_APPROX_SIMPLE | NONE).  OpenCV (imgproc/src/contours.cpp) finds borders with a sequential raster scan that
+// marks pixels as it goes; what it returns can be stated without the scan:
+//   * one outer border per 8-connected foreground component, starting at the component's first pixel in raster order;
+//   * one hole border per 4-connected background region that does not reach the image frame, starting at the
+//     foreground pixel left of the region's first pixel;
+//   * RETR_LIST returns all of them, RETR_EXTERNAL the outer borders of components that are not inside a hole;
+//   * order: by start pixel, raster order, newest (= last) first;
+//   * each border is the Suzuki-Abe trace from its start pixel, which depends on the binary image only.
+// So: two union-find passes (foreground 8-conn, background 4-conn, both with first-pixel ids = VP_CCL_PIXEL), a
+// bitmap of start pixels + popcount prefix for the order, and one thread per border for the sequential trace
+// (counting pass, exclusive scan of the counts, writing pass).
+//
+// Known divergence (documented in DESIGN.md): OpenCV's RETR_EXTERNAL decides "inside a hole" from the sign of the
+// last mark left of the start pixel, which differs from the topological rule when a one-pixel-thick wall pixel was
+// negatively marked by its outer trace; tests/test_gpu_contours.py counts such cases on random masks.
+
+struct ct_frame_out {      // per frame, device
+    int32_t n_contours;
+    int32_t n_points;
+};
+
+// outside[] bit per background root: the region touches the image frame
+__global__ __launch_bounds__(256) void k_ct_outside(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent, u32* __restrict__ outside)
+{
+    // one thread per frame-border word: rows 0 and h-1 fully, columns 0 and ww-1 of the other rows
+    const int f = blockIdx.y;
+    const int nborder = 2 * G.ww + 2 * G.h;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nborder) return;
+    int y, j, which;   // which: 0 = every segment of the word, 1 = the one touching bit 0, 2 = the one touching the last valid bit
+    if (t < G.ww) { y = 0; j = t; which = 0; }
+    else if (t < 2 * G.ww) { y = G.h - 1; j = t - G.ww; which = 0; }
+    else if (t < 2 * G.ww + G.h) { y = t - 2 * G.ww; j = 0; which = 1; }
+    else { y = t - 2 * G.ww - G.h; j = G.ww - 1; which = 2; }
+    const u64* fb = bits + (size_t)f * G.h * G.ww;
+    const u64 w = ccl_word(G, fb, y * G.ww + j, j);
+    if (!w) return;
+    const u32* p = parent + (size_t)f * G.nids;
+    u32* o = outside + (size_t)f * G.nw32;
+    u64 rem = w;
+    if (which == 1) rem = (w & 1ull) ? bit_range(0, run_end(w, 0)) : 0ull;
+    if (which == 2) { const int last = ((G.w - 1) & 63); rem = ((w >> last) & 1ull) ? bit_range(run_start(w, last), last) : 0ull; }
+    while (rem) {
+        const int s = __ffsll((long long)rem) - 1;
+        const int e = run_end(rem, s);
+        rem &= ~bit_range(s, e);
+        const int st = run_start(w, s);   // `rem` may have been cut: the segment id comes from the real start
+        u32 r = seg_id(G, y, 64 * j + st);
+        for (u32 q = p[r]; q != r; q = p[r]) r = q;
+        atomicOr(o + (r >> 5), 1u << (r & 31));
+    }
+}
+
+// root id (VP_CCL_PIXEL: y*wb + x/2) -> first pixel of the region
+__device__ __forceinline__ void ct_root_pixel(const ccl_geom& G, const u64* __restrict__ fb, u32 id, int& y, int& x)
+{
+    y = (int)(id / (u32)G.wb);
+    const int x2 = (int)(id - (u32)y * (u32)G.wb);
+    const int j = (2 * x2) >> 6;
+    const u64 w = ccl_word(G, fb, y * G.ww + j, j);
+    x = ((w >> ((2 * x2) & 63)) & 1ull) ? 2 * x2 : 2 * x2 + 1;
+}
+
+// seeds: start-pixel bitmap (same layout as a bit image) + hole bitmap.
+// grid (ceil(nw32/256), n): thread = one 32-bit word of the root bitmaps.
+__global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, ccl_geom Gf, ccl_geom Gb, const u32* __restrict__ fg_flags,
+                                                  const u32* __restrict__ bg_flags, const u32* __restrict__ bg_parent,
+                                                  const u32* __restrict__ outside, int mode, u64* __restrict__ startmap, u64* __restrict__ holemap)
+{
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Gf.nw32) return;
+    const int f = blockIdx.y;
+    const u64* fb = bits + (size_t)f * Gf.h * Gf.ww;
+    u64* sm = startmap + (size_t)f * Gf.h * Gf.ww;
+    u64* hm = holemap + (size_t)f * Gf.h * Gf.ww;
+    const u32* bp = bg_parent + (size_t)f * Gb.nids;
+    const u32* out = outside + (size_t)f * Gb.nw32;
+    u32 m = fg_flags[(size_t)f * Gf.nw32 + t];
+    while (m) {
+        const int b = __ffs((int)m) - 1;
+        m &= m - 1;
+        int y, x;
+        ct_root_pixel(Gf, fb, t * 32 + b, y, x);
+        bool keep = true;
+        if (mode == 0 && x > 0) {   // RETR_EXTERNAL: the region left of the first pixel must reach the frame
+            const int xl = x - 1, j = xl >> 6;
+            const u64 wb = ccl_word(Gb, fb, y * Gb.ww + j, j);
+            u32 r = seg_id(Gb, y, 64 * j + run_start(wb, xl & 63));
+            for (u32 q = bp[r]; q != r; q = bp[r]) r = q;
+            keep = (out[r >> 5] >> (r & 31)) & 1u;
+        }
+        if (keep) atomicOr((unsigned long long*)&sm[y * Gf.ww + (x >> 6)], 1ull << (x & 63));
+    }
+    if (mode == 1) {   // RETR_LIST: hole borders
+        u32 hb = bg_flags[(size_t)f * Gb.nw32 + t] & ~out[t];
+        while (hb) {
+            const int b = __ffs((int)hb) - 1;
+            hb &= hb - 1;
+            int y, x;
+            ct_root_pixel(Gb, fb, t * 32 + b, y, x);
+            const int xs = x - 1;   // a hole never touches column 0
+            atomicOr((unsigned long long*)&sm[y * Gf.ww + (xs >> 6)], 1ull << (xs & 63));
+            atomicOr((unsigned long long*)&hm[y * Gf.ww + (xs >> 6)], 1ull << (xs & 63));
+        }
+    }
+}
+
+// per frame: exclusive popcount prefix over the start bitmap (one block per frame; the bitmap is small)
+__global__ __launch_bounds__(1024) void k_ct_rank(const u64* __restrict__ startmap, int nwords, u32* __restrict__ base, ct_frame_out* __restrict__ out)
+{
+    __shared__ u32 wsum[16];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64* sm = startmap + (size_t)f * nwords;
+    u32* bs = base + (size_t)f * nwords;
+    const int per = (nwords + 1023) / 1024;
+    const int lo = min(tid * per, nwords), hi = min(lo + per, nwords);
+    u32 cnt = 0;
+    for (int i = lo; i < hi; i++) cnt += (u32)__popcll(sm[i]);
+    u32 inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 woff = 0, total = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) woff += wsum[k]; total += wsum[k]; }
+    u32 run = woff + inc - cnt;
+    for (int i = lo; i < hi; i++) { bs[i] = run; run += (u32)__popcll(sm[i]); }
+    if (tid == 0) out[f].n_contours = (int32_t)total;
+}
+
+struct ct_window { u64 c[3]; u32 l, r; int y, j; };   // rows y-1..y+1 of word column j, + edge bits of the neighbour columns
+
+__device__ __forceinline__ void ct_load(const ccl_geom& G, const u64* __restrict__ fb, int y, int j, ct_window& W)
+{
+    W.y = y; W.j = j; W.l = 0; W.r = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int yy = y + k - 1;
+        u64 c = 0, l = 0, r = 0;
+        if (yy >= 0 && yy < G.h) {
+            const u64* row = fb + (size_t)yy * G.ww;
+            c = row[j];
+            if (j > 0) l = row[j - 1] >> 63;
+            if (j + 1 < G.ww) r = row[j + 1] & 1ull;
+        }
+        W.c[k] = c;
+        W.l |= (u32)l << k;
+        W.r |= (u32)r << k;
+    }
+}
+// pixel (W.y + dy, x + dx) with x in word column W.j
+__device__ __forceinline__ bool ct_probe(const ct_window& W, int x, int dy, int dx)
+{
+    const int k = dy + 1, b = (x & 63) + dx;
+    if (b < 0) return (W.l >> k) & 1u;
+    if (b > 63) return (W.r >> k) & 1u;
+    return (W.c[k] >> b) & 1ull;
+}
+
+// Suzuki-Abe trace of one border (imgproc/src/contours.cpp icvFetchContour), counting or writing points.
+template <bool WRITE>
+__device__ int ct_trace(const ccl_geom& G, const u64* __restrict__ fb, int y0, int x0, bool is_hole, int method, int32_t* __restrict__ pts)
+{
+    const int dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy8[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    ct_window W;
+    ct_load(G, fb, y0, x0 >> 6, W);
+    int s, s_end;
+    s_end = s = is_hole ? 0 : 4;
+    bool found;
+    do { s = (s - 1) & 7; found = ct_probe(W, x0, dy8[s], dx8[s]); } while (!found && s != s_end);
+    int n = 0;
+    if (s == s_end) {
+        if (WRITE) { pts[0] = x0; pts[1] = y0; }
+        return 1;
+    }
+    const int x1 = x0 + dx8[s], y1 = y0 + dy8[s];   // i1
+    int x3 = x0, y3 = y0, x4 = x0, y4 = y0;
+    int prev_s = s ^ 4;
+    // a border visits a pixel at most once per incoming direction: bound the walk so that a corrupted image cannot
+    // keep the wave alive forever
+    long long guard = 8ll * G.w * G.h + 16;
+    for (; guard > 0; guard--) {
+        s_end = s;
+        while (s < 15) {
+            ++s;
+            x4 = x3 + dx8[s & 7];
+            y4 = y3 + dy8[s & 7];
+            if (ct_probe(W, x3, dy8[s & 7], dx8[s & 7])) break;
+        }
+        s &= 7;
+        if (s != prev_s || method == 1) {
+            if (WRITE) { pts[2 * n] = x3; pts[2 * n + 1] = y3; }
+            n++;
+            prev_s = s;
+        }
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
+        x3 = x4; y3 = y4;
+        if (y3 != W.y || (x3 >> 6) != W.j) ct_load(G, fb, y3, x3 >> 6, W);
+        s = (s + 4) & 7;
+    }
+    return n;
+}
+
+// grid (ceil(h*ww/64), n), 64 threads: thread = one word of the start bitmap; a thread traces the borders starting in its word
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_ct_trace(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ startmap,
+                                                 const u64* __restrict__ holemap, const u32* __restrict__ base, int method,
+                                                 int32_t* __restrict__ counts, uint8_t* __restrict__ is_hole_out,
+                                                 const int32_t* __restrict__ offsets, int32_t* __restrict__ points, int max_contours,
+                                                 long long max_points)
+{
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const int nwords = G.h * G.ww;
+    if (idx >= nwords) return;
+    const int f = blockIdx.y;
+    u64 sm = startmap[(size_t)f * nwords + idx];
+    if (!sm) return;
+    const u64 hm = holemap[(size_t)f * nwords + idx];
+    const u64* fb = bits + (size_t)f * nwords;
+    const int y = idx / G.ww, j = idx - y * G.ww;
+    u32 rank = base[(size_t)f * nwords + idx];
+    while (sm) {
+        const int b = __ffsll((long long)sm) - 1;
+        sm &= sm - 1;
+        const bool hole = (hm >> b) & 1ull;
+        if ((int)rank < max_contours) {
+            if (!WRITE) {
+                counts[(size_t)f * max_contours + rank] = ct_trace<false>(G, fb, y, 64 * j + b, hole, method, nullptr);
+                is_hole_out[(size_t)f * max_contours + rank] = hole ? 1 : 0;
+            } else {
+                const long long off = offsets[(size_t)f * max_contours + rank];
+                const int cnt = counts[(size_t)f * max_contours + rank];
+                if (off + cnt <= max_points) ct_trace<true>(G, fb, y, 64 * j + b, hole, method, points + 2 * ((size_t)f * max_points + off));
+            }
+        }
+        rank++;
+    }
+}
+
+// per frame: exclusive scan of counts[0..K) -> offsets, total -> out[f].n_points (one block per frame)
+__global__ __launch_bounds__(256) void k_ct_offsets(const int32_t* __restrict__ counts, int32_t* __restrict__ offsets, ct_frame_out* __restrict__ out, int max_contours)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 carry;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int K = min(out[f].n_contours, max_contours);
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < K; base += 256) {
+        const int i = base + tid;
+        const u32 v = i < K ? (u32)counts[(size_t)f * max_contours + i] : 0u;
+        u32 inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int k = 0; k < wv; k++) woff += wsum[k];
+        if (i < K) offsets[(size_t)f * max_contours + i] = (int32_t)(carry + woff + inc - v);
+        __syncthreads();
+        if (tid == 255) carry += woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) out[f].n_points = (int32_t)carry;
+}
+
+size_t vp_contours_ws_bytes(int w, int h, int n)
+{
+    const size_t nids = vp_ccl_nids(w, h);
+    const size_t words = (size_t)n * h * vp_ww(w);
+    return 2 * vp_align(nids * 4 * n) + 3 * vp_align(nids / 8 * n) + 2 * vp_align(words * 8) + vp_align(words * 4) + vp_align(sizeof(ct_frame_out) * n) + 4096;
+}
+
+// d_counts / d_is_hole: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are stored
+// in discovery order (raster order of the start pixel); cv2 returns them reversed — the caller reverses.
+int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
+                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info)
+{
+    if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
+    if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
+    ccl_geom Gf, Gb;
+    ccl_make_geom(Gf, w, h, VP_CCL_PIXEL, 0, 0);
+    ccl_make_geom(Gb, w, h, VP_CCL_PIXEL, 1, 1);
+    const size_t nids = Gf.nids;
+    const size_t words = (size_t)n * h * Gf.ww;
+    u32* fg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
+    u32* bg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
+    u32* fg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    u32* bg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    u32* outside = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    u64* startmap = (u64*)vp_ws_take(ctx, words * 8);
+    u64* holemap = (u64*)vp_ws_take(ctx, words * 8);
+    u32* base = (u32*)vp_ws_take(ctx, words * 4);
+    if (!fg_parent || !bg_parent || !fg_flags || !bg_flags || !outside || !startmap || !holemap || !base)
+        return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
+    hipStream_t s = ctx->stream;
+    ct_frame_out* info = reinterpret_cast<ct_frame_out*>(d_info);
+    int rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
+    if (rc != VP_OK) return rc;
+    rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags);
+    if (rc != VP_OK) return rc;
+    VP_HIP(ctx, hipMemsetAsync(outside, 0, nids / 8 * n, s));
+    VP_HIP(ctx, hipMemsetAsync(startmap, 0, words * 8, s));
+    VP_HIP(ctx, hipMemsetAsync(holemap, 0, words * 8, s));
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gb, bg_parent, outside);
+    hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
+                       outside, mode, startmap, holemap);
+    hipLaunchKernelGGL(k_ct_rank, dim3((unsigned)n), dim3(1024), 0, s, startmap, h * Gf.ww, base, info);
+    const dim3 tgrid((unsigned)((h * Gf.ww + 63) / 64), (unsigned)n);
+    hipLaunchKernelGGL((k_ct_trace<false>), tgrid, dim3(64), 0, s, d_bits, Gf, startmap, holemap, base, method, d_counts, d_is_hole, d_offsets, d_points,
+                       max_contours, max_points);
+    hipLaunchKernelGGL(k_ct_offsets, dim3((unsigned)n), dim3(256), 0, s, d_counts, d_offsets, info, max_contours);
+    hipLaunchKernelGGL((k_ct_trace<true>), tgrid, dim3(64), 0, s, d_bits, Gf, startmap, holemap, base, method, d_counts, d_is_hole, d_offsets, d_points,
+                       max_contours, max_points);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

@@ -17,6 +17,8 @@ BGR2LAB, BGR2HSV, BGR2GRAY, GRAY2BGR = 0, 1, 2, 3
 MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
 SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
 CCL_PIXEL, CCL_BLOCK2X2 = 1, 2
+RETR_EXTERNAL, RETR_LIST = 0, 1
+CHAIN_APPROX_NONE, CHAIN_APPROX_SIMPLE = 1, 2
 CHAIN_MAX_MORPH = 8
 OPT_CHAIN_STREAMS = 1
 PROF_KERNELS = 12
@@ -66,6 +68,8 @@ _SIGS = {
     "vp_structuring_element": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vp_morph_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vp_ccl_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vp_find_contours_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
     "vp_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
     "vp_chain_algorithmic_bytes": (C.c_uint64, [C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),

@@ -85,12 +85,44 @@ def contour_area(contour: np.ndarray) -> float:
     return abs(a00 * 0.5)
 
 
+def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = _vp.CHAIN_APPROX_SIMPLE, with_holes: bool = False):
+    """cv2.findContours(mat, mode, method)[0] on the GPU (libvp vp_find_contours_u8): tuple of (N,1,2) int32 arrays of
+    (x, y) points, newest contour first like cv2."""
+    mat = as_mat(mat)
+    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
+        raise TypeError("expected a uint8 mask")
+    if mat.ndim == 3 and mat.shape[2] == 1:
+        mat = mat[:, :, 0]
+    if mat.ndim != 2 or mat.size == 0:
+        raise ValueError("expected a non-empty (h, w) mask")
+    if mat.strides[1] != 1:
+        mat = np.ascontiguousarray(mat)
+    h, w = mat.shape
+    ctx = _vp.default_context()
+    max_c, max_p = 256, 1 << 14
+    while True:
+        pts = np.empty((max_p, 2), np.int32)
+        counts = np.empty(max_c, np.int32)
+        holes = np.empty(max_c, np.uint8)
+        nc, npts = _vp.C.c_int32(0), _vp.C.c_int64(0)
+        _vp.check(_vp.lib().vp_find_contours_u8(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, int(mode), int(method), _vp.ptr(pts), max_p,
+                                                _vp.ptr(counts), _vp.ptr(holes), max_c, _vp.C.byref(nc), _vp.C.byref(npts)), ctx.handle)
+        if nc.value <= max_c and npts.value <= max_p:
+            break
+        max_c = max(max_c, 2 * nc.value)
+        max_p = max(max_p, 2 * npts.value)
+    out, o = [], 0
+    for k in range(nc.value):
+        out.append(pts[o:o + counts[k]].reshape(-1, 1, 2).copy())
+        o += int(counts[k])
+    return (tuple(out), holes[:nc.value].copy()) if with_holes else tuple(out)
+
+
 def outer_contours(mat: np.ndarray) -> List[np.ndarray]:
     """utils/feature.py:5-21 (cv2.findContours RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)."""
-    raise NotImplementedError("contour extraction is the next row of the scope table (SURVEY §8f rank 1); "
-                              "use connected_components for the accelerated path")
+    return find_contours(mat, _vp.RETR_EXTERNAL, _vp.CHAIN_APPROX_SIMPLE)
 
 
 def all_contours(mat: np.ndarray) -> List[np.ndarray]:
     """utils/feature.py:25-40 (cv2.findContours RETR_LIST, CHAIN_APPROX_SIMPLE)."""
-    raise NotImplementedError("contour extraction is the next row of the scope table (SURVEY §8f rank 1)")
+    return find_contours(mat, _vp.RETR_LIST, _vp.CHAIN_APPROX_SIMPLE)

@@ -117,6 +117,17 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride, int w, in
               int32_t* labels_host, int32_t* stats_host, double* centroids_host, int max_labels,
               int32_t* nlabels);
 
+/* utils/feature.py:5-40 `outer_contours` / `all_contours` (cv2.findContours): mode VP_RETR_EXTERNAL or VP_RETR_LIST,
+ * method VP_CHAIN_APPROX_NONE or VP_CHAIN_APPROX_SIMPLE, offset (0,0); non-zero = foreground.  Contours come back in
+ * cv2's order (last found first): counts[k] points of contour k, is_hole[k] (may be NULL), points = (x, y) int32 pairs
+ * of all contours back to back.  *n_contours / *n_points are always the true totals; when either exceeds its capacity
+ * nothing is copied out and the caller retries with larger buffers. */
+enum { VP_RETR_EXTERNAL = 0, VP_RETR_LIST = 1 };
+enum { VP_CHAIN_APPROX_NONE = 1, VP_CHAIN_APPROX_SIMPLE = 2 };
+int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride, int w, int h, int mode, int method,
+                        int32_t* points_host, int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours,
+                        int32_t* n_contours, int64_t* n_points);
+
 /* ---- fused, batched, device-resident chain -------------------------------------------- */
 
 #define VP_CHAIN_MAX_MORPH 8

@@ -185,3 +185,39 @@ def chain(bgr, mode, lo, hi, ops, kw=5, kh=5, block=2, max_k=4096, want_labels=T
                            _p(th, _u8p), _p(cl, _u8p), _p(labels, _i32p), _p(stats, _i32p), _p(cent, _f64p), max_k)
     k = min(n, max_k)
     return dict(threshed=th, cleaned=cl, labels=labels, nlabels=n, stats=stats[:k].copy(), centroids=cent[:k].copy())
+
+
+RETR_EXTERNAL, RETR_LIST = 0, 1
+CHAIN_APPROX_NONE, CHAIN_APPROX_SIMPLE = 1, 2
+
+
+def find_contours(mask, mode=RETR_EXTERNAL, method=CHAIN_APPROX_SIMPLE, with_holes=False):
+    """-> tuple of (N,1,2) int32 arrays in cv2.findContours order (newest first)."""
+    mask = _c(mask)
+    h, w = mask.shape
+    L = lib()
+    L.orc_find_contours.restype = C.c_int
+    max_c, max_p = 1024, 1 << 16
+    while True:
+        pts = np.empty((max_p, 2), np.int32)
+        counts = np.empty(max_c, np.int32)
+        holes = np.empty(max_c, np.uint8)
+        total = C.c_long(0)
+        rc = L.orc_find_contours(_p(mask, _u8p), C.c_size_t(w), w, h, int(mode), int(method), _p(pts, _i32p), C.c_long(max_p),
+                                 _p(counts, _i32p), _p(holes, _u8p), max_c, C.byref(total))
+        if rc >= 0:
+            break
+        max_c = max(max_c, 2 * abs(rc)) if abs(rc) > max_c else max_c
+        max_p = max(max_p, 2 * total.value)
+    out, o = [], 0
+    for k in range(rc):
+        out.append(pts[o:o + counts[k]].reshape(-1, 1, 2).copy())
+        o += counts[k]
+    return (tuple(out), holes[:rc].copy()) if with_holes else tuple(out)
+
+
+def contour_moments(contour):
+    pts = np.ascontiguousarray(np.asarray(contour, np.int32).reshape(-1, 2))
+    m = [C.c_double() for _ in range(4)]
+    lib().orc_contour_moments(_p(pts, _i32p), len(pts), *[C.byref(v) for v in m])
+    return dict(m00=m[0].value, m10=m[1].value, m01=m[2].value, area=m[3].value)

@@ -619,3 +619,138 @@ ORC_API int orc_chain_u8(const uint8_t* bgr, int w, int h, int mode, const int32
     free(conv); free(m0); free(m1); free(kern);
     return k;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * a9  outer_contours / all_contours — utils/feature.py:5-40
+ *     (cv2.findContours, RETR_EXTERNAL / RETR_LIST, CHAIN_APPROX_NONE / CHAIN_APPROX_SIMPLE, offset 0)
+ *     OpenCV: imgproc/src/contours.cpp cvFindNextContour() + icvFetchContour() (Suzuki-Abe border
+ *     following on a signed-char work image padded by one background pixel):
+ *       pixel values 0 = background, 1 = unvisited foreground, 2 = visited, 2|-128 = visited with the
+ *       east neighbour examined and empty.  Raster scan; at a value change prev -> p: (prev == 0, p == 1)
+ *       starts an outer border at x; (p == 0, prev >= 1) starts a hole border at x-1; RETR_EXTERNAL skips
+ *       holes and any outer border whose last marked pixel to the left on the row (lnbd) is positive.
+ *       Tracing: first neighbour clockwise from west (outer) / east (hole); then repeatedly the first
+ *       non-zero neighbour counter-clockwise after the direction we came from; a point is emitted when
+ *       the chain direction changes (SIMPLE) or always (NONE); ends when back at the start pixel moving to
+ *       the same second pixel.  Contours are returned newest first (each is pushed at the list head).
+ *     mode: 0 = RETR_EXTERNAL, 1 = RETR_LIST.  method: 1 = CHAIN_APPROX_NONE, 2 = CHAIN_APPROX_SIMPLE.
+ *     Output: points (x,y) int32 pairs of all contours back to back in *return* order, counts[k] points
+ *     of contour k, is_hole[k]; returns the number of contours, or -(needed) if a capacity is too small
+ *     (needed = contours if max_contours is short, else points).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_find_contours(const uint8_t* src, size_t sstride, int w, int h, int mode, int method, int32_t* points,
+                              long max_points, int32_t* counts, uint8_t* is_hole_out, int max_contours, long* total_points)
+{
+    const int W = w + 2, H = h + 2;
+    const int step = W;
+    signed char* img = (signed char*)calloc((size_t)W * H, 1);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) img[(size_t)(y + 1) * W + x + 1] = src[(size_t)y * sstride + x] ? 1 : 0;
+    const int dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy8[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int deltas[16];
+    for (int k = 0; k < 8; k++) deltas[k] = deltas[k + 8] = dy8[k] * step + dx8[k];
+    /* discovery-order storage; reversed at the end */
+    long cap_pts = 1024, npts = 0;
+    int cap_c = 64, nc = 0;
+    int32_t* pts = (int32_t*)malloc(sizeof(int32_t) * 2 * cap_pts);
+    long* first = (long*)malloc(sizeof(long) * cap_c);
+    int* cnt = (int*)malloc(sizeof(int) * cap_c);
+    uint8_t* hole = (uint8_t*)malloc(cap_c);
+#define PUSH_PT(px, py) do { if (npts == cap_pts) { cap_pts *= 2; pts = (int32_t*)realloc(pts, sizeof(int32_t) * 2 * cap_pts); } \
+                             pts[2 * npts] = (px); pts[2 * npts + 1] = (py); npts++; } while (0)
+    for (int y = 1; y < H - 1; y++) {
+        signed char* row = img + (size_t)y * W;
+        int lnbd_x = 0;
+        int prev = 0;
+        for (int x = 1; x < W; x++) {   /* x == W-1 is the right padding column (always 0): closes the last run */
+            int p = row[x];
+            if (p == prev) continue;
+            int is_hole = 0;
+            if (!(prev == 0 && p == 1)) {
+                if (p != 0 || prev < 1) goto resume_scan;
+                if (prev & -2) lnbd_x = x - 1;
+                is_hole = 1;
+            }
+            if (mode == 0 && (is_hole || row[lnbd_x] > 0)) goto resume_scan;
+            {
+                const int ox = x - is_hole;
+                lnbd_x = ox;
+                if (nc == cap_c) { cap_c *= 2; first = (long*)realloc(first, sizeof(long) * cap_c); cnt = (int*)realloc(cnt, sizeof(int) * cap_c); hole = (uint8_t*)realloc(hole, cap_c); }
+                first[nc] = npts;
+                hole[nc] = (uint8_t)is_hole;
+                /* icvFetchContour */
+                signed char* i0 = row + ox;
+                signed char *i1, *i3, *i4 = 0;
+                int px = ox - 1, py = y - 1;   /* back to unpadded coordinates */
+                int s, s_end, prev_s;
+                s_end = s = is_hole ? 0 : 4;
+                do { s = (s - 1) & 7; i1 = i0 + deltas[s]; } while (*i1 == 0 && s != s_end);
+                if (s == s_end) {            /* single pixel */
+                    *i0 = (signed char)(2 | -128);
+                    PUSH_PT(px, py);
+                } else {
+                    i3 = i0;
+                    prev_s = s ^ 4;
+                    for (;;) {
+                        s_end = s;
+                        while (s < 15) { i4 = i3 + deltas[++s]; if (*i4 != 0) break; }
+                        s &= 7;
+                        if ((unsigned)(s - 1) < (unsigned)s_end) *i3 = (signed char)(2 | -128);
+                        else if (*i3 == 1) *i3 = 2;
+                        if (s != prev_s || method == 1) { PUSH_PT(px, py); prev_s = s; }
+                        px += dx8[s];
+                        py += dy8[s];
+                        if (i4 == i0 && i3 == i1) break;
+                        i3 = i4;
+                        s = (s + 4) & 7;
+                    }
+                }
+                cnt[nc] = (int)(npts - first[nc]);
+                nc++;
+                p = row[x];
+            }
+        resume_scan:
+            prev = p;
+            if (prev & -2) lnbd_x = x;
+        }
+    }
+#undef PUSH_PT
+    if (total_points) *total_points = npts;
+    int rc = nc;
+    if (nc > max_contours) rc = -nc;
+    else if (npts > max_points) rc = (int)-npts;
+    else {
+        long o = 0;
+        for (int k = nc - 1, j = 0; k >= 0; k--, j++) {   /* newest first */
+            memcpy(points + 2 * o, pts + 2 * first[k], sizeof(int32_t) * 2 * cnt[k]);
+            o += cnt[k];
+            counts[j] = cnt[k];
+            if (is_hole_out) is_hole_out[j] = hole[k];
+        }
+    }
+    free(pts); free(first); free(cnt); free(hole); free(img);
+    return rc;
+}
+
+/* cv2.moments on a contour (imgproc/src/moments.cpp contourMoments) — m00, m10, m01 only — and
+ * cv2.contourArea(oriented=False): utils/feature.py:240-265 */
+ORC_API void orc_contour_moments(const int32_t* pts, int n, double* m00, double* m10, double* m01, double* area)
+{
+    double a00 = 0, a10 = 0, a01 = 0;
+    if (n > 0) {
+        double xi_1 = pts[2 * (n - 1)], yi_1 = pts[2 * (n - 1) + 1];
+        for (int i = 0; i < n; i++) {
+            double xi = pts[2 * i], yi = pts[2 * i + 1];
+            double dxy = xi_1 * yi - xi * yi_1;
+            a00 += dxy;
+            a10 += dxy * (xi_1 + xi);
+            a01 += dxy * (yi_1 + yi);
+            xi_1 = xi; yi_1 = yi;
+        }
+    }
+    if (area) *area = fabs(a00 * 0.5);
+    if (fabs(a00) > 1.1920929e-07) {
+        double s2 = a00 > 0 ? 0.5 : -0.5, s6 = a00 > 0 ? 1.0 / 6 : -1.0 / 6;
+        *m00 = a00 * s2; *m10 = a10 * s6; *m01 = a01 * s6;
+    } else { *m00 = *m10 = *m01 = 0; }
+}
