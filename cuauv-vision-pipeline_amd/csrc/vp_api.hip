@@ -286,7 +286,7 @@ static void norm_range(int cn, const int32_t* lo, const int32_t* hi, vp_range3* 
 
 struct rect_se { int kw, kh, ax, ay; };
 
-// Adds one rect erode/dilate to a stage list, split so that every stage has extents <= 32.
+// Adds one rect erode/dilate to a stage list, split so that every stage has extents <= 31 (the kernels' funnel shifts).
 static void push_rect_stage(std::vector<vp_bitstage>& v, int dilate, const rect_se& k)
 {
     int l = k.ax, r = k.kw - 1 - k.ax, u = k.ay, d = k.kh - 1 - k.ay;
@@ -300,7 +300,7 @@ static void push_rect_stage(std::vector<vp_bitstage>& v, int dilate, const rect_
     do {
         vp_bitstage s;
         s.dilate = dilate;
-        s.l = l > 32 ? 32 : l; s.r = r > 32 ? 32 : r; s.u = u > 32 ? 32 : u; s.d = d > 32 ? 32 : d;
+        s.l = l > 31 ? 31 : l; s.r = r > 31 ? 31 : r; s.u = u > 31 ? 31 : u; s.d = d > 31 ? 31 : d;
         l -= s.l; r -= s.r; u -= s.u; d -= s.d;
         v.push_back(s);
     } while (l | r | u | d);

@@ -14,9 +14,26 @@
 // Everything else (grey-level images, ellipse/cross kernels, multi-channel) goes through the
 // generic kernel: brute-force min/max over the structuring element's offsets.
 #include "vp_internal.h"
+#include <cstdlib>
 
 #define MB_THREADS 256
 #define MB_STRIP 32
+
+
+// 64-bit funnel shifts built from v_alignbit_b32 (full rate) instead of 64-bit variable shifts (quarter rate):
+// fsr(next, cur, d) = (cur >> d) | (next << (64 - d)),  fsl(cur, prev, d) = (cur << d) | (prev >> (64 - d)),  1 <= d <= 31
+__device__ __forceinline__ u64 fsr(u64 next, u64 cur, int d)
+{
+    const u32 lo = __builtin_amdgcn_alignbit((u32)(cur >> 32), (u32)cur, (u32)d);
+    const u32 hi = __builtin_amdgcn_alignbit((u32)next, (u32)(cur >> 32), (u32)d);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 fsl(u64 cur, u64 prev, int d)
+{
+    const u32 hi = __builtin_amdgcn_alignbit((u32)(cur >> 32), (u32)cur, (u32)(32 - d));
+    const u32 lo = __builtin_amdgcn_alignbit((u32)cur, (u32)(prev >> 32), (u32)(32 - d));
+    return ((u64)hi << 32) | lo;
+}
 
 __device__ __forceinline__ u32 expand4m(u32 nib) { return (((nib & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu; }
 
@@ -111,6 +128,11 @@ struct mb_params {
     vp_bitplan plan;
 };
 
+// iterate the staged words with a division-free (row, column) mapping: 8 rows x 32 columns per pass of the block
+#define MB_FOR_WORDS(r, j, i)                                   \
+    for (int r = threadIdx.x >> 5; r < rows; r += 8)            \
+        for (int j = threadIdx.x & 31, i = r * ww + j; j < ww; j += 32, i += 32)
+
 // dynamic LDS: two buffers of rows*ww u64
 __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict__ in, mb_params P, u64* __restrict__ out_bits,
                                                            uint8_t* __restrict__ out_mask)
@@ -124,11 +146,9 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
     const int y0 = strip * MB_STRIP;          // first output row of this strip
     const int ybase = y0 - P.halo_top;        // image row of LDS row 0
     const u64* fin = in + (size_t)frame * P.h * ww;
-    const int nwords = rows * ww;
     const u64 lastmask = (P.w & 63) ? ((1ull << (P.w & 63)) - 1ull) : ~0ull;  // valid bits of word ww-1
 
-    for (int i = threadIdx.x; i < nwords; i += MB_THREADS) {
-        const int r = i / ww, j = i - r * ww;
+    MB_FOR_WORDS(r, j, i) {
         const int y = ybase + r;
         A[i] = (y >= 0 && y < P.h) ? fin[(size_t)y * ww + j] : 0ull;
     }
@@ -138,8 +158,7 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
         const vp_bitstage st = P.plan.s[si];
         const u64 neutral = st.dilate ? 0ull : ~0ull;
         // horizontal half: A -> B
-        for (int i = threadIdx.x; i < nwords; i += MB_THREADS) {
-            const int r = i / ww, j = i - r * ww;
+        MB_FOR_WORDS(r, j, i) {
             const int y = ybase + r;
             if (y < 0 || y >= P.h) continue;
             u64 cur = A[i];
@@ -151,34 +170,31 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
             }
             u64 acc = cur;
             if (st.dilate) {
-                for (int d = 1; d <= st.r; d++) acc |= (cur >> d) | (next << (64 - d));
-                for (int d = 1; d <= st.l; d++) acc |= (cur << d) | (prev >> (64 - d));
+                for (int d = 1; d <= st.r; d++) acc |= fsr(next, cur, d);
+                for (int d = 1; d <= st.l; d++) acc |= fsl(cur, prev, d);
             } else {
-                for (int d = 1; d <= st.r; d++) acc &= (cur >> d) | (next << (64 - d));
-                for (int d = 1; d <= st.l; d++) acc &= (cur << d) | (prev >> (64 - d));
+                for (int d = 1; d <= st.r; d++) acc &= fsr(next, cur, d);
+                for (int d = 1; d <= st.l; d++) acc &= fsl(cur, prev, d);
             }
             if (j == ww - 1) acc &= lastmask;
             B[i] = acc;
         }
         __syncthreads();
-        // vertical half: B -> A
-        for (int i = threadIdx.x; i < nwords; i += MB_THREADS) {
-            const int r = i / ww;
+        // vertical half: B -> A.  Rows outside the image never win; rows outside the staged range only feed halo
+        // rows that are no longer needed.
+        MB_FOR_WORDS(r, j, i) {
             const int y = ybase + r;
             if (y < 0 || y >= P.h) continue;
+            int lo = max(max(r - st.u, 0), -ybase);
+            int hi = min(min(r + st.d, rows - 1), P.h - 1 - ybase);
             u64 acc = B[i];
-            // rows outside the image never win; rows outside the staged range only feed halo rows that
-            // are no longer needed
-            int lo = r - st.u, hi = r + st.d;
-            if (lo < 0) lo = 0;
-            if (hi > rows - 1) hi = rows - 1;
-            if (ybase + lo < 0) lo = -ybase;
-            if (ybase + hi > P.h - 1) hi = P.h - 1 - ybase;
-            const int j = i - r * ww;
+            const u64* col = B + j;
             if (st.dilate) {
-                for (int rr = lo; rr <= hi; rr++) acc |= B[rr * ww + j];
+#pragma unroll 4
+                for (int rr = lo; rr <= hi; rr++) acc |= col[rr * ww];
             } else {
-                for (int rr = lo; rr <= hi; rr++) acc &= B[rr * ww + j];
+#pragma unroll 4
+                for (int rr = lo; rr <= hi; rr++) acc &= col[rr * ww];
             }
             A[i] = acc;
         }
@@ -189,26 +205,287 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
     const int nout_rows = min(MB_STRIP, P.h - y0);
     if (out_bits) {
         u64* fo = out_bits + (size_t)frame * P.h * ww;
-        for (int i = threadIdx.x; i < nout_rows * ww; i += MB_THREADS) {
-            const int r = i / ww, j = i - r * ww;
-            fo[(size_t)(y0 + r) * ww + j] = A[(P.halo_top + r) * ww + j];
-        }
+        for (int r = threadIdx.x >> 5; r < nout_rows; r += 8)
+            for (int j = threadIdx.x & 31; j < ww; j += 32) fo[(size_t)(y0 + r) * ww + j] = A[(P.halo_top + r) * ww + j];
     }
     if (out_mask) {
         uint8_t* fm = out_mask + (size_t)frame * P.h * P.w;
         const int gpr = ww * 4;  // 16-px groups per row
-        for (int i = threadIdx.x; i < nout_rows * gpr; i += MB_THREADS) {
-            const int r = i / gpr, g = i - r * gpr;
-            const u64 wv = A[(P.halo_top + r) * ww + (g >> 2)];
+        for (int r = threadIdx.x >> 7; r < nout_rows; r += 2) {
             uint8_t* drow = fm + (size_t)(y0 + r) * P.w;
-            store_mask16(drow, g * 16, P.w, (u32)(wv >> (16 * (g & 3))) & 0xffffu, (((uintptr_t)drow) & 15) == 0);
+            const bool vec_ok = (((uintptr_t)drow) & 15) == 0;
+            const u64* arow = A + (P.halo_top + r) * ww;
+            for (int g = threadIdx.x & 127; g < gpr; g += 128)
+                store_mask16(drow, g * 16, P.w, (u32)(arow[g >> 2] >> (16 * (g & 3))) & 0xffffu, vec_ok);
         }
     }
+}
+
+// Compile-time specialisation for the plans the modules actually use (square kernels, centre anchor): radii and
+// kinds are template constants, so the shift loops unroll into immediate funnel shifts and the vertical windows
+// into straight-line LDS reads.  KIND bit k = stage k dilates.
+template <int NS, int R0, int R1, int R2, int KIND>
+__global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __restrict__ in, int w, int h, int ww, int strips,
+                                                               u64* __restrict__ out_bits, uint8_t* __restrict__ out_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int HALO = R0 + (NS > 1 ? R1 : 0) + (NS > 2 ? R2 : 0);
+    constexpr int rows = MB_STRIP + 2 * HALO;
+    u64* A = lds;
+    u64* B = lds + (size_t)rows * ww;
+    const int frame = blockIdx.x / strips;
+    const int strip = blockIdx.x - frame * strips;
+    const int y0 = strip * MB_STRIP;
+    const int ybase = y0 - HALO;
+    const u64* fin = in + (size_t)frame * h * ww;
+    const u64 lastmask = (w & 63) ? ((1ull << (w & 63)) - 1ull) : ~0ull;
+    MB_FOR_WORDS(r, j, i) {
+        const int y = ybase + r;
+        A[i] = (y >= 0 && y < h) ? fin[(size_t)y * ww + j] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int si = 0; si < NS; si++) {
+        const int R = si == 0 ? R0 : (si == 1 ? R1 : R2);
+        const bool dil = (KIND >> si) & 1;
+        const u64 neutral = dil ? 0ull : ~0ull;
+        MB_FOR_WORDS(r, j, i) {
+            const int y = ybase + r;
+            if (y < 0 || y >= h) continue;
+            u64 cur = A[i];
+            u64 prev = j > 0 ? A[i - 1] : neutral;
+            u64 next = j + 1 < ww ? A[i + 1] : neutral;
+            if (!dil) {
+                if (j == ww - 1) cur |= ~lastmask;
+                if (j + 1 == ww - 1) next |= ~lastmask;
+            }
+            u64 acc = cur;
+#pragma unroll
+            for (int d = 1; d <= R; d++) {
+                if (dil) acc |= fsr(next, cur, d) | fsl(cur, prev, d);
+                else acc &= fsr(next, cur, d) & fsl(cur, prev, d);
+            }
+            if (j == ww - 1) acc &= lastmask;
+            B[i] = acc;
+        }
+        __syncthreads();
+        MB_FOR_WORDS(r, j, i) {
+            const int y = ybase + r;
+            if (y < 0 || y >= h) continue;
+            u64 acc = B[i];
+#pragma unroll
+            for (int d = 1; d <= R; d++) {
+                // rows outside the image never win; rows outside the staged range only feed dead halo rows
+                const bool up = (r - d >= 0) && (y - d >= 0), dn = (r + d < rows) && (y + d < h);
+                const u64 a = up ? B[i - d * ww] : neutral, b = dn ? B[i + d * ww] : neutral;
+                if (dil) acc |= a | b;
+                else acc &= a & b;
+            }
+            A[i] = acc;
+        }
+        __syncthreads();
+    }
+    const int nout_rows = min(MB_STRIP, h - y0);
+    if (out_bits) {
+        u64* fo = out_bits + (size_t)frame * h * ww;
+        for (int r = threadIdx.x >> 5; r < nout_rows; r += 8)
+            for (int j = threadIdx.x & 31; j < ww; j += 32) fo[(size_t)(y0 + r) * ww + j] = A[(HALO + r) * ww + j];
+    }
+    if (out_mask) {
+        uint8_t* fm = out_mask + (size_t)frame * h * w;
+        const int gpr = ww * 4;
+        for (int r = threadIdx.x >> 7; r < nout_rows; r += 2) {
+            uint8_t* drow = fm + (size_t)(y0 + r) * w;
+            const bool vec_ok = (((uintptr_t)drow) & 15) == 0;
+            const u64* arow = A + (HALO + r) * ww;
+            for (int g = threadIdx.x & 127; g < gpr; g += 128)
+                store_mask16(drow, g * 16, w, (u32)(arow[g >> 2] >> (16 * (g & 3))) & 0xffffu, vec_ok);
+        }
+    }
+}
+
+template <int NS, int R0, int R1, int R2, int KIND>
+static int launch_sym(vp_ctx* ctx, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask)
+{
+    constexpr int HALO = R0 + (NS > 1 ? R1 : 0) + (NS > 2 ? R2 : 0);
+    const int ww = vp_ww(w), strips = (h + MB_STRIP - 1) / MB_STRIP;
+    const size_t lds = (size_t)2 * (MB_STRIP + 2 * HALO) * ww * sizeof(u64);
+    if (lds > 64 * 1024) return VP_ERR_UNSUPPORTED;
+    vp_prof_scope prof(ctx, VPK_MORPH);
+    hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in, w, h,
+                       ww, strips, d_out_bits, d_out_mask);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+// returns VP_ERR_UNSUPPORTED when the plan is not one of the specialised shapes
+static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* ob, uint8_t* om)
+{
+    if (plan.n < 1 || plan.n > 3) return VP_ERR_UNSUPPORTED;
+    int rad[3] = {0, 0, 0}, kind = 0;
+    for (int i = 0; i < plan.n; i++) {
+        const vp_bitstage& s = plan.s[i];
+        if (s.l != s.r || s.l != s.u || s.l != s.d) return VP_ERR_UNSUPPORTED;
+        rad[i] = s.l;
+        kind |= (s.dilate ? 1 : 0) << i;
+    }
+#define SYM(NS, A, B, C, K) if (plan.n == NS && rad[0] == A && rad[1] == B && rad[2] == C && kind == K) return launch_sym<NS, A, B, C, K>(ctx, d_in, w, h, n, ob, om)
+    SYM(3, 2, 4, 2, 2);   // OPEN 5x5 + CLOSE 5x5  (erode, dilate x2 merged, erode)      — modules/red_buoy.py:31-33
+    SYM(3, 2, 4, 2, 5);   // CLOSE 5x5 + OPEN 5x5
+    SYM(2, 2, 2, 0, 2);   // OPEN 5x5                                                   — modules/bins.py:23-24
+    SYM(2, 2, 2, 0, 1);   // CLOSE 5x5
+    SYM(3, 1, 2, 1, 2);   // OPEN 3x3 + CLOSE 3x3
+    SYM(3, 1, 2, 1, 5);
+    SYM(2, 1, 1, 0, 2);   // OPEN 3x3
+    SYM(2, 1, 1, 0, 1);   // CLOSE 3x3
+    SYM(1, 1, 0, 0, 0); SYM(1, 1, 0, 0, 1);   // erode / dilate 3x3
+    SYM(1, 2, 0, 0, 0); SYM(1, 2, 0, 0, 1);   // erode / dilate 5x5
+#undef SYM
+    return VP_ERR_UNSUPPORTED;
+}
+
+// ---- bit-plane morphology, row sweep ------------------------------------------------------------------
+// One lane owns one word column (64 px) of a strip of MS_SR output rows and walks down the rows; a wave holds one
+// strip (ww <= 64) or two (ww <= 32).  Each stage keeps the last (up + down + 1) horizontally-filtered rows of its
+// column in an LDS ring private to the lane; the horizontal filter takes the neighbour columns' words by lane
+// shuffle.  Rows outside the image enter a ring as the stage's neutral value ("outside never wins"), so a window
+// never needs clamping.  No barriers, no index divisions; per row a lane issues ~150 VALU instructions for
+// OPEN+CLOSE 5x5 (erode r2, dilate r4, erode r2) including the 64-byte mask row it writes.
+#define MS_SR 32
+#define MS_MAXST 4
+struct ms_params {
+    int w, h, ww, nst, upw, strips, nunits, rows_in, halo_top;
+    int ring_base[MS_MAXST], ring_depth[MS_MAXST];
+    vp_bitstage st[MS_MAXST];
+};
+
+__global__ __launch_bounds__(64) void k_morph_sweep(const u64* __restrict__ in, ms_params P, u64* __restrict__ out_bits,
+                                                    uint8_t* __restrict__ out_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 ms_lds[];
+    const int lane = threadIdx.x;
+    const int lpu = 64 / P.upw;
+    const int uiw = lane / lpu, j = lane - uiw * lpu;
+    const int unit = blockIdx.x * P.upw + uiw;
+    const bool col = j < P.ww && unit < P.nunits;
+    const int uu = min(unit, P.nunits - 1);
+    const int frame = uu / P.strips, strip = uu - frame * P.strips;
+    const int y0 = strip * MS_SR, y1 = min(y0 + MS_SR, P.h);
+    const int ystart = y0 - P.halo_top;   // image row that reaches stage 0 at step 0
+    const u64* fin = in + (size_t)frame * P.h * P.ww;
+    const u64 lastmask = (P.w & 63) ? ((1ull << (P.w & 63)) - 1ull) : ~0ull;
+    const bool lastcol = j == P.ww - 1;
+    u64* inrows = ms_lds;                           // [rows_in][64]
+    u64* ring = ms_lds + (size_t)P.rows_in * 64;    // [sum of ring depths][64]
+    for (int r = 0; r < P.rows_in; r++) {           // all loads of the column issued back to back
+        const int y = ystart + r;
+        u64 v = 0;
+        if (col && y >= 0 && y < P.h) v = fin[(size_t)y * P.ww + j];
+        inrows[r * 64 + lane] = v;
+    }
+    int slot[MS_MAXST] = {0, 0, 0, 0};
+    uint8_t* mrow_base = out_mask ? out_mask + (size_t)frame * P.h * P.w : nullptr;
+    u64* brow_base = out_bits ? out_bits + (size_t)frame * P.h * P.ww : nullptr;
+    for (int t = 0; t < P.rows_in; t++) {
+        int yr = ystart + t;
+        u64 v = inrows[t * 64 + lane];
+        bool present = yr >= 0 && yr < P.h;
+#pragma unroll
+        for (int k = 0; k < MS_MAXST; k++) {
+            if (k < P.nst) {
+                const vp_bitstage st = P.st[k];
+                const u64 neutral = st.dilate ? 0ull : ~0ull;
+                u64 cur = v;
+                if (!st.dilate && lastcol) cur |= ~lastmask;   // out-of-image columns of the last word count as 1 for erosion
+                u64 left = __shfl_up(cur, 1), right = __shfl_down(cur, 1);
+                if (j == 0) left = neutral;
+                if (lastcol) right = neutral;
+                u64 acc = cur;
+                if (st.dilate) {
+                    for (int d = 1; d <= st.r; d++) acc |= fsr(right, cur, d);
+                    for (int d = 1; d <= st.l; d++) acc |= fsl(cur, left, d);
+                } else {
+                    for (int d = 1; d <= st.r; d++) acc &= fsr(right, cur, d);
+                    for (int d = 1; d <= st.l; d++) acc &= fsl(cur, left, d);
+                }
+                const u64 hres = present ? acc : neutral;
+                const int D = P.ring_depth[k];
+                u64* rk = ring + (size_t)P.ring_base[k] * 64 + lane;
+                rk[slot[k] * 64] = hres;
+                u64 o = hres;
+                int si = slot[k];
+                if (st.dilate) { for (int q = 1; q < D; q++) { si = si == 0 ? D - 1 : si - 1; o |= rk[si * 64]; } }
+                else { for (int q = 1; q < D; q++) { si = si == 0 ? D - 1 : si - 1; o &= rk[si * 64]; } }
+                slot[k] = slot[k] + 1 == D ? 0 : slot[k] + 1;
+                if (lastcol) o &= lastmask;
+                v = o;
+                yr -= st.d;
+                present = yr >= 0 && yr < P.h;
+            }
+        }
+        const bool wr = col && yr >= y0 && yr < y1;
+        if (brow_base && wr) brow_base[(size_t)yr * P.ww + j] = v;
+        if (mrow_base) {
+            const int yc = min(max(yr, 0), P.h - 1);
+            uint8_t* drow = mrow_base + (size_t)yc * P.w;
+            const bool vec_ok = (((uintptr_t)drow) & 15) == 0;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {
+                const int g = j + P.ww * t4;                       // 16-px group of the row handled by this lane
+                const u64 wv = __shfl(v, uiw * lpu + ((g >> 2) & (lpu - 1)));
+                if (wr) store_mask16(drow, g * 16, P.w, (u32)(wv >> (16 * (g & 3))) & 0xffffu, vec_ok);
+            }
+        }
+    }
+}
+
+static bool sweep_eligible(const vp_bitplan& plan, int w, ms_params* P, size_t* lds)
+{
+    const int ww = vp_ww(w);
+    if (plan.n < 1 || plan.n > MS_MAXST || ww > 64) return false;
+    int top = 0, bot = 0, slots = 0;
+    for (int i = 0; i < plan.n; i++) {
+        P->st[i] = plan.s[i];
+        P->ring_base[i] = slots;
+        P->ring_depth[i] = plan.s[i].u + plan.s[i].d + 1;
+        slots += P->ring_depth[i];
+        top += plan.s[i].u;
+        bot += plan.s[i].d;
+    }
+    for (int i = plan.n; i < MS_MAXST; i++) { P->ring_base[i] = 0; P->ring_depth[i] = 1; P->st[i] = plan.s[0]; }
+    P->nst = plan.n;
+    P->halo_top = top;
+    P->rows_in = MS_SR + top + bot;
+    *lds = (size_t)(P->rows_in + slots) * 64 * sizeof(u64);
+    return *lds <= 64 * 1024;
 }
 
 int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits,
                    uint8_t* d_out_mask)
 {
+    for (int i = 0; i < plan.n; i++)
+        if (plan.s[i].l > 31 || plan.s[i].r > 31 || plan.s[i].l < 0 || plan.s[i].r < 0 || plan.s[i].u < 0 || plan.s[i].d < 0)
+            return vp_fail(ctx, VP_ERR_INVALID, "bit stage extent");
+    {
+        ms_params S;
+        size_t lds = 0;
+        static const bool use_sweep = getenv("VP_SWEEP") != nullptr;   // measured slower than the multi-pass LDS kernel
+        if (use_sweep && sweep_eligible(plan, w, &S, &lds)) {
+            S.w = w; S.h = h; S.ww = vp_ww(w);
+            S.upw = S.ww <= 32 ? 2 : 1;
+            S.strips = (h + MS_SR - 1) / MS_SR;
+            S.nunits = n * S.strips;
+            vp_prof_scope prof(ctx, VPK_MORPH);
+            hipLaunchKernelGGL(k_morph_sweep, dim3((unsigned)((S.nunits + S.upw - 1) / S.upw)), dim3(64), lds, ctx->stream, d_in, S, d_out_bits, d_out_mask);
+            VP_HIP(ctx, hipGetLastError());
+            return VP_OK;
+        }
+    }
+    {
+        static const bool no_sym = getenv("VP_NO_SYM") != nullptr;
+        const int rc = no_sym ? VP_ERR_UNSUPPORTED : try_sym(ctx, plan, d_in, w, h, n, d_out_bits, d_out_mask);
+        if (rc != VP_ERR_UNSUPPORTED) return rc;
+    }
     mb_params P;
     P.w = w;
     P.h = h;
@@ -216,7 +493,7 @@ int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, 
     P.plan = plan;
     P.halo_top = P.halo_bot = 0;
     for (int i = 0; i < plan.n; i++) {
-        if (plan.s[i].l > 63 || plan.s[i].r > 63 || plan.s[i].l < 0 || plan.s[i].r < 0 || plan.s[i].u < 0 || plan.s[i].d < 0)
+        if (plan.s[i].l > 31 || plan.s[i].r > 31 || plan.s[i].l < 0 || plan.s[i].r < 0 || plan.s[i].u < 0 || plan.s[i].d < 0)
             return vp_fail(ctx, VP_ERR_INVALID, "bit stage extent");
         P.halo_top += plan.s[i].u;
         P.halo_bot += plan.s[i].d;
