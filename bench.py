@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="1080p frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="1080p frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,9 +158,9 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
 
     # HBM-side bytes per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
-    # separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py); collected at batch 64
+    # separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py); collected at batch 128
     traffic_tab = {}
-    if args.batch == 64:
+    if args.batch == 128:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*traffic.json")))
         if cands:
