@@ -1,0 +1,242 @@
+"""A narrow `cv2` look-alike for module files that call OpenCV directly (modules/bins.py:13-75 and the colour /
+morphology lines of modules/preprocessor.py:52-129), so they run where no OpenCV exists.
+
+`install()` registers this module as `cv2` ONLY when a real cv2 cannot be imported — a real OpenCV is never shadowed.
+Image arithmetic (cvtColor, inRange, erode/dilate/morphologyEx, findContours, connectedComponentsWithStats) goes to
+libvp (HIP); small polygon maths (moments, contourArea, arcLength, minAreaRect, boxPoints, approxPolyDP) and overlay
+helpers (addWeighted, drawContours, split/merge) are host numpy, as they are CPU code in OpenCV too.  Anything else
+raises AttributeError like a missing cv2 symbol would."""
+import math
+import sys
+
+import numpy as np
+
+from vision import _vp
+from vision.utils import color as _color
+from vision.utils import draw as _draw
+from vision.utils import feature as _feature
+from vision.utils import transform as _transform
+
+COLOR_BGR2LAB, COLOR_BGR2HSV, COLOR_BGR2GRAY, COLOR_GRAY2BGR = 44, 40, 6, 8     # cv2's own enum values
+MORPH_RECT, MORPH_CROSS, MORPH_ELLIPSE = 0, 1, 2
+MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
+RETR_EXTERNAL, RETR_LIST = 0, 1
+CHAIN_APPROX_NONE, CHAIN_APPROX_SIMPLE = 1, 2
+CC_STAT_LEFT, CC_STAT_TOP, CC_STAT_WIDTH, CC_STAT_HEIGHT, CC_STAT_AREA = 0, 1, 2, 3, 4
+CV_32S = 4
+
+
+class UMat:   # only so that `from cv2 import UMat` and isinstance checks work
+    def __init__(self, arr):
+        self._arr = np.asarray(arr)
+
+    def get(self):
+        return self._arr
+
+
+class error(Exception):
+    pass
+
+
+_CVT = {COLOR_BGR2LAB: _color.bgr_to_lab, COLOR_BGR2HSV: _color.bgr_to_hsv, COLOR_BGR2GRAY: _color.bgr_to_gray,
+        COLOR_GRAY2BGR: _color.gray_to_bgr}
+
+
+def cvtColor(src, code):
+    if code not in _CVT:
+        raise error(f"cvtColor code {code} is outside the accelerated path")
+    return _CVT[code](src)[0]
+
+
+def split(m):
+    m = np.asarray(m)
+    return tuple(np.ascontiguousarray(m[:, :, c]) for c in range(m.shape[2])) if m.ndim == 3 else (m.copy(),)
+
+
+def merge(mv):
+    return np.ascontiguousarray(np.dstack(list(mv)))
+
+
+def inRange(src, lowerb, upperb):
+    return _color.range_threshold(src, lowerb, upperb)
+
+
+def getStructuringElement(shape, ksize):
+    return _transform._structuring_element(int(shape), int(ksize[0]), int(ksize[1]))
+
+
+def erode(src, kernel, iterations=1, anchor=(-1, -1)):
+    return _transform._morph(_vp.MORPH_ERODE, src, kernel, iterations, anchor)
+
+
+def dilate(src, kernel, iterations=1, anchor=(-1, -1)):
+    return _transform._morph(_vp.MORPH_DILATE, src, kernel, iterations, anchor)
+
+
+def morphologyEx(src, op, kernel, iterations=1, anchor=(-1, -1)):
+    return _transform._morph(int(op), src, kernel, iterations, anchor)
+
+
+def findContours(image, mode, method):
+    """-> (contours, hierarchy); hierarchy is None (RETR_EXTERNAL / RETR_LIST are flat)."""
+    return _feature.find_contours(image, int(mode), int(method)), None
+
+
+def connectedComponentsWithStats(image, connectivity=8, ltype=CV_32S):
+    if connectivity != 8:
+        raise error("only 8-connectivity is implemented")
+    n, labels, stats, cent = _feature.connected_components(image, max_labels=65536)
+    return n, labels, stats, cent
+
+
+def moments(contour):
+    m00, m10, m01 = _feature._polygon_moments(contour)
+    return {"m00": m00, "m10": m10, "m01": m01}
+
+
+def contourArea(contour, oriented=False):
+    pts = np.asarray(contour).reshape(-1, 2).astype(np.float64)
+    if len(pts) == 0:
+        return 0.0
+    x, y = pts[:, 0], pts[:, 1]
+    a = 0.5 * float(np.sum(np.roll(x, 1) * y - np.roll(y, 1) * x))
+    return a if oriented else abs(a)
+
+
+def arcLength(curve, closed):
+    """imgproc/src/shapedescr.cpp arcLength: segment lengths in float32, summed in float64."""
+    pts = np.asarray(curve).reshape(-1, 2).astype(np.float32)
+    if len(pts) <= 1:
+        return 0.0
+    prev = pts[-1] if closed else pts[0]
+    total = 0.0
+    for i in range(0 if closed else 1, len(pts)):
+        d = pts[i] - prev
+        total += float(np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1])))
+        prev = pts[i]
+    return total
+
+
+def _convex_hull(pts):
+    pts = sorted(set(map(tuple, pts.tolist())))
+    if len(pts) <= 2:
+        return np.array(pts, np.float64)
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+    lower, upper = [], []
+    for p in pts:
+        while len(lower) >= 2 and cross(lower[-2], lower[-1], p) <= 0:
+            lower.pop()
+        lower.append(p)
+    for p in reversed(pts):
+        while len(upper) >= 2 and cross(upper[-2], upper[-1], p) <= 0:
+            upper.pop()
+        upper.append(p)
+    return np.array(lower[:-1] + upper[:-1], np.float64)
+
+
+def minAreaRect(points):
+    """Minimum-area enclosing rectangle by rotating calipers over the convex hull: ((cx, cy), (w, h), angle in degrees).
+    Angle convention of OpenCV >= 4.5.1: in (0, 90], width measured along the edge that defines the angle."""
+    pts = np.asarray(points).reshape(-1, 2).astype(np.float64)
+    hull = _convex_hull(pts)
+    if len(hull) == 0:
+        return (0.0, 0.0), (0.0, 0.0), 0.0
+    if len(hull) == 1:
+        return (float(hull[0, 0]), float(hull[0, 1])), (0.0, 0.0), 90.0
+    best = None
+    n = len(hull)
+    for i in range(n if n > 2 else 1):
+        e = hull[(i + 1) % n] - hull[i]
+        ln = math.hypot(e[0], e[1])
+        if ln == 0:
+            continue
+        ux, uy = e[0] / ln, e[1] / ln
+        a = hull[:, 0] * ux + hull[:, 1] * uy
+        b = -hull[:, 0] * uy + hull[:, 1] * ux
+        wd, ht = a.max() - a.min(), b.max() - b.min()
+        if best is None or wd * ht < best[0]:
+            ca, cb = (a.max() + a.min()) / 2, (b.max() + b.min()) / 2
+            best = (wd * ht, (ca * ux - cb * uy, ca * uy + cb * ux), wd, ht, math.degrees(math.atan2(uy, ux)))
+    _, (cx, cy), wd, ht, ang = best
+    while ang <= 0:
+        ang += 90
+        wd, ht = ht, wd
+    while ang > 90:
+        ang -= 90
+        wd, ht = ht, wd
+    return (float(np.float32(cx)), float(np.float32(cy))), (float(np.float32(wd)), float(np.float32(ht))), float(np.float32(ang))
+
+
+def boxPoints(box):
+    """Corners of a rotated rect, in OpenCV's order (RotatedRect::points): bottom-left, top-left, top-right, bottom-right."""
+    (cx, cy), (w, h), ang = box
+    a = math.radians(ang)
+    b, c = math.cos(a) * 0.5, math.sin(a) * 0.5
+    p0 = (cx - c * h - b * w, cy + b * h - c * w)   # a = sin*0.5, b = cos*0.5 in OpenCV's source
+    p1 = (cx + c * h - b * w, cy - b * h - c * w)
+    p2 = (2 * cx - p0[0], 2 * cy - p0[1])
+    p3 = (2 * cx - p1[0], 2 * cy - p1[1])
+    return np.array([p0, p1, p2, p3], np.float32)
+
+
+def approxPolyDP(curve, epsilon, closed):
+    """Douglas-Peucker on the point list (closed curves are split at the two mutually farthest points)."""
+    pts = np.asarray(curve).reshape(-1, 2).astype(np.float64)
+    n = len(pts)
+    if n <= 2:
+        return np.asarray(curve).reshape(-1, 1, 2).copy()
+
+    def rdp(lo, hi, keep):
+        a, b = pts[lo], pts[hi % n]
+        idx = [i % n for i in range(lo + 1, hi)]
+        if not idx:
+            return
+        d = b - a
+        ln = math.hypot(d[0], d[1])
+        seg = pts[idx]
+        dist = np.abs(d[0] * (seg[:, 1] - a[1]) - d[1] * (seg[:, 0] - a[0])) / ln if ln > 0 else np.hypot(seg[:, 0] - a[0], seg[:, 1] - a[1])
+        k = int(np.argmax(dist))
+        if dist[k] > epsilon:
+            m = lo + 1 + k
+            keep.add(m % n)
+            rdp(lo, m, keep)
+            rdp(m, hi, keep)
+    keep = set()
+    if closed:
+        d0 = np.hypot(pts[:, 0] - pts[0, 0], pts[:, 1] - pts[0, 1])
+        far = int(np.argmax(d0))
+        d1 = np.hypot(pts[:, 0] - pts[far, 0], pts[:, 1] - pts[far, 1])
+        start = int(np.argmax(d1))
+        keep.update((start, far))
+        a, b = sorted((start, far))
+        rdp(a, b, keep)
+        rdp(b, a + n, keep)
+    else:
+        keep.update((0, n - 1))
+        rdp(0, n - 1, keep)
+    out = np.asarray(curve).reshape(-1, 2)[sorted(keep)]
+    return out.reshape(-1, 1, 2).copy()
+
+
+def addWeighted(src1, alpha, src2, beta, gamma):
+    """saturate_cast<uchar>(src1*alpha + src2*beta + gamma) with round-half-even (modules/bins.py:20)."""
+    acc = np.asarray(src1, np.float64) * alpha + np.asarray(src2, np.float64) * beta + gamma
+    return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+
+
+def drawContours(image, contours, contourIdx, color, thickness=1):
+    sel = contours if contourIdx < 0 else [contours[contourIdx]]
+    _draw.draw_contours(image, [np.asarray(c) for c in sel], color, thickness)
+    return image
+
+
+def install():
+    """Registers this facade as `cv2` when no real OpenCV is importable.  Returns the module that `import cv2` yields."""
+    try:
+        import cv2 as real
+        return real
+    except ImportError:
+        sys.modules["cv2"] = sys.modules[__name__]
+        return sys.modules[__name__]

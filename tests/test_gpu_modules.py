@@ -1,0 +1,185 @@
+"""GPU suite: module files written exactly like the reference's (`import cv2` + vision.utils + shm), running through
+the cv2 facade and the runtime: modules/bins.py:11-81 and the full modules/red_buoy.py:19-52 flow incl. contours."""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import frames as F
+from vision.core.bindings.camera_message_framework import BlockAccessor
+
+pytestmark = pytest.mark.gpu
+PID = os.getpid()
+
+
+@pytest.fixture()
+def cv2mod():
+    from vision import cv2_facade
+    had = sys.modules.get("cv2")
+    mod = cv2_facade.install()
+    yield mod
+    if had is None:
+        sys.modules.pop("cv2", None)
+
+
+def test_facade_matches_oracle(vp, oracle, cv2mod):
+    cv2 = cv2mod
+    img = F.s2_bins(0, 320, 180)
+    hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV)
+    assert np.array_equal(hsv, oracle.bgr2hsv(img))
+    mask = cv2.inRange(hsv, np.array([10, 20, 60]), np.array([30, 100, 255]))
+    assert np.array_equal(mask, oracle.inrange(hsv, (10, 20, 60), (30, 100, 255)))
+    k = cv2.getStructuringElement(cv2.MORPH_RECT, (5, 5))
+    opened = cv2.morphologyEx(mask, cv2.MORPH_OPEN, k)
+    assert np.array_equal(opened, oracle.morph(oracle.OPEN, mask, k))
+    cs, hier = cv2.findContours(opened, cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)
+    exp = oracle.find_contours(opened, 0, 2)
+    assert hier is None and len(cs) == len(exp) and all(np.array_equal(a, b) for a, b in zip(cs, exp))
+    n, lab, st, ce = cv2.connectedComponentsWithStats(opened, 8, cv2.CV_32S)
+    on, olab, ost, oce = oracle.ccl(opened, 2)
+    assert n == on and np.array_equal(lab, olab) and np.array_equal(st, ost)
+    vis = cv2.cvtColor(mask, cv2.COLOR_GRAY2BGR)
+    over = cv2.addWeighted(img, 0.7, vis, 0.3, 0)
+    assert over.dtype == np.uint8 and over.shape == img.shape
+    with pytest.raises(AttributeError):
+        cv2.GaussianBlur
+
+
+def test_rotated_rect_helpers(cv2mod):
+    cv2 = cv2mod
+    sq = np.array([[[10, 10]], [[10, 30]], [[50, 30]], [[50, 10]]], np.int32)
+    (cx, cy), (w, h), ang = cv2.minAreaRect(sq)
+    assert (cx, cy) == (30.0, 20.0) and sorted((w, h)) == [20.0, 40.0] and 0 < ang <= 90
+    box = cv2.boxPoints(((cx, cy), (w, h), ang))
+    assert {tuple(p) for p in np.rint(box).astype(int).tolist()} == {(10, 10), (10, 30), (50, 30), (50, 10)}
+    th = np.deg2rad(30)
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    rect = (np.array([[-40, -10], [40, -10], [40, 10], [-40, 10]]) @ R.T + [100, 80]).astype(np.float32).reshape(-1, 1, 2)
+    (cx, cy), (w, h), ang = cv2.minAreaRect(rect)
+    assert abs(cx - 100) < 1e-3 and abs(cy - 80) < 1e-3 and abs(max(w, h) - 80) < 1e-3 and abs(min(w, h) - 20) < 1e-3 and 0 < ang <= 90
+    assert cv2.contourArea(sq) == 800.0 and cv2.arcLength(sq, True) == 120.0
+    assert len(cv2.approxPolyDP(sq, 1.0, True)) == 4
+    dense = np.array([[[x, 0]] for x in range(0, 50)] + [[[49, y]] for y in range(1, 30)] + [[[x, 29]] for x in range(48, -1, -1)] +
+                     [[[0, y]] for y in range(28, 0, -1)], np.int32)
+    assert len(cv2.approxPolyDP(dense, 2.0, True)) == 4
+
+
+def _run_module(mod, feed, want, timeout=30):
+    runner = threading.Thread(target=mod)
+    runner.start()
+    try:
+        t0 = time.time()
+        while not want(mod) and time.time() - t0 < timeout:
+            feed()
+            time.sleep(0.02)
+    finally:
+        mod.stop()
+        runner.join(10)
+
+
+def test_bins_module_style(vp, oracle, cv2mod, monkeypatch):
+    """Body = modules/bins.py:11-81 (np.int0 spelled np.intp: removed in numpy 2)."""
+    monkeypatch.setattr(sys, "argv", ["bins.py"])
+    import cv2
+    from vision.core.base import ModuleBase
+    from vision.utils.feature import outer_contours
+    from vision.utils.transform import morph_remove_noise, rect_kernel
+    seen = []
+
+    class BinDetector(ModuleBase):
+        def process(self, direction, img):
+            hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV)
+            mask = cv2.inRange(hsv, np.array([10, 20, 60]), np.array([30, 100, 255]))
+            mask_vis = cv2.cvtColor(mask, cv2.COLOR_GRAY2BGR)
+            overlayed = cv2.addWeighted(img, 0.7, mask_vis, 0.3, 0)
+            cleaned = morph_remove_noise(mask, rect_kernel(5))
+            contours = outer_contours(cleaned)
+            valid = []
+            for contour in contours:
+                rect = cv2.minAreaRect(contour)
+                (center, (w, h), angle) = rect
+                if w * h < 500:
+                    continue
+                if 1.0 <= max(w, h) / min(w, h) <= 3.0:
+                    valid.append(rect)
+            for rect in valid:
+                cv2.drawContours(overlayed, [np.intp(cv2.boxPoints(rect))], 0, (0, 255, 0), 4)
+            self.post("bins", overlayed)
+            seen.append((cleaned, contours, valid, overlayed))
+
+    d = f"pytbins{PID}"
+    frame = F.s2_bins(1, 640, 360)
+    with BlockAccessor(d, max_entry_size_bytes=frame.nbytes) as w:
+        mod = BinDetector(video_sources=[d], tuners=[])
+        mod._fps = 200
+        _run_module(mod, lambda: w.write_frame(int(time.monotonic() * 1000), frame), lambda m: len(seen) >= 2)
+    assert len(seen) >= 2
+    cleaned, contours, valid, over = seen[0]
+    exp_clean = oracle.morph(oracle.OPEN, oracle.inrange(oracle.bgr2hsv(frame), (10, 20, 60), (30, 100, 255)), np.ones((5, 5), np.uint8))
+    assert np.array_equal(cleaned, exp_clean)
+    exp_c = oracle.find_contours(exp_clean, 0, 2)
+    assert len(contours) == len(exp_c) and all(np.array_equal(a, b) for a, b in zip(contours, exp_c))
+    assert len(valid) >= 3                                      # the 2:1 beige rectangles of S2
+    for (c, (w_, h_), a) in valid:
+        assert 1.5 < max(w_, h_) / min(w_, h_) < 2.6
+    assert (over[:, :, 1] == 255).sum() > 100                   # green boxes were drawn
+
+
+def test_red_buoy_module_style(vp, oracle, monkeypatch):
+    """Body = modules/red_buoy.py:19-52, with the method the reference leaves undefined supplied by the test."""
+    monkeypatch.setattr(sys, "argv", ["red_buoy.py"])
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "shims"))
+    import shm
+    from vision.core.base import ModuleBase, sources
+    from vision.core.tuners import IntTuner
+    from vision.utils.color import bgr_to_lab, range_threshold
+    from vision.utils.draw import draw_contours
+    from vision.utils.feature import contour_area, contour_centroid, outer_contours
+    from vision.utils.transform import morph_close_holes, morph_remove_noise, rect_kernel
+    log = []
+
+    class BuoyLAB(ModuleBase):
+        @sources("zed[forward]", "zed[normal]")
+        def process_img(self, image, normal):
+            lab, (lab_l, lab_a, lab_b) = bgr_to_lab(image)
+            threshed = range_threshold(lab_a, self.tuners["thresh_min"], self.tuners["thresh_max"])
+            self.post("threshed", threshed, "GRAY")
+            kernel = rect_kernel(5)
+            cleaned = morph_remove_noise(threshed, kernel)
+            cleaned = morph_close_holes(cleaned, kernel)
+            self.post("threshed_cleaned", cleaned, "GRAY")
+            self._contours = outer_contours(threshed)
+            draw_contours(image, self._contours, thickness=10)
+            contour = self.extract_most_likely_contour()
+            x, y = contour_centroid(contour)
+            area = contour_area(contour)
+            ny, nx = self.normalize((y, x))
+            shm.red_buoy_results.center_x.set(nx)
+            shm.red_buoy_results.center_x.set(ny)
+            shm.red_buoy_results.area.set(area)
+            self.post("contours", image)
+            log.append((threshed, self._contours, (x, y), area))
+
+        def extract_most_likely_contour(self):          # "logic omitted" upstream (modules/red_buoy.py:40)
+            return max(self._contours, key=contour_area)
+
+    d = f"pytzedb{PID}"
+    frame = F.s1_buoy(2, 640, 360)
+    normal = np.zeros((360, 640, 3), np.float32)
+    with BlockAccessor(d, max_entry_size_bytes=frame.nbytes + normal.nbytes) as w:
+        mod = BuoyLAB([d], [IntTuner("thresh_min", 150, 0, 255), IntTuner("thresh_max", 255, 0, 255)])
+        mod._fps = 200
+        _run_module(mod, lambda: w.write_frame(int(time.monotonic() * 1000), [("forward", frame), ("normal", normal)]), lambda m: len(log) >= 1)
+    assert log
+    threshed, contours, (x, y), area = log[0]
+    th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(frame)[:, :, 1]), 150, 255)
+    assert np.array_equal(threshed, th)
+    exp = oracle.find_contours(th, 0, 2)
+    assert len(contours) == len(exp) and all(np.array_equal(a, b) for a, b in zip(contours, exp))
+    best = max(exp, key=lambda c: oracle.contour_moments(c)["area"])
+    m = oracle.contour_moments(best)
+    assert area == m["area"] and (x, y) == (int(m["m10"] / m["m00"]), int(m["m01"] / m["m00"]))
+    assert shm.red_buoy_results.area.get() == area
