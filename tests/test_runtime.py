@@ -244,3 +244,31 @@ def test_capture_source_harness_and_image_directory(tmp_path):
         t.join(5)
         src.close()
     assert not os.path.exists(BLOCK_STUB + d)
+
+
+def test_video_capture_source(tmp_path):
+    """capture_sources/video.py:9-39: one decoded frame per tick fanned out to every listed direction."""
+    from vision.capture_sources.video import Video
+    frames = np.random.default_rng(3).integers(0, 255, (4, 12, 16, 3), dtype=np.uint8)
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    a, b = f"pytva{PID}", f"pytvb{PID}"
+    src = Video(str(path), [a, b], fps=200, loop=True)
+    t = threading.Thread(target=src.run_event_loop)
+    t.start()
+    try:
+        seen = {a: set(), b: set()}
+        with BlockAccessor(a) as ra, BlockAccessor(b) as rb:
+            def pump():
+                for name, r in ((a, ra), (b, rb)):
+                    st, data, _ = r.read_frame()
+                    if data is not None:
+                        for k in range(4):
+                            if np.array_equal(data, frames[k]):
+                                seen[name].add(k)
+                return len(seen[a]) == 4 and len(seen[b]) == 4
+            assert _wait(pump, timeout=5)
+    finally:
+        src._quit_flag.set()
+        t.join(5)
+        src.close()
