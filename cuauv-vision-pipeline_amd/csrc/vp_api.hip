@@ -438,6 +438,33 @@ int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src, size_t src_stride
     return vp_synchronize(ctx);
 }
 
+int vp_cvt_bgr2lab_f32(vp_ctx* ctx, const float* src, int w, int h, float* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_cvt_bgr2lab_f32 arguments");
+    const size_t npx = (size_t)w * h;
+    VP_TRY(vp_ws_reserve(ctx, 2 * vp_align(npx * 12) + 1024));
+    TAKE(d_src, float*, npx * 12);
+    TAKE(d_dst, float*, npx * 12);
+    VP_TRY(h2d(ctx, d_src, src, npx * 12));
+    VP_TRY(vpk_bgr2lab_f32(ctx, d_src, npx, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, npx * 12));
+    return vp_synchronize(ctx);
+}
+
+int vp_order_stats_f32(vp_ctx* ctx, const float* src, size_t n, size_t k, float* v_k, float* v_k1)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !v_k || n == 0 || k >= n) return vp_fail(ctx, VP_ERR_INVALID, "vp_order_stats_f32 arguments");
+    VP_TRY(vp_ws_reserve(ctx, vp_align(n * 4) + 4096));
+    TAKE(d_src, float*, n * 4);
+    TAKE(d_hist, u32*, 1024);
+    VP_TRY(h2d(ctx, d_src, src, n * 4));
+    VP_TRY(vpk_kth_f32(ctx, d_src, n, k, d_hist, v_k));
+    if (v_k1) VP_TRY(vpk_kth_f32(ctx, d_src, n, k + 1 < n ? k + 1 : n - 1, d_hist, v_k1));
+    return VP_OK;
+}
+
 int vp_inrange_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, int cn, const int32_t* lo, const int32_t* hi,
                   uint8_t* dst)
 {

@@ -10,6 +10,7 @@
 // LUTs live in LDS.  HBM-bound: 4.125 B/px.
 #include "vp_internal.h"
 #include <cstdlib>
+#include <cstring>
 
 #define LAB_LSHIFT (-1336934)  // -((16*255*32768 + 50)/100)
 
@@ -368,5 +369,92 @@ int vpk_color_distance(vp_ctx* ctx, const uint8_t* p0, const uint8_t* p1, const 
     hipLaunchKernelGGL(k_color_distance, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, p0 ? p0 : any,
                        p1 ? p1 : any, p2 ? p2 : any, npx, prm, d2, sq);
     VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+
+// ---- float32 CIE L*a*b* (north star: "LAB floats match within 1e-4") -------------------------------------------------
+// Analytic conversion of BGR float32 in [0,1] (sRGB gamma, D65, the same matrix/white point as the 8-bit path):
+// L in [0,100], a/b in about [-127,127].  The reference never converts float images (every LAB call site is on u8,
+// SURVEY A1), so this is an extension; it is checked against float64 arithmetic at 1e-4, not against cv2's
+// interpolated-LUT float path.
+__global__ __launch_bounds__(256) void k_bgr2lab_f32(const float* __restrict__ src, size_t npx, float* __restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float v = src[3 * i + k];
+        c[k] = v <= 0.04045f ? v * (1.0f / 12.92f) : powf((v + 0.055f) * (1.0f / 1.055f), 2.4f);
+    }
+    const float B = c[0], G = c[1], R = c[2];
+    float X = (0.412453f * R + 0.357580f * G + 0.180423f * B) * (1.0f / 0.950456f);
+    float Y = 0.212671f * R + 0.715160f * G + 0.072169f * B;
+    float Z = (0.019334f * R + 0.119193f * G + 0.950227f * B) * (1.0f / 1.088754f);
+    const float thr = 216.0f / 24389.0f, sl = 841.0f / 108.0f, bi = 16.0f / 116.0f;
+    const float fx = X > thr ? cbrtf(X) : sl * X + bi;
+    const float fy = Y > thr ? cbrtf(Y) : sl * Y + bi;
+    const float fz = Z > thr ? cbrtf(Z) : sl * Z + bi;
+    dst[3 * i] = 116.0f * fy - 16.0f;
+    dst[3 * i + 1] = 500.0f * (fx - fy);
+    dst[3 * i + 2] = 200.0f * (fy - fz);
+}
+
+int vpk_bgr2lab_f32(vp_ctx* ctx, const float* d_src, size_t npx, float* d_dst)
+{
+    hipLaunchKernelGGL(k_bgr2lab_f32, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, d_src, npx, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+
+// ---- order statistics of a float32 image (np.percentile in thresh_color_distance, utils/color.py:98) ------------------
+// Exact k-th smallest by 4 rounds of 8-bit radix selection on order-preserving keys; each round is one histogram
+// kernel (LDS bins per block, then 256 global atomics) and a 1 KB read-back.
+__device__ __forceinline__ u32 f32_key(float f)
+{
+    const u32 b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void k_radix_hist(const float* __restrict__ src, size_t n, u32 prefix, u32 prefix_mask, int shift,
+                                                    u32* __restrict__ hist)
+{
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const u32 k = f32_key(src[i]);
+        if ((k & prefix_mask) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
+}
+
+int vpk_kth_f32(vp_ctx* ctx, const float* d_src, size_t n, size_t k, u32* d_hist, float* out)
+{
+    if (k >= n) return vp_fail(ctx, VP_ERR_INVALID, "order statistic index");
+    u32 prefix = 0, mask = 0;
+    size_t rank = k;
+    u32 host_hist[256];
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (size_t)ctx->num_cu * 8) blocks = (size_t)ctx->num_cu * 8;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        VP_HIP(ctx, hipMemsetAsync(d_hist, 0, 1024, ctx->stream));
+        hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_src, n, prefix, mask, shift, d_hist);
+        VP_HIP(ctx, hipMemcpyAsync(host_hist, d_hist, 1024, hipMemcpyDeviceToHost, ctx->stream));
+        VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int b = 0;
+        for (; b < 256; b++) {
+            if (rank < host_hist[b]) break;
+            rank -= host_hist[b];
+        }
+        if (b == 256) return vp_fail(ctx, VP_ERR_HIP, "radix select lost its element");
+        prefix |= (u32)b << shift;
+        mask |= 0xffu << shift;
+    }
+    const u32 bits = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+    memcpy(out, &bits, 4);
     return VP_OK;
 }

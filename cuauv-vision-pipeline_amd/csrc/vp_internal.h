@@ -86,6 +86,8 @@ int vpk_inrange_u8(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int 
                    uint8_t* d_dst);
 int vpk_inrange_f32(vp_ctx* ctx, const float* d_src, size_t stride_bytes, int w, int h, float lo, float hi,
                     uint8_t* d_dst);
+int vpk_kth_f32(vp_ctx* ctx, const float* d_src, size_t n, size_t k, u32* d_hist, float* out);
+int vpk_bgr2lab_f32(vp_ctx* ctx, const float* d_src, size_t npx, float* d_dst);
 int vpk_color_distance(vp_ctx* ctx, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, size_t npx,
                        const float* color, const float* wts, int skipmask, float* d2, uint8_t* sq);
 

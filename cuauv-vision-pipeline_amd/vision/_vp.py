@@ -62,6 +62,8 @@ _SIGS = {
     "vp_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "vp_profile_kernel_name": (C.c_char_p, [C.c_int]),
     "vp_cvt_color_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vp_cvt_bgr2lab_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vp_order_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "vp_inrange_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vp_inrange_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "vp_color_distance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

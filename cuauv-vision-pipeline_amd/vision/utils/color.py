@@ -69,6 +69,37 @@ lab_to_bgr = _unsupported("lab_to_bgr")
 hsv_to_bgr = _unsupported("hsv_to_bgr")
 
 
+def bgr_to_lab_f32(mat: np.ndarray):
+    """Extension: float32 BGR in [0,1] -> (lab float32 (h,w,3), (L, a, b) planes), analytic CIE L*a*b* (L 0..100)."""
+    mat = np.ascontiguousarray(as_mat(mat), dtype=np.float32)
+    if mat.ndim != 3 or mat.shape[2] != 3 or mat.size == 0:
+        raise ValueError("expected a non-empty (h, w, 3) float image")
+    h, w = mat.shape[:2]
+    out = np.empty_like(mat)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_cvt_bgr2lab_f32(ctx.handle, _vp.ptr(mat), w, h, _vp.ptr(out)), ctx.handle)
+    return out, tuple(np.ascontiguousarray(out[:, :, c]) for c in range(3))
+
+
+def percentile_f32(arr: np.ndarray, q: float) -> float:
+    """np.percentile(arr, q) (method 'linear') of a float32 array: the two neighbouring order statistics are selected on
+    the GPU (libvp vp_order_stats_f32), the interpolation follows numpy's _lerp in float64."""
+    flat = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+    n = flat.size
+    if n == 0:
+        raise ValueError("percentile of an empty array")
+    virtual = (n - 1) * (float(q) / 100.0)
+    lo = int(np.floor(virtual))
+    lo = min(max(lo, 0), n - 1)
+    gamma = virtual - lo
+    a, b = _vp.C.c_float(), _vp.C.c_float()
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_order_stats_f32(ctx.handle, _vp.ptr(flat), n, lo, _vp.C.byref(a), _vp.C.byref(b)), ctx.handle)
+    a, b = np.float64(np.float32(a.value)), np.float64(np.float32(b.value))
+    diff = b - a
+    return float(b - diff * (1 - gamma)) if gamma >= 0.5 else float(a + diff * gamma)
+
+
 def color_dist(c1, c2) -> float:
     """utils/color.py:35-48."""
     return sqrt((c1[0] - c2[0])**2 + (c1[1] - c2[1])**2 + (c1[2] - c2[2])**2)
@@ -154,9 +185,7 @@ def thresh_color_distance(split: List[np.ndarray], color, distance: float, auto_
     ctx = _vp.default_context()
     _vp.check(_vp.lib().vp_color_distance_u8(ctx.handle, arr, w, h, _vp.ptr(col), _vp.ptr(wts), skip, _vp.ptr(d2), _vp.ptr(sq)), ctx.handle)
     if auto_distance_percentile:
-        # the reference takes np.percentile over the whole image (utils/color.py:98); order statistics of
-        # a float image are host-side numpy here, outside the accelerated chain
-        distance = min(np.percentile(d2, auto_distance_percentile), distance**2)
+        distance = min(percentile_f32(d2, auto_distance_percentile), distance**2)
     else:
         distance = distance**2
     return range_threshold(d2, 0, distance), sq

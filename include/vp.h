@@ -84,6 +84,10 @@ int vp_get_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* h
 int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src_host, size_t src_stride, int w, int h,
                     uint8_t* dst_interleaved_host, uint8_t* const* dst_planes_host);
 
+/* Extension (BASELINE north star "LAB floats within 1e-4"; no reference call site converts float images): BGR float32 in
+ * [0,1] (h,w,3 tightly packed) -> CIE L*a*b* float32 (L 0..100, a/b about -127..127), analytic sRGB / D65. */
+int vp_cvt_bgr2lab_f32(vp_ctx* ctx, const float* src_host, int w, int h, float* dst_host);
+
 /* utils/color.py:105-121 `range_threshold` / modules/bins.py:16 (cv2.inRange): cn = 1 or 3;
  * lo/hi have cn entries (already rounded to integers); dst is (h,w) 0/255. */
 int vp_inrange_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride, int w, int h, int cn,
@@ -97,6 +101,9 @@ int vp_inrange_f32(vp_ctx* ctx, const float* src_host, size_t src_stride_bytes, 
  * dist2_out ((h,w) f32) and sqrt_out ((h,w) u8 = uint8(sqrt(d2))) may each be NULL. */
 int vp_color_distance_u8(vp_ctx* ctx, const uint8_t* const* planes_host, int w, int h, const float* color,
                          const float* wts, int skipmask, float* dist2_out_host, uint8_t* sqrt_out_host);
+/* Order statistics for np.percentile(dists, p) in utils/color.py:98: the k-th and (k+1)-th smallest of n float32 values
+ * (exact, by radix selection on the device); v_k1 may be NULL; k+1 is clamped to n-1. */
+int vp_order_stats_f32(vp_ctx* ctx, const float* src_host, size_t n, size_t k, float* v_k, float* v_k1);
 /* utils/transform.py:27-77 `elliptic_kernel` / `rect_kernel` (cv2.getStructuringElement):
  * out is (kh,kw) 0/1.  Integer geometry on the host, no device needed. */
 int vp_structuring_element(int shape, int kw, int kh, uint8_t* out);

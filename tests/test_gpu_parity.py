@@ -320,3 +320,41 @@ def test_device_resident_chain_matches_host_chain(vp):
     assert L.vp_chain_algorithmic_bytes(C.byref(desc), C.byref(bufs), n) == npx * 9
     for p in (bufs.bgr, bufs.threshed, bufs.cleaned, bufs.labels, bufs.stats, bufs.centroids, bufs.nlabels):
         vp.check(L.vp_dev_free(ctx.handle, p))
+
+
+def test_lab_float32_within_1e_4(vp):
+    """North star: "LAB floats match within 1e-4".  Float path vs float64 analytic CIE L*a*b* (tolerance 1e-4 absolute
+    on L in [0,100] / a,b in [-127,127]; measured error is ~2e-5)."""
+    from vision.utils import color
+    rng = np.random.default_rng(0)
+    img = rng.random((120, 200, 3)).astype(np.float32)
+    img[0, :8] = np.array([[0, 0, 0], [1, 1, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0.04045, 0.04045, 0.04045], [0.003, 0.002, 0.001], [0.5, 0.5, 0.5]], np.float32)
+    lab, (L, a, b) = color.bgr_to_lab_f32(img)
+    rgb = img[:, :, ::-1].astype(np.float64)
+    lin = np.where(rgb <= 0.04045, rgb / 12.92, ((rgb + 0.055) / 1.055) ** 2.4)
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    xyz = lin @ M.T / np.array([0.950456, 1.0, 1.088754])
+    f = np.where(xyz > 216 / 24389, np.cbrt(xyz), 841 / 108 * xyz + 16 / 116)
+    ref = np.stack([116 * f[..., 1] - 16, 500 * (f[..., 0] - f[..., 1]), 200 * (f[..., 1] - f[..., 2])], -1)
+    err = np.abs(lab.astype(np.float64) - ref).max()
+    assert err <= 1e-4, err
+    assert np.array_equal(L, lab[:, :, 0]) and abs(lab[0, 1, 0] - 100.0) < 1e-4 and abs(lab[0, 0]).max() < 1e-4
+
+
+def test_percentile_and_auto_distance(vp, oracle):
+    """utils/color.py:98: distance = min(np.percentile(dists, p), distance**2); the order statistics come from the GPU."""
+    from vision.utils import color
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 7, 1000, 70001):
+        a = (rng.normal(0, 50, n) ** 2).astype(np.float32)
+        if n > 5:
+            a[:3] = [-4.0, 0.0, -0.0]
+        for q in (0, 0.5, 25, 50, 90, 99.9, 100):
+            assert color.percentile_f32(a, q) == float(np.percentile(a.astype(np.float64), q)), (n, q)
+    img = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    split = [np.ascontiguousarray(img[:, :, c]) for c in range(3)]
+    mask, dist = color.thresh_color_distance(split, (100, 150, 60), 500.0, auto_distance_percentile=20)
+    wn = (np.ones(3) / np.linalg.norm((1, 1, 1))).astype(np.float32)
+    d2, sq = oracle.color_distance(split, (100, 150, 60), wn, 0)
+    thr = min(np.percentile(d2.astype(np.float64), 20), 500.0 ** 2)
+    assert np.array_equal(mask, oracle.inrange(d2, 0.0, float(np.float32(thr)))) and 0.18 < (mask > 0).mean() < 0.22
