@@ -643,7 +643,7 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, 
     TAKE(d_nl, int32_t*, 4);
     vp_ccl_ws ws;
     vp_ccl_ws_carve(ctx, w, h, 1, max_labels, &ws);
-    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart || !ws.done) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
     VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
     VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
     VP_TRY(vpk_ccl(ctx, d_bits, w, h, 1, numbering, ws, labels ? d_labels : nullptr, d_stats, d_cent, max_labels, d_nl));
@@ -769,7 +769,7 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
     if (d->ccl) {
         vp_ccl_ws ws;
         vp_ccl_ws_carve(ctx, w, h, n, d->max_labels, &ws);
-        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart || !ws.done) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
         VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
                        b->nlabels ? b->nlabels : d_nl));
     }

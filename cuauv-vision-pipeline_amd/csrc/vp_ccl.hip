@@ -23,7 +23,8 @@
 //                  of the same launch reduce the background row (label 0) without atomics
 //   k_ccl_stats    label = rank(root)+1 per segment -> seglabel[id], wordlabel[word]; per-block LDS aggregation,
 //                  then one set of global atomics per (block, label)
-//   k_ccl_final    accumulators -> stats (i32 x5) + centroids (f64 x2)
+//                  the last block of a frame (done counter) turns the accumulators into stats (i32 x5) + centroids (f64 x2)
+//   k_ccl_final    the same as a separate launch (the default: the in-kernel variant costs a fence + counter atomic per block)
 //   k_ccl_write    bits + wordlabel (+ seglabel for words holding several segments) -> int32 label image
 #include "vp_internal.h"
 #include <limits.h>
@@ -70,7 +71,7 @@ size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
 {
     const size_t nids = vp_ccl_nids(w, h);
     return vp_align(nids * 4 * n) * 2 + vp_align(nids / 8 * n) * 2 + vp_align(sizeof(ccl_acc) * (size_t)max_labels * n) +
-           vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) + 2048;
+           vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) + vp_align(4 * (size_t)n) + 2048;
 }
 
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out)
@@ -83,6 +84,7 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->acc = vp_ws_take(ctx, sizeof(ccl_acc) * (size_t)max_labels * n);
     out->wordlabel = (u32*)vp_ws_take(ctx, (size_t)n * h * vp_ww(w) * 4);
     out->bgpart = vp_ws_take(ctx, sizeof(contrib) * BG_PARTS * (size_t)n);
+    out->done = (u32*)vp_ws_take(ctx, 4 * (size_t)n);
 }
 
 __device__ __forceinline__ u32 seg_id(const ccl_geom& G, int y, int x)
@@ -416,9 +418,10 @@ __device__ __forceinline__ void wave_combine(contrib& c)
 // blocks [RK_PARTS, RK_PARTS + BG_PARTS): background pixels of a slice of the frame reduced to one record.
 __global__ __launch_bounds__(256) void k_ccl_rank(ccl_geom G, const u32* __restrict__ flags, u32* __restrict__ prefix,
                                                   int32_t* __restrict__ nlabels, ccl_acc* __restrict__ acc, int max_labels,
-                                                  const u64* __restrict__ bits, contrib* __restrict__ bgpart)
+                                                  const u64* __restrict__ bits, contrib* __restrict__ bgpart, u32* __restrict__ done)
 {
     __shared__ u32 wsum[4];
+    __shared__ u32 wsum2[4];
     __shared__ u32 bcast;
     __shared__ contrib part[4];
     const int f = blockIdx.y, tid = threadIdx.x;
@@ -460,27 +463,49 @@ __global__ __launch_bounds__(256) void k_ccl_rank(ccl_geom G, const u32* __restr
     const u32 q0 = min((u32)partno * qper, nq), q1 = min(q0 + qper, nq);
     const uint4* fl = reinterpret_cast<const uint4*>(flags + (size_t)f * G.nw32);
     uint4* pf = reinterpret_cast<uint4*>(prefix + (size_t)f * G.nw32);
-    u32 before = 0;
-    for (u32 q = tid; q < q0; q += 256) { const uint4 v = fl[q]; before += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) before += __shfl_xor(before, d);
-    if (lane == 0) wsum[wv] = before;
-    __syncthreads();
-    const u32 base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
+    // own slice: thread = contiguous run of uint4s, loaded once and kept in registers (RK_OWN covers 1080p..4K)
+    constexpr int RK_OWN = 16;
     const u32 per = (q1 - q0 + 255) / 256;
     const u32 lo = min(q0 + (u32)tid * per, q1), hi = min(lo + per, q1);
+    uint4 own[RK_OWN];
     u32 cnt = 0;
-    for (u32 q = lo; q < hi; q++) { const uint4 v = fl[q]; cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+#pragma unroll
+    for (int k = 0; k < RK_OWN; k++) {
+        own[k] = make_uint4(0, 0, 0, 0);
+        if (lo + k < hi) own[k] = fl[lo + k];
+    }
+    // bits before this part: independent loads, issued in batches
+    u32 before = 0;
+#pragma unroll 8
+    for (u32 q = tid; q < q0; q += 256) { const uint4 v = fl[q]; before += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+#pragma unroll
+    for (int k = 0; k < RK_OWN; k++) cnt += __popc(own[k].x) + __popc(own[k].y) + __popc(own[k].z) + __popc(own[k].w);
+    for (u32 q = lo + RK_OWN; q < hi; q++) { const uint4 v = fl[q]; cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }   // slices beyond RK_OWN (huge images)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) before += __shfl_xor(before, d);
     u32 inc = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
+    if (lane == 0) wsum[wv] = before;
+    if (lane == 63) wsum2[wv] = inc;
     __syncthreads();
+    const u32 base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     u32 woff = 0;
-    for (int k = 0; k < wv; k++) woff += wsum[k];
+    for (int k = 0; k < wv; k++) woff += wsum2[k];
     u32 run = base + woff + inc - cnt;
-    for (u32 q = lo; q < hi; q++) {
+#pragma unroll
+    for (int k = 0; k < RK_OWN; k++) {
+        if (lo + k < hi) {
+            const uint4 v = own[k];
+            uint4 o;
+            o.x = run; run += __popc(v.x);
+            o.y = run; run += __popc(v.y);
+            o.z = run; run += __popc(v.z);
+            o.w = run; run += __popc(v.w);
+            pf[lo + k] = o;
+        }
+    }
+    for (u32 q = lo + RK_OWN; q < hi; q++) {
         const uint4 v = fl[q];
         uint4 o;
         o.x = run; run += __popc(v.x);
@@ -494,6 +519,7 @@ __global__ __launch_bounds__(256) void k_ccl_rank(ccl_geom G, const u32* __restr
         __syncthreads();
         const int nl = (int)bcast + 1;
         if (tid == 0 && nlabels) nlabels[f] = nl;
+        if (tid == 0 && done) done[f] = 0;
         ccl_acc* a = acc + (size_t)f * max_labels;
         const int nz = min(nl, max_labels);
         for (int i = tid; i < nz; i += 256) {
@@ -530,71 +556,120 @@ struct st_table {
 __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent,
                                                    const u32* __restrict__ flags, const u32* __restrict__ prefix,
                                                    u32* __restrict__ seglabel, u32* __restrict__ wordlabel,
-                                                   ccl_acc* __restrict__ acc, int max_labels)
+                                                   ccl_acc* __restrict__ acc, int max_labels, u32* __restrict__ done,
+                                                   const contrib* __restrict__ bgpart, const int32_t* __restrict__ nlabels,
+                                                   int32_t* __restrict__ stats, double* __restrict__ cent)
 {
     __shared__ st_table T;
+    __shared__ u32 s_last;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < G.h * G.ww;
     const int f = blockIdx.y;
     const u64 w = live ? bits[(size_t)f * G.h * G.ww + idx] : 0ull;
-    if (!__syncthreads_or(w != 0ull)) return;   // block-uniform
-    if (threadIdx.x < ST_SLOTS) {
-        const int i = threadIdx.x;
-        T.label[i] = 0; T.area[i] = 0; T.sx[i] = 0; T.sy[i] = 0;
-        T.minx[i] = INT_MAX; T.miny[i] = INT_MAX; T.maxx[i] = INT_MIN; T.maxy[i] = INT_MIN;
-    }
-    __syncthreads();
+    const bool any_fg = __syncthreads_or(w != 0ull);   // block-uniform
     ccl_acc* a = acc + (size_t)f * max_labels;
-    if (w) {
-        const int y = idx / G.ww, j = idx - y * G.ww;
-        const u32* p = parent + (size_t)f * G.nids;
-        const u32* fl = flags + (size_t)f * G.nw32;
-        const u32* pf = prefix + (size_t)f * G.nw32;
-        u32* sl = seglabel + (size_t)f * G.nids;
-        u64 rem = w;
-        bool first = true;
-        while (rem) {
-            const int s = __ffsll((long long)rem) - 1;
-            const int e = run_end(rem, s);
-            rem &= ~bit_range(s, e);
-            const u32 id = seg_id(G, y, 64 * j + s);
-            u32 r = id;
-            for (u32 q = p[r]; q != r; q = p[r]) r = q;   // read-only walk: strip root, then across strips
-            const u32 label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
-            sl[id] = label;
-            if (first) { wordlabel[(size_t)f * G.h * G.ww + idx] = label; first = false; }
-            if (label >= (u32)max_labels) continue;
-            const u32 len = (u32)(e - s + 1);
-            const int xs = 64 * j + s, xe = 64 * j + e;
-            const u64 sx = (u64)len * (u64)(xs + xe) / 2ull, sy = (u64)len * (u64)y;
-            u32 slot = (label * 2654435761u) >> 26;   // 6 bits
-            bool done = false;
-            for (int probe = 0; probe < 8 && !done; probe++, slot = (slot + 1) & (ST_SLOTS - 1)) {
-                const u32 cur = atomicCAS(&T.label[slot], 0u, label);
-                if (cur == 0u || cur == label) {
-                    atomicAdd(&T.area[slot], len);
-                    atomicAdd((unsigned long long*)&T.sx[slot], (unsigned long long)sx);
-                    atomicAdd((unsigned long long*)&T.sy[slot], (unsigned long long)sy);
-                    atomicMin(&T.minx[slot], xs);
-                    atomicMax(&T.maxx[slot], xe);
-                    atomicMin(&T.miny[slot], y);
-                    atomicMax(&T.maxy[slot], y);
-                    done = true;
+    if (any_fg) {
+        if (threadIdx.x < ST_SLOTS) {
+            const int i = threadIdx.x;
+            T.label[i] = 0; T.area[i] = 0; T.sx[i] = 0; T.sy[i] = 0;
+            T.minx[i] = INT_MAX; T.miny[i] = INT_MAX; T.maxx[i] = INT_MIN; T.maxy[i] = INT_MIN;
+        }
+        __syncthreads();
+        if (w) {
+            const int y = idx / G.ww, j = idx - y * G.ww;
+            const u32* p = parent + (size_t)f * G.nids;
+            const u32* fl = flags + (size_t)f * G.nw32;
+            const u32* pf = prefix + (size_t)f * G.nw32;
+            u32* sl = seglabel + (size_t)f * G.nids;
+            u64 rem = w;
+            bool first = true;
+            while (rem) {
+                const int s = __ffsll((long long)rem) - 1;
+                const int e = run_end(rem, s);
+                rem &= ~bit_range(s, e);
+                const u32 id = seg_id(G, y, 64 * j + s);
+                u32 r = id;
+                for (u32 q = p[r]; q != r; q = p[r]) r = q;   // read-only walk: strip root, then across strips
+                const u32 label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
+                sl[id] = label;
+                if (first) { wordlabel[(size_t)f * G.h * G.ww + idx] = label; first = false; }
+                if (label >= (u32)max_labels) continue;
+                const u32 len = (u32)(e - s + 1);
+                const int xs = 64 * j + s, xe = 64 * j + e;
+                const u64 sx = (u64)len * (u64)(xs + xe) / 2ull, sy = (u64)len * (u64)y;
+                u32 slot = (label * 2654435761u) >> 26;   // 6 bits
+                bool placed = false;
+                for (int probe = 0; probe < 8 && !placed; probe++, slot = (slot + 1) & (ST_SLOTS - 1)) {
+                    const u32 cur = atomicCAS(&T.label[slot], 0u, label);
+                    if (cur == 0u || cur == label) {
+                        atomicAdd(&T.area[slot], len);
+                        atomicAdd((unsigned long long*)&T.sx[slot], (unsigned long long)sx);
+                        atomicAdd((unsigned long long*)&T.sy[slot], (unsigned long long)sy);
+                        atomicMin(&T.minx[slot], xs);
+                        atomicMax(&T.maxx[slot], xe);
+                        atomicMin(&T.miny[slot], y);
+                        atomicMax(&T.maxy[slot], y);
+                        placed = true;
+                    }
+                }
+                if (!placed) {   // crowded block (noise): straight to global memory
+                    contrib c;
+                    c.area = len; c.sx = sx; c.sy = sy; c.minx = xs; c.maxx = xe; c.miny = c.maxy = y;
+                    acc_commit(a + label, c);
                 }
             }
-            if (!done) {   // crowded block (noise): straight to global memory
-                contrib c;
-                c.area = len; c.sx = sx; c.sy = sy; c.minx = xs; c.maxx = xe; c.miny = c.maxy = y;
-                acc_commit(a + label, c);
-            }
+        }
+        __syncthreads();
+        if (threadIdx.x < ST_SLOTS && T.label[threadIdx.x]) {
+            const int i = threadIdx.x;
+            contrib c;
+            c.area = T.area[i]; c.sx = T.sx[i]; c.sy = T.sy[i]; c.minx = T.minx[i]; c.maxx = T.maxx[i]; c.miny = T.miny[i]; c.maxy = T.maxy[i];
+            acc_commit(a + T.label[i], c);
         }
     }
+    if (!stats && !cent) return;
+    // the block that finishes last turns the accumulators of its frame into stats rows (no extra launch)
+    __threadfence();
     __syncthreads();
-    if (threadIdx.x < ST_SLOTS && T.label[threadIdx.x]) {
-        const int i = threadIdx.x;
-        contrib c;
-        c.area = T.area[i]; c.sx = T.sx[i]; c.sy = T.sy[i]; c.minx = T.minx[i]; c.maxx = T.maxx[i]; c.miny = T.miny[i]; c.maxy = T.maxy[i];
-        acc_commit(a + T.label[i], c);
+    if (threadIdx.x == 0) s_last = (atomicAdd(done + f, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int nl = nlabels[f];
+    for (int l = threadIdx.x; l < max_labels; l += 256) {
+        const size_t o = (size_t)f * max_labels + l;
+        if (l < nl) {
+            ccl_acc v;
+            v.area = __hip_atomic_load(&a[l].area, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.minx = __hip_atomic_load(&a[l].minx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.miny = __hip_atomic_load(&a[l].miny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.maxx = __hip_atomic_load(&a[l].maxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.maxy = __hip_atomic_load(&a[l].maxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.sx = __hip_atomic_load(&a[l].sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.sy = __hip_atomic_load(&a[l].sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 0) {   // background: merge the per-slice records
+                contrib c;
+                contrib_zero(c);
+                for (int k = 0; k < BG_PARTS; k++) contrib_merge(c, bgpart[(size_t)f * BG_PARTS + k]);
+                v.area = c.area; v.minx = c.minx; v.maxx = c.maxx; v.miny = c.miny; v.maxy = c.maxy; v.sx = c.sx; v.sy = c.sy;
+            }
+            if (stats) {
+                int32_t* sr = stats + o * 5;
+                sr[0] = v.minx;
+                sr[1] = v.miny;
+                sr[2] = (int32_t)((u32)v.maxx - (u32)v.minx + 1u);
+                sr[3] = (int32_t)((u32)v.maxy - (u32)v.miny + 1u);
+                sr[4] = (int32_t)v.area;
+            }
+            if (cent) {
+                const double area = (double)v.area;
+                cent[o * 2] = (double)v.sx / area;
+                cent[o * 2 + 1] = (double)v.sy / area;
+            }
+        } else {
+            if (stats) { int32_t* sr = stats + o * 5; sr[0] = sr[1] = sr[2] = sr[3] = sr[4] = 0; }
+            if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
+        }
     }
 }
 
@@ -927,8 +1002,10 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
         hipLaunchKernelGGL(k_ccl_frame, dim3((unsigned)n), dim3(FR_THREADS), (size_t)max_labels * sizeof(fr_slot), s, d_bits, G, ws.parent, ws.flags,
                            ws.prefix, ws.seglabel, ws.wordlabel, d_nlabels, max_labels, d_stats, d_centroids, join);
     } else {
-        { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart); }
-        { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels); }
+        { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart, ws.done); }
+        // (k_ccl_stats can also write the stats rows from its last block per frame — measured 35x slower: a counter atomic and a
+        //  fence in each of ~10^6 mostly empty blocks — so the rows come from a separate small launch)
+        { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels, ws.done, (const contrib*)ws.bgpart, d_nlabels, (int32_t*)nullptr, (double*)nullptr); }
         if (d_stats || d_centroids) {
             vp_prof_scope ps(ctx, VPK_CCL_FINAL);
             hipLaunchKernelGGL(k_ccl_final, dim3((unsigned)((max_labels + 255) / 256), (unsigned)n), dim3(256), 0, s, (const ccl_acc*)ws.acc,

@@ -118,6 +118,7 @@ struct vp_ccl_ws {           // per-batch scratch, all device pointers
     void* acc;               // [n][max_labels] accumulators
     u32* wordlabel;          // [n][h*ww]      label of the first segment of each word
     void* bgpart;            // [n][8]         background partial records
+    u32* done;               // [n]            blocks of k_ccl_stats finished per frame
 };
 size_t vp_ccl_nids(int w, int h);   // multiple of 32
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels);
