@@ -27,27 +27,9 @@
 //   k_ccl_final    the same as a separate launch (the default: the in-kernel variant costs a fence + counter atomic per block)
 //   k_ccl_write    bits + wordlabel (+ seglabel for words holding several segments) -> int32 label image
 #include "vp_internal.h"
+#include "vp_ccl_dev.h"
 #include <limits.h>
 #include <cstdlib>
-
-struct ccl_geom {
-    int w, h, ww, wb, numbering;
-    u32 nids;   // multiple of 128
-    u32 nw32;   // nids / 32
-    int invert; // label the zero pixels instead (background regions, for hole borders)
-    int conn4;  // 4-connectivity (background of an 8-connected foreground)
-};
-
-// word j of a row as the labelling sees it
-__device__ __forceinline__ u64 ccl_word(const ccl_geom& G, const u64* __restrict__ fb, int idx, int j)
-{
-    u64 w = fb[idx];
-    if (G.invert) {
-        w = ~w;
-        if (j == G.ww - 1 && (G.w & 63)) w &= (1ull << (G.w & 63)) - 1ull;
-    }
-    return w;
-}
 
 struct ccl_acc {   // 48 B
     u32 area;
@@ -87,95 +69,6 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->done = (u32*)vp_ws_take(ctx, 4 * (size_t)n);
 }
 
-__device__ __forceinline__ u32 seg_id(const ccl_geom& G, int y, int x)
-{
-    if (G.numbering == VP_CCL_BLOCK2X2) return (((u32)(y >> 1) * (u32)G.wb + (u32)(x >> 1)) << 1) | (u32)(y & 1);
-    return (u32)y * (u32)G.wb + (u32)(x >> 1);
-}
-
-__device__ __forceinline__ u64 bit_range(int s, int e)  // bits s..e inclusive
-{
-    const int len = e - s + 1;
-    return (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s;
-}
-// start / end (inclusive) of the run of 1s of `w` that contains set bit b
-__device__ __forceinline__ int run_start(u64 w, int b)
-{
-    const u64 t = ~w & ((1ull << b) - 1ull);
-    return t ? 64 - __clzll(t) : 0;
-}
-__device__ __forceinline__ int run_end(u64 w, int b)
-{
-    const u64 t = ~(w >> b);  // bit 0 is clear
-    return t ? b + (__ffsll((long long)t) - 1) - 1 : 63;
-}
-__device__ __forceinline__ u32 nstarts(u64 w) { return (u32)__popcll(w & ~(w << 1)); }
-
-__device__ __forceinline__ u32 ld_rlx(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_rlx(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// find with path halving.  Parent ids strictly decrease towards the root, links are only ever
-// added at roots (CAS below), so a stale or half-compressed pointer still names an ancestor.
-__device__ __forceinline__ u32 uf_find_halve(u32* p, u32 x)
-{
-    for (;;) {
-        const u32 q = ld_rlx(p + x);
-        if (q == x) return x;
-        const u32 g = ld_rlx(p + q);
-        if (g == q) return q;
-        st_rlx(p + x, g);
-        x = g;
-    }
-}
-// links the larger root under the smaller; the absorbed root loses its bit in the root bitmap
-__device__ __forceinline__ void uf_unite(u32* p, u32* flags, u32 a, u32 b)
-{
-    for (;;) {
-        a = uf_find_halve(p, a);
-        b = uf_find_halve(p, b);
-        if (a == b) return;
-        if (a < b) { const u32 t = a; a = b; b = t; }
-        const u32 old = atomicCAS(p + a, a, b);
-        if (old == a) { atomicAnd(flags + (a >> 5), ~(1u << (a & 31))); return; }
-        a = old;
-    }
-}
-
-// Unions of the segments of word (y, j) in global memory.  horiz: with the segment ending the previous
-// word of the row; vert: with the 8-connected segments of row y-1.  A contact through the left/right
-// neighbour word of the row above is skipped when the word straight above already bridges it (that
-// row's own horizontal union connects them).
-__device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, const ccl_geom& G, u32* p, u32* flags, int y, int j,
-                                                 int idx, u64 w, bool horiz, bool vert)
-{
-    if (horiz && (w & 1ull) && j > 0) {
-        const u64 prev = ccl_word(G, fb, idx - 1, j - 1);
-        if (prev >> 63) uf_unite(p, flags, seg_id(G, y, 64 * j), seg_id(G, y, 64 * (j - 1) + run_start(prev, 63)));
-    }
-    if (!vert || y == 0) return;
-    const u64 um = ccl_word(G, fb, idx - G.ww, j);
-    const u64 ul = (j > 0 && !G.conn4) ? ccl_word(G, fb, idx - G.ww - 1, j - 1) : 0ull;
-    const u64 ur = (j + 1 < G.ww && !G.conn4) ? ccl_word(G, fb, idx - G.ww + 1, j + 1) : 0ull;
-    if (!(um | (ul >> 63) | (ur & 1ull))) return;
-    u64 rem = w;
-    while (rem) {
-        const int s = __ffsll((long long)rem) - 1;
-        const int e = run_end(rem, s);
-        const u64 S = bit_range(s, e);
-        rem &= ~S;
-        const u32 me = seg_id(G, y, 64 * j + s);
-        u64 c = um & (G.conn4 ? S : (S | (S << 1) | (S >> 1)));
-        while (c) {
-            const int b = __ffsll((long long)c) - 1;
-            const int st = run_start(um, b), en = run_end(um, b);
-            uf_unite(p, flags, me, seg_id(G, y - 1, 64 * j + st));
-            c &= ~bit_range(st, en);
-        }
-        if ((S & 1ull) && (ul >> 63) && !(um & 1ull)) uf_unite(p, flags, me, seg_id(G, y - 1, 64 * (j - 1) + run_start(ul, 63)));
-        if ((S >> 63) && (ur & 1ull) && !(um >> 63)) uf_unite(p, flags, me, seg_id(G, y - 1, 64 * (j + 1)));
-    }
-}
-
 // ---- whole-image global-memory path (fallback for images too wide for the LDS strip kernel) ---------------
 // grid: (ceil(h*ww/256), n); flags zeroed by a memset before k_ccl_init
 __global__ __launch_bounds__(256) void k_ccl_init(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent, u32* __restrict__ flags)
@@ -208,41 +101,8 @@ __global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, 
     global_link_word(fb, G, parent + (size_t)blockIdx.y * G.nids, flags + (size_t)blockIdx.y * G.nw32, y, j, idx, w, true, true);
 }
 
-// ---- strip-local union-find in LDS ------------------------------------------------------------------
-#define CL_ROWS 32
-#define CL_CAP 1024   // segments per strip handled in LDS; denser strips fall back to global memory
-
-__device__ __forceinline__ u32 lds_find(volatile u32* p, u32 x)
-{
-    for (;;) {
-        const u32 q = p[x];
-        if (q == x) return x;
-        const u32 g = p[q];
-        if (g == q) return q;
-        p[x] = g;
-        x = g;
-    }
-}
-__device__ __forceinline__ void lds_unite(u32* p, u32 a, u32 b)
-{
-    for (;;) {
-        a = lds_find(p, a);
-        b = lds_find(p, b);
-        if (a == b) return;
-        if (a < b) { const u32 t = a; a = b; b = t; }
-        const u32 old = atomicCAS(p + a, a, b);
-        if (old == a) return;
-        a = old;
-    }
-}
-
-// iterate the words of the strip with a division-free (row, column) mapping: 8 rows x 32 columns per pass
-#define CL_FOR_WORDS(r, j, i)                                   \
-    for (int r = threadIdx.x >> 5; r < nrows; r += 8)           \
-        for (int j = threadIdx.x & 31, i = r * ww + j; j < ww; j += 32, i += 32)
-
 // One block per (frame, strip of CL_ROWS rows).
-// dynamic LDS: lbits[nw] u64 | wbase[nw] u32 | lparent[CAP] | lgid[CAP] | lmin[CAP]
+// dynamic LDS: lbits[nw] u64 | wbase[nw + 2] u32 | lparent[CAP] | lgid[CAP] | lmin[CAP]
 __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
                                                    u32* __restrict__ flags, int strips)
 {
@@ -257,112 +117,11 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
     u64* lbits = cl_lds;
     u32* wbase = reinterpret_cast<u32*>(cl_lds + nwmax);
     u32* lparent = wbase + (nwmax + 2);
-    u32* lgid = lparent + CL_CAP;
-    u32* lmin = lgid + CL_CAP;
     const u64* fb = bits + (size_t)frame * G.h * ww;
-    u32* gp = parent + (size_t)frame * G.nids;
-    u32* gf = flags + (size_t)frame * G.nw32;
-    const int tid = threadIdx.x;
-
-    // this strip's slice of the root bitmap (ids of 32 rows = a multiple of 32 ids, so slices never share a word)
-    {
-        const u32 rows_ids = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;   // ids per row pair / per row
-        const u32 lo = (G.numbering == VP_CCL_BLOCK2X2) ? (u32)(y0 >> 1) * rows_ids : (u32)y0 * rows_ids;
-        const u32 w0 = lo >> 5;
-        const u32 w1 = (strip == strips - 1) ? G.nw32 : ((G.numbering == VP_CCL_BLOCK2X2) ? ((u32)((y0 + CL_ROWS) >> 1) * rows_ids) >> 5
-                                                                                         : ((u32)(y0 + CL_ROWS) * rows_ids) >> 5);
-        for (u32 i = w0 + tid; i < w1; i += 256) gf[i] = 0u;
-    }
-    u32 cnt = 0;
-    CL_FOR_WORDS(r, j, i) { const u64 w = ccl_word(G, fb, (y0 + r) * ww + j, j); lbits[i] = w; cnt += nstarts(w); }
-    // block exclusive scan of the per-thread segment counts
-    u32 inc = cnt;
-    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
+    CL_FOR_WORDS(r, j, i) lbits[i] = ccl_word(G, fb, (y0 + r) * ww + j, j);
     __syncthreads();
-    if (tid == 0) { u32 run = 0; for (int k = 0; k < 4; k++) { const u32 t = wsum[k]; wsum[k] = run; run += t; } total_s = run; }
-    __syncthreads();
-    const u32 S = total_s;
-    if (S == 0) return;
-    if (S > CL_CAP) {
-        // dense strip: same algorithm in global memory, restricted to this strip's rows
-        CL_FOR_WORDS(r, j, i) {
-            u64 st = lbits[i] & ~(lbits[i] << 1);
-            while (st) {
-                const int s = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                const u32 id = seg_id(G, y0 + r, 64 * j + s);
-                st_rlx(gp + id, id);
-                atomicOr(gf + (id >> 5), 1u << (id & 31));
-            }
-        }
-        __threadfence();
-        __syncthreads();
-        CL_FOR_WORDS(r, j, i) {
-            const u64 w = lbits[i];
-            if (w) global_link_word(fb, G, gp, gf, y0 + r, j, (y0 + r) * ww + j, w, true, r > 0);
-        }
-        return;
-    }
-    {
-        u32 run = wsum[wv] + inc - cnt;
-        CL_FOR_WORDS(r, j, i) {
-            const u64 w = lbits[i];
-            wbase[i] = run;
-            u64 st = w & ~(w << 1);
-            while (st) {
-                const int s = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                lparent[run] = run;
-                lgid[run] = seg_id(G, y0 + r, 64 * j + s);
-                lmin[run] = 0xffffffffu;
-                run++;
-            }
-        }
-    }
-    __syncthreads();
-    CL_FOR_WORDS(r, j, i) {
-        const u64 w = lbits[i];
-        if (!w) continue;
-        const u32 base = wbase[i];
-        if ((w & 1ull) && j > 0 && (lbits[i - 1] >> 63)) lds_unite(lparent, base, wbase[i - 1] + nstarts(lbits[i - 1]) - 1u);
-        if (r == 0) continue;
-        const u64 um = lbits[i - ww];
-        const u64 ul = (j > 0 && !G.conn4) ? lbits[i - ww - 1] : 0ull;
-        const u64 ur = (j + 1 < ww && !G.conn4) ? lbits[i - ww + 1] : 0ull;
-        if (!(um | (ul >> 63) | (ur & 1ull))) continue;
-        const u32 ubase = wbase[i - ww];
-        const u64 ustarts = um & ~(um << 1);
-        u64 rem = w;
-        u32 me = base;
-        while (rem) {
-            const int s = __ffsll((long long)rem) - 1;
-            const int e = run_end(rem, s);
-            const u64 Sg = bit_range(s, e);
-            rem &= ~Sg;
-            u64 c = um & (G.conn4 ? Sg : (Sg | (Sg << 1) | (Sg >> 1)));
-            while (c) {
-                const int b = __ffsll((long long)c) - 1;
-                const int st = run_start(um, b), en = run_end(um, b);
-                lds_unite(lparent, me, ubase + (u32)__popcll(ustarts & ((1ull << st) - 1ull)));
-                c &= ~bit_range(st, en);
-            }
-            if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) lds_unite(lparent, me, wbase[i - ww - 1] + nstarts(ul) - 1u);
-            if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) lds_unite(lparent, me, wbase[i - ww + 1]);
-            me++;
-        }
-    }
-    __syncthreads();
-    for (u32 ci = tid; ci < S; ci += 256) atomicMin(lmin + lds_find(lparent, ci), lgid[ci]);
-    __syncthreads();
-    for (u32 ci = tid; ci < S; ci += 256) {
-        const u32 id = lgid[ci];
-        const u32 m = lmin[lds_find(lparent, ci)];
-        gp[id] = m;
-        if (m == id) atomicOr(gf + (id >> 5), 1u << (id & 31));   // strip-local representative = root candidate
-    }
+    ccl_local_strip(G, lbits, wbase, lparent, lparent + CL_CAP, lparent + 2 * CL_CAP, wsum, &total_s, y0, nrows, strip, strips, fb,
+                    parent + (size_t)frame * G.nids, flags + (size_t)frame * G.nw32);
 }
 
 // vertical unions across strip boundaries: grid (strips - 1, n), block = 64 threads over the words of the row
@@ -958,7 +717,8 @@ static void ccl_make_geom(ccl_geom& G, int w, int h, int numbering, int invert, 
 
 // union-find phase only: parent[] (every segment points at a smaller id of its component, roots at themselves)
 // and the exact root bitmap in flags[]
-static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags, int* boundary_left = nullptr)
+static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags, int* boundary_left = nullptr,
+                     bool local_done = false)
 {
     if (boundary_left) *boundary_left = 0;
     const int h = G.h;
@@ -968,7 +728,7 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
     const size_t nwmax = (size_t)CL_ROWS * G.ww;
     const size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + (size_t)3 * CL_CAP * 4;
     if (lds_local <= 64 * 1024) {
-        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips); }
+        if (!local_done) { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips); }
         if (strips > 1) {
             if (boundary_left) *boundary_left = strips - 1;   // the caller joins the strips itself (k_ccl_frame)
             else { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags); }
@@ -983,7 +743,7 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
 }
 
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
-            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels)
+            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels, bool local_done)
 {
     if (numbering != VP_CCL_BLOCK2X2 && numbering != VP_CCL_PIXEL) return vp_fail(ctx, VP_ERR_INVALID, "numbering");
     if (max_labels < 1) return vp_fail(ctx, VP_ERR_INVALID, "max_labels");
@@ -995,7 +755,7 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
     static const bool want_fused = getenv("VP_CCL_FUSED") != nullptr;
     const bool fused = want_fused && max_labels <= FR_MAX_LABELS;
     int join = 0;
-    int rc = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags, fused ? &join : nullptr);
+    int rc = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags, fused ? &join : nullptr, local_done);
     if (rc != VP_OK) return rc;
     if (fused) {
         vp_prof_scope ps(ctx, VPK_CCL_RANK);

@@ -14,7 +14,9 @@
 // Everything else (grey-level images, ellipse/cross kernels, multi-channel) goes through the
 // generic kernel: brute-force min/max over the structuring element's offsets.
 #include "vp_internal.h"
+#include "vp_ccl_dev.h"
 #include <cstdlib>
+#include <cstring>
 
 #define MB_THREADS 256
 #define MB_STRIP 32
@@ -224,11 +226,18 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
 // Compile-time specialisation for the plans the modules actually use (square kernels, centre anchor): radii and
 // kinds are template constants, so the shift loops unroll into immediate funnel shifts and the vertical windows
 // into straight-line LDS reads.  KIND bit k = stage k dilates.
-template <int NS, int R0, int R1, int R2, int KIND>
+// FUSE: after its stores are issued the block also runs the strip-local labelling (vp_ccl_dev.h ccl_local_strip) on the
+// rows it still holds in LDS — same 32-row strips as k_ccl_local — so that kernel, its launch and its reload of the
+// bit image disappear and the union-find latency overlaps the mask stores.
+struct mb_fuse { ccl_geom G; u32* parent; u32* flags; };
+
+template <int NS, int R0, int R1, int R2, int KIND, bool FUSE>
 __global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __restrict__ in, int w, int h, int ww, int strips,
-                                                               u64* __restrict__ out_bits, uint8_t* __restrict__ out_mask)
+                                                               u64* __restrict__ out_bits, uint8_t* __restrict__ out_mask, mb_fuse Fz)
 {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    __shared__ u32 f_wsum[4];
+    __shared__ u32 f_total;
     constexpr int HALO = R0 + (NS > 1 ? R1 : 0) + (NS > 2 ? R2 : 0);
     constexpr int rows = MB_STRIP + 2 * HALO;
     u64* A = lds;
@@ -302,24 +311,45 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __rest
                 store_mask16(drow, g * 16, w, (u32)(arow[g >> 2] >> (16 * (g & 3))) & 0xffffu, vec_ok);
         }
     }
+    if constexpr (FUSE) {
+        // A's final rows stay untouched; B is dead and becomes the labelling scratch (plus the tail the host reserved)
+        static_assert(MB_STRIP == CL_ROWS, "strip decompositions must match");
+        __syncthreads();
+        u32* wbase = reinterpret_cast<u32*>(B);
+        u32* lparent = wbase + (MB_STRIP * ww + 2);
+        ccl_local_strip(Fz.G, A + (size_t)HALO * ww, wbase, lparent, lparent + CL_CAP, lparent + 2 * CL_CAP, f_wsum, &f_total, y0, nout_rows,
+                        strip, strips, out_bits + (size_t)frame * h * ww, Fz.parent + (size_t)frame * Fz.G.nids,
+                        Fz.flags + (size_t)frame * Fz.G.nw32);
+    }
 }
 
 template <int NS, int R0, int R1, int R2, int KIND>
-static int launch_sym(vp_ctx* ctx, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask)
+static int launch_sym(vp_ctx* ctx, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask, const mb_fuse* fuse)
 {
     constexpr int HALO = R0 + (NS > 1 ? R1 : 0) + (NS > 2 ? R2 : 0);
     const int ww = vp_ww(w), strips = (h + MB_STRIP - 1) / MB_STRIP;
-    const size_t lds = (size_t)2 * (MB_STRIP + 2 * HALO) * ww * sizeof(u64);
+    const size_t buf = (size_t)(MB_STRIP + 2 * HALO) * ww * sizeof(u64);
+    size_t lds = 2 * buf;
+    if (fuse) {   // labelling scratch lives in buffer B; extend the allocation when B is too small for it
+        const size_t need = ((size_t)MB_STRIP * ww + 2 + 3 * CL_CAP) * sizeof(u32);
+        if (need > buf) lds = buf + need;
+    }
     if (lds > 64 * 1024) return VP_ERR_UNSUPPORTED;
     vp_prof_scope prof(ctx, VPK_MORPH);
-    hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in, w, h,
-                       ww, strips, d_out_bits, d_out_mask);
+    mb_fuse z;
+    memset(&z, 0, sizeof z);
+    if (fuse)
+        hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND, true>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in,
+                           w, h, ww, strips, d_out_bits, d_out_mask, *fuse);
+    else
+        hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND, false>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in,
+                           w, h, ww, strips, d_out_bits, d_out_mask, z);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
 
 // returns VP_ERR_UNSUPPORTED when the plan is not one of the specialised shapes
-static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* ob, uint8_t* om)
+static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* ob, uint8_t* om, const mb_fuse* fuse)
 {
     if (plan.n < 1 || plan.n > 3) return VP_ERR_UNSUPPORTED;
     int rad[3] = {0, 0, 0}, kind = 0;
@@ -329,7 +359,7 @@ static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, 
         rad[i] = s.l;
         kind |= (s.dilate ? 1 : 0) << i;
     }
-#define SYM(NS, A, B, C, K) if (plan.n == NS && rad[0] == A && rad[1] == B && rad[2] == C && kind == K) return launch_sym<NS, A, B, C, K>(ctx, d_in, w, h, n, ob, om)
+#define SYM(NS, A, B, C, K) if (plan.n == NS && rad[0] == A && rad[1] == B && rad[2] == C && kind == K) return launch_sym<NS, A, B, C, K>(ctx, d_in, w, h, n, ob, om, fuse)
     SYM(3, 2, 4, 2, 2);   // OPEN 5x5 + CLOSE 5x5  (erode, dilate x2 merged, erode)      — modules/red_buoy.py:31-33
     SYM(3, 2, 4, 2, 5);   // CLOSE 5x5 + OPEN 5x5
     SYM(2, 2, 2, 0, 2);   // OPEN 5x5                                                   — modules/bins.py:23-24
@@ -460,6 +490,23 @@ static bool sweep_eligible(const vp_bitplan& plan, int w, ms_params* P, size_t* 
     return *lds <= 64 * 1024;
 }
 
+// Morphology + strip-local labelling of the result in one launch (chain with ccl == 1).  VP_ERR_UNSUPPORTED when the plan
+// is not a specialised one or the image is too wide: the caller then runs vpk_morph_bits and the normal labelling.
+int vpk_morph_bits_ccl(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask,
+                       int numbering, u32* d_parent, u32* d_flags)
+{
+    static const bool no_fuse = getenv("VP_NO_FUSE") != nullptr;
+    if (no_fuse || !d_out_bits) return VP_ERR_UNSUPPORTED;
+    mb_fuse fz;
+    fz.G.w = w; fz.G.h = h; fz.G.ww = vp_ww(w); fz.G.wb = (w + 1) / 2; fz.G.numbering = numbering;
+    fz.G.nids = (u32)vp_ccl_nids(w, h);
+    fz.G.nw32 = fz.G.nids / 32;
+    fz.G.invert = 0; fz.G.conn4 = 0;
+    fz.parent = d_parent;
+    fz.flags = d_flags;
+    return try_sym(ctx, plan, d_in, w, h, n, d_out_bits, d_out_mask, &fz);
+}
+
 int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits,
                    uint8_t* d_out_mask)
 {
@@ -483,7 +530,7 @@ int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, 
     }
     {
         static const bool no_sym = getenv("VP_NO_SYM") != nullptr;
-        const int rc = no_sym ? VP_ERR_UNSUPPORTED : try_sym(ctx, plan, d_in, w, h, n, d_out_bits, d_out_mask);
+        const int rc = no_sym ? VP_ERR_UNSUPPORTED : try_sym(ctx, plan, d_in, w, h, n, d_out_bits, d_out_mask, nullptr);
         if (rc != VP_ERR_UNSUPPORTED) return rc;
     }
     mb_params P;
