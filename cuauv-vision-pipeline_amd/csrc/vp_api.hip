@@ -309,10 +309,8 @@ static void push_rect_stage(std::vector<vp_bitstage>& v, int dilate, const rect_
 // Runs a stage list over bit images, grouping stages into launches whose halo fits LDS.
 // bits_a holds the input; bits_b is scratch of equal size.  The final launch writes out_bits /
 // out_mask (either may be NULL).  With an empty list the input is forwarded.
-struct fuse_req { int numbering; u32* parent; u32* flags; bool done; };
-
 static int run_bit_stages(vp_ctx* ctx, const std::vector<vp_bitstage>& st, u64* bits_a, u64* bits_b, int w, int h, int n,
-                          u64* out_bits, uint8_t* out_mask, fuse_req* fuse = nullptr)
+                          u64* out_bits, uint8_t* out_mask)
 {
     const size_t words = (size_t)n * h * vp_ww(w);
     if (st.empty()) {
@@ -339,11 +337,6 @@ static int run_bit_stages(vp_ctx* ctx, const std::vector<vp_bitstage>& st, u64* 
         }
         const bool last = i == st.size();
         u64* dst_bits = last ? out_bits : other;
-        if (last && fuse && dst_bits) {   // morphology + strip-local labelling in one launch when the plan is a specialised one
-            const int frc = vpk_morph_bits_ccl(ctx, plan, cur, w, h, n, dst_bits, out_mask, fuse->numbering, fuse->parent, fuse->flags);
-            if (frc == VP_OK) { fuse->done = true; break; }
-            if (frc != VP_ERR_UNSUPPORTED) return frc;
-        }
         VP_TRY(vpk_morph_bits(ctx, plan, cur, w, h, n, dst_bits, last ? out_mask : nullptr));
         if (!last) { u64* t = cur; cur = other; other = t; }
     }
@@ -650,7 +643,7 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, 
     TAKE(d_nl, int32_t*, 4);
     vp_ccl_ws ws;
     vp_ccl_ws_carve(ctx, w, h, 1, max_labels, &ws);
-    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart || !ws.done) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
     VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
     VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
     VP_TRY(vpk_ccl(ctx, d_bits, w, h, 1, numbering, ws, labels ? d_labels : nullptr, d_stats, d_cent, max_labels, d_nl));
@@ -768,21 +761,20 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
     memset(&ws, 0, sizeof ws);
     if (d->ccl) {
         vp_ccl_ws_carve(ctx, w, h, n, d->max_labels, &ws);
-        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart || !ws.done) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
     }
-    fuse_req fuse = {d->numbering, ws.parent, ws.flags, false};
     if ((!st.empty() && (need_clean_bits || b->cleaned)) || (st.empty() && b->cleaned)) {
         if (st.empty()) {
             VP_TRY(vpk_unpack_bits(ctx, bits_t, w, h, n, b->cleaned));
         } else {
             // bits_t must survive when CCL labels the threshold mask; run_bit_stages only reads its input
-            VP_TRY(run_bit_stages(ctx, st, bits_t, bits_b, w, h, n, need_clean_bits ? bits_a : nullptr, b->cleaned, need_clean_bits ? &fuse : nullptr));
+            VP_TRY(run_bit_stages(ctx, st, bits_t, bits_b, w, h, n, need_clean_bits ? bits_a : nullptr, b->cleaned));
             if (need_clean_bits) ccl_bits = bits_a;
         }
     }
     if (d->ccl) {
         VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
-                       b->nlabels ? b->nlabels : d_nl, fuse.done));
+                       b->nlabels ? b->nlabels : d_nl));
     }
     return VP_OK;
 }

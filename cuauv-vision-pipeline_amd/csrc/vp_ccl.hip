@@ -23,8 +23,11 @@
 //                  of the same launch reduce the background row (label 0) without atomics
 //   k_ccl_stats    label = rank(root)+1 per segment -> seglabel[id], wordlabel[word]; per-block LDS aggregation,
 //                  then one set of global atomics per (block, label)
-//                  the last block of a frame (done counter) turns the accumulators into stats (i32 x5) + centroids (f64 x2)
-//   k_ccl_final    the same as a separate launch (the default: the in-kernel variant costs a fence + counter atomic per block)
+//   k_ccl_final    accumulators -> stats (i32 x5) + centroids (f64 x2)
+//
+// Measured and dropped (git history has them): one 1024-thread block per frame running boundary -> rank -> stats -> final
+// with block barriers (111 us vs 65 us for the separate launches, 64 x 1080p: per-thread serial chains); writing the
+// stats rows from the last block of k_ccl_stats (a counter atomic + fence per block: 35x slower); 2-4 internal streams.
 //   k_ccl_write    bits + wordlabel (+ seglabel for words holding several segments) -> int32 label image
 #include "vp_internal.h"
 #include "vp_ccl_dev.h"
@@ -53,7 +56,7 @@ size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
 {
     const size_t nids = vp_ccl_nids(w, h);
     return vp_align(nids * 4 * n) * 2 + vp_align(nids / 8 * n) * 2 + vp_align(sizeof(ccl_acc) * (size_t)max_labels * n) +
-           vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) + vp_align(4 * (size_t)n) + 2048;
+           vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) + 2048;
 }
 
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out)
@@ -66,7 +69,6 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->acc = vp_ws_take(ctx, sizeof(ccl_acc) * (size_t)max_labels * n);
     out->wordlabel = (u32*)vp_ws_take(ctx, (size_t)n * h * vp_ww(w) * 4);
     out->bgpart = vp_ws_take(ctx, sizeof(contrib) * BG_PARTS * (size_t)n);
-    out->done = (u32*)vp_ws_take(ctx, 4 * (size_t)n);
 }
 
 // ---- whole-image global-memory path (fallback for images too wide for the LDS strip kernel) ---------------
@@ -177,7 +179,7 @@ __device__ __forceinline__ void wave_combine(contrib& c)
 // blocks [RK_PARTS, RK_PARTS + BG_PARTS): background pixels of a slice of the frame reduced to one record.
 __global__ __launch_bounds__(256) void k_ccl_rank(ccl_geom G, const u32* __restrict__ flags, u32* __restrict__ prefix,
                                                   int32_t* __restrict__ nlabels, ccl_acc* __restrict__ acc, int max_labels,
-                                                  const u64* __restrict__ bits, contrib* __restrict__ bgpart, u32* __restrict__ done)
+                                                  const u64* __restrict__ bits, contrib* __restrict__ bgpart)
 {
     __shared__ u32 wsum[4];
     __shared__ u32 wsum2[4];
@@ -278,7 +280,6 @@ __global__ __launch_bounds__(256) void k_ccl_rank(ccl_geom G, const u32* __restr
         __syncthreads();
         const int nl = (int)bcast + 1;
         if (tid == 0 && nlabels) nlabels[f] = nl;
-        if (tid == 0 && done) done[f] = 0;
         ccl_acc* a = acc + (size_t)f * max_labels;
         const int nz = min(nl, max_labels);
         for (int i = tid; i < nz; i += 256) {
@@ -315,12 +316,9 @@ struct st_table {
 __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent,
                                                    const u32* __restrict__ flags, const u32* __restrict__ prefix,
                                                    u32* __restrict__ seglabel, u32* __restrict__ wordlabel,
-                                                   ccl_acc* __restrict__ acc, int max_labels, u32* __restrict__ done,
-                                                   const contrib* __restrict__ bgpart, const int32_t* __restrict__ nlabels,
-                                                   int32_t* __restrict__ stats, double* __restrict__ cent)
+                                                   ccl_acc* __restrict__ acc, int max_labels)
 {
     __shared__ st_table T;
-    __shared__ u32 s_last;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < G.h * G.ww;
     const int f = blockIdx.y;
@@ -386,50 +384,6 @@ __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits,
             acc_commit(a + T.label[i], c);
         }
     }
-    if (!stats && !cent) return;
-    // the block that finishes last turns the accumulators of its frame into stats rows (no extra launch)
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(done + f, 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const int nl = nlabels[f];
-    for (int l = threadIdx.x; l < max_labels; l += 256) {
-        const size_t o = (size_t)f * max_labels + l;
-        if (l < nl) {
-            ccl_acc v;
-            v.area = __hip_atomic_load(&a[l].area, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.minx = __hip_atomic_load(&a[l].minx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.miny = __hip_atomic_load(&a[l].miny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.maxx = __hip_atomic_load(&a[l].maxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.maxy = __hip_atomic_load(&a[l].maxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.sx = __hip_atomic_load(&a[l].sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.sy = __hip_atomic_load(&a[l].sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (l == 0) {   // background: merge the per-slice records
-                contrib c;
-                contrib_zero(c);
-                for (int k = 0; k < BG_PARTS; k++) contrib_merge(c, bgpart[(size_t)f * BG_PARTS + k]);
-                v.area = c.area; v.minx = c.minx; v.maxx = c.maxx; v.miny = c.miny; v.maxy = c.maxy; v.sx = c.sx; v.sy = c.sy;
-            }
-            if (stats) {
-                int32_t* sr = stats + o * 5;
-                sr[0] = v.minx;
-                sr[1] = v.miny;
-                sr[2] = (int32_t)((u32)v.maxx - (u32)v.minx + 1u);
-                sr[3] = (int32_t)((u32)v.maxy - (u32)v.miny + 1u);
-                sr[4] = (int32_t)v.area;
-            }
-            if (cent) {
-                const double area = (double)v.area;
-                cent[o * 2] = (double)v.sx / area;
-                cent[o * 2 + 1] = (double)v.sy / area;
-            }
-        } else {
-            if (stats) { int32_t* sr = stats + o * 5; sr[0] = sr[1] = sr[2] = sr[3] = sr[4] = 0; }
-            if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
-        }
-    }
 }
 
 // grid: (ceil(max_labels/256), n)
@@ -465,162 +419,6 @@ __global__ __launch_bounds__(256) void k_ccl_final(const ccl_acc* __restrict__ a
     } else {
         if (stats) { int32_t* s = stats + o * 5; s[0] = s[1] = s[2] = s[3] = s[4] = 0; }
         if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
-    }
-}
-
-// ---- fused per-frame tail: boundary unions -> ranks -> background + per-label statistics -> stats rows ----------
-// Everything after the strip-local pass depends on data of ONE frame only, so one 1024-thread block per frame runs
-// the phases back to back with block barriers instead of four kernel launches, and keeps the per-label
-// accumulators in LDS (indexed by label; no global atomics).  dynamic LDS: fr_slot[max_labels].
-struct fr_slot { u32 area; int minx, maxx, miny, maxy; u32 pad; u64 sx, sy; };   // 40 B
-#define FR_THREADS 1024
-#define FR_MAX_LABELS 1536   // 60 KB of LDS; larger tables use the unfused kernels
-
-__global__ __launch_bounds__(FR_THREADS) void k_ccl_frame(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
-                                                          u32* __restrict__ flags, u32* __restrict__ prefix, u32* __restrict__ seglabel,
-                                                          u32* __restrict__ wordlabel, int32_t* __restrict__ nlabels, int max_labels,
-                                                          int32_t* __restrict__ stats, double* __restrict__ cent, int strips_to_join)
-{
-    extern __shared__ __attribute__((aligned(16))) u64 fr_lds[];
-    fr_slot* T = reinterpret_cast<fr_slot*>(fr_lds);
-    __shared__ u32 wsum[16];
-    __shared__ contrib bgp[16];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ww = G.ww, nwords = G.h * G.ww;
-    const u64* fb = bits + (size_t)f * nwords;
-    u32* p = parent + (size_t)f * G.nids;
-    u32* fl = flags + (size_t)f * G.nw32;
-    u32* pf = prefix + (size_t)f * G.nw32;
-    u32* sl = seglabel + (size_t)f * G.nids;
-    u32* wl = wordlabel + (size_t)f * nwords;
-
-    // phase 1: unions across strip boundaries
-    for (int idx = tid; idx < strips_to_join * ww; idx += FR_THREADS) {
-        const int sb = idx / ww, j = idx - sb * ww;
-        const int y = (sb + 1) * CL_ROWS;
-        const int wi = y * ww + j;
-        const u64 w = ccl_word(G, fb, wi, j);
-        if (w) global_link_word(fb, G, p, fl, y, j, wi, w, false, true);
-    }
-    __syncthreads();
-    __threadfence();          // the unions went through L2 atomics: drop stale L1 lines before the plain loads below
-    __syncthreads();
-
-    // phase 2: exclusive popcount prefix over the root bitmap
-    const u32 nq = G.nw32 / 4;
-    const u32 per = (nq + FR_THREADS - 1) / FR_THREADS;
-    const u32 lo = min((u32)tid * per, nq), hi = min(lo + per, nq);
-    const uint4* fl4 = reinterpret_cast<const uint4*>(fl);
-    uint4* pf4 = reinterpret_cast<uint4*>(pf);
-    u32 cnt = 0;
-    for (u32 q = lo; q < hi; q++) { const uint4 v = fl4[q]; cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
-    u32 inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    u32 woff = 0, total = 0;
-    for (int k = 0; k < 16; k++) { if (k < wv) woff += wsum[k]; total += wsum[k]; }
-    u32 run = woff + inc - cnt;
-    for (u32 q = lo; q < hi; q++) {
-        const uint4 v = fl4[q];
-        uint4 o;
-        o.x = run; run += __popc(v.x);
-        o.y = run; run += __popc(v.y);
-        o.z = run; run += __popc(v.z);
-        o.w = run; run += __popc(v.w);
-        pf4[q] = o;
-    }
-    const int nl = (int)total + 1;
-    const int nz = min(nl, max_labels);
-    for (int i = tid; i < nz; i += FR_THREADS) {
-        fr_slot z;
-        z.area = 0; z.minx = INT_MAX; z.miny = INT_MAX; z.maxx = INT_MIN; z.maxy = INT_MIN; z.pad = 0; z.sx = 0; z.sy = 0;
-        T[i] = z;
-    }
-    __syncthreads();
-
-    // phase 3: labels per segment, background record, per-label accumulation in LDS
-    contrib c0;
-    contrib_zero(c0);
-    const u64 lastmask = (G.w & 63) ? ((1ull << (G.w & 63)) - 1ull) : ~0ull;
-    const int qy = FR_THREADS / ww, qj = FR_THREADS - qy * ww;
-    int y = tid / ww, j = tid - y * ww;
-    for (int idx = tid; idx < nwords; idx += FR_THREADS) {
-        const u64 w = fb[idx];
-        u64 z = ~w;
-        if (j == ww - 1) z &= lastmask;
-        if (z) {
-            const u32 c = (u32)__popcll(z);
-            c0.area += c;
-            c0.sx += (u64)c * (u64)(64 * j) + sum_bitpos(z);
-            c0.sy += (u64)c * (u64)y;
-            c0.minx = min(c0.minx, 64 * j + (__ffsll((long long)z) - 1));
-            c0.maxx = max(c0.maxx, 64 * j + 63 - __clzll(z));
-            c0.miny = min(c0.miny, y);
-            c0.maxy = max(c0.maxy, y);
-        }
-        u64 rem = w;
-        bool first = true;
-        while (rem) {
-            const int s = __ffsll((long long)rem) - 1;
-            const int e = run_end(rem, s);
-            rem &= ~bit_range(s, e);
-            const u32 id = seg_id(G, y, 64 * j + s);
-            u32 r = id;
-            for (u32 q = p[r]; q != r; q = p[r]) r = q;
-            const u32 label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
-            sl[id] = label;
-            if (first) { wl[idx] = label; first = false; }
-            if (label < (u32)max_labels) {
-                const u32 len = (u32)(e - s + 1);
-                const int xs = 64 * j + s, xe = 64 * j + e;
-                fr_slot* t = T + label;
-                atomicAdd(&t->area, len);
-                atomicAdd((unsigned long long*)&t->sx, (unsigned long long)((u64)len * (u64)(xs + xe) / 2ull));
-                atomicAdd((unsigned long long*)&t->sy, (unsigned long long)((u64)len * (u64)y));
-                atomicMin(&t->minx, xs);
-                atomicMax(&t->maxx, xe);
-                atomicMin(&t->miny, y);
-                atomicMax(&t->maxy, y);
-            }
-        }
-        y += qy; j += qj;
-        if (j >= ww) { j -= ww; y++; }
-    }
-    wave_combine(c0);
-    if (lane == 0) bgp[wv] = c0;
-    __syncthreads();
-    if (tid == 0) {
-        for (int k = 1; k < 16; k++) contrib_merge(c0, bgp[k]);
-        fr_slot* t = T;   // label 0 = background
-        t->area = c0.area; t->minx = c0.minx; t->maxx = c0.maxx; t->miny = c0.miny; t->maxy = c0.maxy; t->sx = c0.sx; t->sy = c0.sy;
-        if (nlabels) nlabels[f] = nl;
-    }
-    __syncthreads();
-
-    // phase 4: stats rows [left, top, width, height, area] and centroids
-    for (int l = tid; l < max_labels; l += FR_THREADS) {
-        const size_t o = (size_t)f * max_labels + l;
-        if (l < nz) {
-            const fr_slot a = T[l];
-            if (stats) {
-                int32_t* sr = stats + o * 5;
-                sr[0] = a.minx;
-                sr[1] = a.miny;
-                sr[2] = (int32_t)((u32)a.maxx - (u32)a.minx + 1u);
-                sr[3] = (int32_t)((u32)a.maxy - (u32)a.miny + 1u);
-                sr[4] = (int32_t)a.area;
-            }
-            if (cent) {
-                const double area = (double)a.area;
-                cent[o * 2] = (double)a.sx / area;
-                cent[o * 2 + 1] = (double)a.sy / area;
-            }
-        } else {
-            if (stats) { int32_t* sr = stats + o * 5; sr[0] = sr[1] = sr[2] = sr[3] = sr[4] = 0; }
-            if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
-        }
     }
 }
 
@@ -717,10 +515,8 @@ static void ccl_make_geom(ccl_geom& G, int w, int h, int numbering, int invert, 
 
 // union-find phase only: parent[] (every segment points at a smaller id of its component, roots at themselves)
 // and the exact root bitmap in flags[]
-static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags, int* boundary_left = nullptr,
-                     bool local_done = false)
+static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags)
 {
-    if (boundary_left) *boundary_left = 0;
     const int h = G.h;
     const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
     hipStream_t s = ctx->stream;
@@ -728,11 +524,8 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
     const size_t nwmax = (size_t)CL_ROWS * G.ww;
     const size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + (size_t)3 * CL_CAP * 4;
     if (lds_local <= 64 * 1024) {
-        if (!local_done) { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips); }
-        if (strips > 1) {
-            if (boundary_left) *boundary_left = strips - 1;   // the caller joins the strips itself (k_ccl_frame)
-            else { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags); }
-        }
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips); }
+        if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags); }
     } else {
         { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)G.nw32 * 4 * n, s)); }
         { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_init, wgrid, dim3(256), 0, s, d_bits, G, parent, flags); }
@@ -743,7 +536,7 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
 }
 
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
-            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels, bool local_done)
+            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels)
 {
     if (numbering != VP_CCL_BLOCK2X2 && numbering != VP_CCL_PIXEL) return vp_fail(ctx, VP_ERR_INVALID, "numbering");
     if (max_labels < 1) return vp_fail(ctx, VP_ERR_INVALID, "max_labels");
@@ -751,26 +544,14 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
     ccl_make_geom(G, w, h, numbering, 0, 0);
     const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
     hipStream_t s = ctx->stream;
-    // the single-block-per-frame tail measured 111 us vs 65 us for the four launches (64 x 1080p): opt-in only
-    static const bool want_fused = getenv("VP_CCL_FUSED") != nullptr;
-    const bool fused = want_fused && max_labels <= FR_MAX_LABELS;
-    int join = 0;
-    int rc = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags, fused ? &join : nullptr, local_done);
+    int rc = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags);
     if (rc != VP_OK) return rc;
-    if (fused) {
-        vp_prof_scope ps(ctx, VPK_CCL_RANK);
-        hipLaunchKernelGGL(k_ccl_frame, dim3((unsigned)n), dim3(FR_THREADS), (size_t)max_labels * sizeof(fr_slot), s, d_bits, G, ws.parent, ws.flags,
-                           ws.prefix, ws.seglabel, ws.wordlabel, d_nlabels, max_labels, d_stats, d_centroids, join);
-    } else {
-        { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart, ws.done); }
-        // (k_ccl_stats can also write the stats rows from its last block per frame — measured 35x slower: a counter atomic and a
-        //  fence in each of ~10^6 mostly empty blocks — so the rows come from a separate small launch)
-        { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels, ws.done, (const contrib*)ws.bgpart, d_nlabels, (int32_t*)nullptr, (double*)nullptr); }
-        if (d_stats || d_centroids) {
-            vp_prof_scope ps(ctx, VPK_CCL_FINAL);
-            hipLaunchKernelGGL(k_ccl_final, dim3((unsigned)((max_labels + 255) / 256), (unsigned)n), dim3(256), 0, s, (const ccl_acc*)ws.acc,
-                               (const contrib*)ws.bgpart, d_nlabels, max_labels, d_stats, d_centroids);
-        }
+    { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart); }
+    { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels); }
+    if (d_stats || d_centroids) {
+        vp_prof_scope ps(ctx, VPK_CCL_FINAL);
+        hipLaunchKernelGGL(k_ccl_final, dim3((unsigned)((max_labels + 255) / 256), (unsigned)n), dim3(256), 0, s, (const ccl_acc*)ws.acc,
+                           (const contrib*)ws.bgpart, d_nlabels, max_labels, d_stats, d_centroids);
     }
     if (d_labels) {
         vp_prof_scope ps(ctx, VPK_CCL_WRITE);

@@ -113,7 +113,7 @@ __device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, con
 
 // ---- strip-local union-find in LDS ------------------------------------------------------------------
 #define CL_ROWS 32
-#define CL_CAP 1024   // segments per strip handled in LDS; denser strips fall back to global memory
+#define CL_CAP 512    // segments per strip handled in LDS; denser strips fall back to global memory
 
 __device__ __forceinline__ u32 lds_find(volatile u32* p, u32 x)
 {

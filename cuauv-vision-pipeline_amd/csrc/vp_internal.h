@@ -104,8 +104,6 @@ int vpk_unpack_bits(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, uint8_t
 // runs the stage plan on bit images; outputs (each nullable): bits, u8 mask
 int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits,
                    uint8_t* d_out_mask);
-int vpk_morph_bits_ccl(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask,
-                       int numbering, u32* d_parent, u32* d_flags);
 // generic u8 morphology, arbitrary structuring element, cn channels, one pass
 int vpk_morph_generic(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int h, int cn, const int16_t* d_offs,
                       int noffs, uint8_t* d_dst);
@@ -120,7 +118,6 @@ struct vp_ccl_ws {           // per-batch scratch, all device pointers
     void* acc;               // [n][max_labels] accumulators
     u32* wordlabel;          // [n][h*ww]      label of the first segment of each word
     void* bgpart;            // [n][8]         background partial records
-    u32* done;               // [n]            blocks of k_ccl_stats finished per frame
 };
 size_t vp_ccl_nids(int w, int h);   // multiple of 32
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels);
@@ -129,7 +126,7 @@ size_t vp_contours_ws_bytes(int w, int h, int n);
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info);
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
-            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels, bool local_done = false);
+            int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels);
 
 // 16-byte streaming store for write-once outputs (masks, labels).  VP_NT_STORES selects the nontemporal form.
 #ifndef VP_NT_STORES

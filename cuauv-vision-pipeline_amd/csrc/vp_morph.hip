@@ -13,8 +13,11 @@
 //
 // Everything else (grey-level images, ellipse/cross kernels, multi-channel) goes through the
 // generic kernel: brute-force min/max over the structuring element's offsets.
+//
+// Measured and dropped (git history has them): a row-sweep variant (lane = word column, rings in LDS, neighbours by
+// shuffle: 237 us vs 60 us for 64 x 1080p — one wave per SIMD running serial LDS/shuffle chains) and fusing the
+// strip-local labelling into this kernel (140.6 us vs 81.3 + 58.1 us: both parts are bound by per-block latency).
 #include "vp_internal.h"
-#include "vp_ccl_dev.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -226,18 +229,11 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
 // Compile-time specialisation for the plans the modules actually use (square kernels, centre anchor): radii and
 // kinds are template constants, so the shift loops unroll into immediate funnel shifts and the vertical windows
 // into straight-line LDS reads.  KIND bit k = stage k dilates.
-// FUSE: after its stores are issued the block also runs the strip-local labelling (vp_ccl_dev.h ccl_local_strip) on the
-// rows it still holds in LDS — same 32-row strips as k_ccl_local — so that kernel, its launch and its reload of the
-// bit image disappear and the union-find latency overlaps the mask stores.
-struct mb_fuse { ccl_geom G; u32* parent; u32* flags; };
-
-template <int NS, int R0, int R1, int R2, int KIND, bool FUSE>
+template <int NS, int R0, int R1, int R2, int KIND>
 __global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __restrict__ in, int w, int h, int ww, int strips,
-                                                               u64* __restrict__ out_bits, uint8_t* __restrict__ out_mask, mb_fuse Fz)
+                                                               u64* __restrict__ out_bits, uint8_t* __restrict__ out_mask)
 {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    __shared__ u32 f_wsum[4];
-    __shared__ u32 f_total;
     constexpr int HALO = R0 + (NS > 1 ? R1 : 0) + (NS > 2 ? R2 : 0);
     constexpr int rows = MB_STRIP + 2 * HALO;
     u64* A = lds;
@@ -311,45 +307,24 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __rest
                 store_mask16(drow, g * 16, w, (u32)(arow[g >> 2] >> (16 * (g & 3))) & 0xffffu, vec_ok);
         }
     }
-    if constexpr (FUSE) {
-        // A's final rows stay untouched; B is dead and becomes the labelling scratch (plus the tail the host reserved)
-        static_assert(MB_STRIP == CL_ROWS, "strip decompositions must match");
-        __syncthreads();
-        u32* wbase = reinterpret_cast<u32*>(B);
-        u32* lparent = wbase + (MB_STRIP * ww + 2);
-        ccl_local_strip(Fz.G, A + (size_t)HALO * ww, wbase, lparent, lparent + CL_CAP, lparent + 2 * CL_CAP, f_wsum, &f_total, y0, nout_rows,
-                        strip, strips, out_bits + (size_t)frame * h * ww, Fz.parent + (size_t)frame * Fz.G.nids,
-                        Fz.flags + (size_t)frame * Fz.G.nw32);
-    }
 }
 
 template <int NS, int R0, int R1, int R2, int KIND>
-static int launch_sym(vp_ctx* ctx, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask, const mb_fuse* fuse)
+static int launch_sym(vp_ctx* ctx, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask)
 {
     constexpr int HALO = R0 + (NS > 1 ? R1 : 0) + (NS > 2 ? R2 : 0);
     const int ww = vp_ww(w), strips = (h + MB_STRIP - 1) / MB_STRIP;
-    const size_t buf = (size_t)(MB_STRIP + 2 * HALO) * ww * sizeof(u64);
-    size_t lds = 2 * buf;
-    if (fuse) {   // labelling scratch lives in buffer B; extend the allocation when B is too small for it
-        const size_t need = ((size_t)MB_STRIP * ww + 2 + 3 * CL_CAP) * sizeof(u32);
-        if (need > buf) lds = buf + need;
-    }
+    const size_t lds = (size_t)2 * (MB_STRIP + 2 * HALO) * ww * sizeof(u64);
     if (lds > 64 * 1024) return VP_ERR_UNSUPPORTED;
     vp_prof_scope prof(ctx, VPK_MORPH);
-    mb_fuse z;
-    memset(&z, 0, sizeof z);
-    if (fuse)
-        hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND, true>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in,
-                           w, h, ww, strips, d_out_bits, d_out_mask, *fuse);
-    else
-        hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND, false>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in,
-                           w, h, ww, strips, d_out_bits, d_out_mask, z);
+    hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in, w, h,
+                       ww, strips, d_out_bits, d_out_mask);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
 
 // returns VP_ERR_UNSUPPORTED when the plan is not one of the specialised shapes
-static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* ob, uint8_t* om, const mb_fuse* fuse)
+static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* ob, uint8_t* om)
 {
     if (plan.n < 1 || plan.n > 3) return VP_ERR_UNSUPPORTED;
     int rad[3] = {0, 0, 0}, kind = 0;
@@ -359,7 +334,7 @@ static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, 
         rad[i] = s.l;
         kind |= (s.dilate ? 1 : 0) << i;
     }
-#define SYM(NS, A, B, C, K) if (plan.n == NS && rad[0] == A && rad[1] == B && rad[2] == C && kind == K) return launch_sym<NS, A, B, C, K>(ctx, d_in, w, h, n, ob, om, fuse)
+#define SYM(NS, A, B, C, K) if (plan.n == NS && rad[0] == A && rad[1] == B && rad[2] == C && kind == K) return launch_sym<NS, A, B, C, K>(ctx, d_in, w, h, n, ob, om)
     SYM(3, 2, 4, 2, 2);   // OPEN 5x5 + CLOSE 5x5  (erode, dilate x2 merged, erode)      — modules/red_buoy.py:31-33
     SYM(3, 2, 4, 2, 5);   // CLOSE 5x5 + OPEN 5x5
     SYM(2, 2, 2, 0, 2);   // OPEN 5x5                                                   — modules/bins.py:23-24
@@ -374,139 +349,6 @@ static int try_sym(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, 
     return VP_ERR_UNSUPPORTED;
 }
 
-// ---- bit-plane morphology, row sweep ------------------------------------------------------------------
-// One lane owns one word column (64 px) of a strip of MS_SR output rows and walks down the rows; a wave holds one
-// strip (ww <= 64) or two (ww <= 32).  Each stage keeps the last (up + down + 1) horizontally-filtered rows of its
-// column in an LDS ring private to the lane; the horizontal filter takes the neighbour columns' words by lane
-// shuffle.  Rows outside the image enter a ring as the stage's neutral value ("outside never wins"), so a window
-// never needs clamping.  No barriers, no index divisions; per row a lane issues ~150 VALU instructions for
-// OPEN+CLOSE 5x5 (erode r2, dilate r4, erode r2) including the 64-byte mask row it writes.
-#define MS_SR 32
-#define MS_MAXST 4
-struct ms_params {
-    int w, h, ww, nst, upw, strips, nunits, rows_in, halo_top;
-    int ring_base[MS_MAXST], ring_depth[MS_MAXST];
-    vp_bitstage st[MS_MAXST];
-};
-
-__global__ __launch_bounds__(64) void k_morph_sweep(const u64* __restrict__ in, ms_params P, u64* __restrict__ out_bits,
-                                                    uint8_t* __restrict__ out_mask)
-{
-    extern __shared__ __attribute__((aligned(16))) u64 ms_lds[];
-    const int lane = threadIdx.x;
-    const int lpu = 64 / P.upw;
-    const int uiw = lane / lpu, j = lane - uiw * lpu;
-    const int unit = blockIdx.x * P.upw + uiw;
-    const bool col = j < P.ww && unit < P.nunits;
-    const int uu = min(unit, P.nunits - 1);
-    const int frame = uu / P.strips, strip = uu - frame * P.strips;
-    const int y0 = strip * MS_SR, y1 = min(y0 + MS_SR, P.h);
-    const int ystart = y0 - P.halo_top;   // image row that reaches stage 0 at step 0
-    const u64* fin = in + (size_t)frame * P.h * P.ww;
-    const u64 lastmask = (P.w & 63) ? ((1ull << (P.w & 63)) - 1ull) : ~0ull;
-    const bool lastcol = j == P.ww - 1;
-    u64* inrows = ms_lds;                           // [rows_in][64]
-    u64* ring = ms_lds + (size_t)P.rows_in * 64;    // [sum of ring depths][64]
-    for (int r = 0; r < P.rows_in; r++) {           // all loads of the column issued back to back
-        const int y = ystart + r;
-        u64 v = 0;
-        if (col && y >= 0 && y < P.h) v = fin[(size_t)y * P.ww + j];
-        inrows[r * 64 + lane] = v;
-    }
-    int slot[MS_MAXST] = {0, 0, 0, 0};
-    uint8_t* mrow_base = out_mask ? out_mask + (size_t)frame * P.h * P.w : nullptr;
-    u64* brow_base = out_bits ? out_bits + (size_t)frame * P.h * P.ww : nullptr;
-    for (int t = 0; t < P.rows_in; t++) {
-        int yr = ystart + t;
-        u64 v = inrows[t * 64 + lane];
-        bool present = yr >= 0 && yr < P.h;
-#pragma unroll
-        for (int k = 0; k < MS_MAXST; k++) {
-            if (k < P.nst) {
-                const vp_bitstage st = P.st[k];
-                const u64 neutral = st.dilate ? 0ull : ~0ull;
-                u64 cur = v;
-                if (!st.dilate && lastcol) cur |= ~lastmask;   // out-of-image columns of the last word count as 1 for erosion
-                u64 left = __shfl_up(cur, 1), right = __shfl_down(cur, 1);
-                if (j == 0) left = neutral;
-                if (lastcol) right = neutral;
-                u64 acc = cur;
-                if (st.dilate) {
-                    for (int d = 1; d <= st.r; d++) acc |= fsr(right, cur, d);
-                    for (int d = 1; d <= st.l; d++) acc |= fsl(cur, left, d);
-                } else {
-                    for (int d = 1; d <= st.r; d++) acc &= fsr(right, cur, d);
-                    for (int d = 1; d <= st.l; d++) acc &= fsl(cur, left, d);
-                }
-                const u64 hres = present ? acc : neutral;
-                const int D = P.ring_depth[k];
-                u64* rk = ring + (size_t)P.ring_base[k] * 64 + lane;
-                rk[slot[k] * 64] = hres;
-                u64 o = hres;
-                int si = slot[k];
-                if (st.dilate) { for (int q = 1; q < D; q++) { si = si == 0 ? D - 1 : si - 1; o |= rk[si * 64]; } }
-                else { for (int q = 1; q < D; q++) { si = si == 0 ? D - 1 : si - 1; o &= rk[si * 64]; } }
-                slot[k] = slot[k] + 1 == D ? 0 : slot[k] + 1;
-                if (lastcol) o &= lastmask;
-                v = o;
-                yr -= st.d;
-                present = yr >= 0 && yr < P.h;
-            }
-        }
-        const bool wr = col && yr >= y0 && yr < y1;
-        if (brow_base && wr) brow_base[(size_t)yr * P.ww + j] = v;
-        if (mrow_base) {
-            const int yc = min(max(yr, 0), P.h - 1);
-            uint8_t* drow = mrow_base + (size_t)yc * P.w;
-            const bool vec_ok = (((uintptr_t)drow) & 15) == 0;
-#pragma unroll
-            for (int t4 = 0; t4 < 4; t4++) {
-                const int g = j + P.ww * t4;                       // 16-px group of the row handled by this lane
-                const u64 wv = __shfl(v, uiw * lpu + ((g >> 2) & (lpu - 1)));
-                if (wr) store_mask16(drow, g * 16, P.w, (u32)(wv >> (16 * (g & 3))) & 0xffffu, vec_ok);
-            }
-        }
-    }
-}
-
-static bool sweep_eligible(const vp_bitplan& plan, int w, ms_params* P, size_t* lds)
-{
-    const int ww = vp_ww(w);
-    if (plan.n < 1 || plan.n > MS_MAXST || ww > 64) return false;
-    int top = 0, bot = 0, slots = 0;
-    for (int i = 0; i < plan.n; i++) {
-        P->st[i] = plan.s[i];
-        P->ring_base[i] = slots;
-        P->ring_depth[i] = plan.s[i].u + plan.s[i].d + 1;
-        slots += P->ring_depth[i];
-        top += plan.s[i].u;
-        bot += plan.s[i].d;
-    }
-    for (int i = plan.n; i < MS_MAXST; i++) { P->ring_base[i] = 0; P->ring_depth[i] = 1; P->st[i] = plan.s[0]; }
-    P->nst = plan.n;
-    P->halo_top = top;
-    P->rows_in = MS_SR + top + bot;
-    *lds = (size_t)(P->rows_in + slots) * 64 * sizeof(u64);
-    return *lds <= 64 * 1024;
-}
-
-// Morphology + strip-local labelling of the result in one launch (chain with ccl == 1).  VP_ERR_UNSUPPORTED when the plan
-// is not a specialised one or the image is too wide: the caller then runs vpk_morph_bits and the normal labelling.
-int vpk_morph_bits_ccl(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits, uint8_t* d_out_mask,
-                       int numbering, u32* d_parent, u32* d_flags)
-{
-    static const bool no_fuse = getenv("VP_NO_FUSE") != nullptr;
-    if (no_fuse || !d_out_bits) return VP_ERR_UNSUPPORTED;
-    mb_fuse fz;
-    fz.G.w = w; fz.G.h = h; fz.G.ww = vp_ww(w); fz.G.wb = (w + 1) / 2; fz.G.numbering = numbering;
-    fz.G.nids = (u32)vp_ccl_nids(w, h);
-    fz.G.nw32 = fz.G.nids / 32;
-    fz.G.invert = 0; fz.G.conn4 = 0;
-    fz.parent = d_parent;
-    fz.flags = d_flags;
-    return try_sym(ctx, plan, d_in, w, h, n, d_out_bits, d_out_mask, &fz);
-}
-
 int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, int h, int n, u64* d_out_bits,
                    uint8_t* d_out_mask)
 {
@@ -514,23 +356,8 @@ int vpk_morph_bits(vp_ctx* ctx, const vp_bitplan& plan, const u64* d_in, int w, 
         if (plan.s[i].l > 31 || plan.s[i].r > 31 || plan.s[i].l < 0 || plan.s[i].r < 0 || plan.s[i].u < 0 || plan.s[i].d < 0)
             return vp_fail(ctx, VP_ERR_INVALID, "bit stage extent");
     {
-        ms_params S;
-        size_t lds = 0;
-        static const bool use_sweep = getenv("VP_SWEEP") != nullptr;   // measured slower than the multi-pass LDS kernel
-        if (use_sweep && sweep_eligible(plan, w, &S, &lds)) {
-            S.w = w; S.h = h; S.ww = vp_ww(w);
-            S.upw = S.ww <= 32 ? 2 : 1;
-            S.strips = (h + MS_SR - 1) / MS_SR;
-            S.nunits = n * S.strips;
-            vp_prof_scope prof(ctx, VPK_MORPH);
-            hipLaunchKernelGGL(k_morph_sweep, dim3((unsigned)((S.nunits + S.upw - 1) / S.upw)), dim3(64), lds, ctx->stream, d_in, S, d_out_bits, d_out_mask);
-            VP_HIP(ctx, hipGetLastError());
-            return VP_OK;
-        }
-    }
-    {
         static const bool no_sym = getenv("VP_NO_SYM") != nullptr;
-        const int rc = no_sym ? VP_ERR_UNSUPPORTED : try_sym(ctx, plan, d_in, w, h, n, d_out_bits, d_out_mask, nullptr);
+        const int rc = no_sym ? VP_ERR_UNSUPPORTED : try_sym(ctx, plan, d_in, w, h, n, d_out_bits, d_out_mask);
         if (rc != VP_ERR_UNSUPPORTED) return rc;
     }
     mb_params P;
