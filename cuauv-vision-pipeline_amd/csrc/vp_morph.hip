@@ -21,7 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#define MB_THREADS 256
+#define MB_THREADS 512
 #define MB_STRIP 32
 
 
@@ -135,7 +135,7 @@ struct mb_params {
 
 // iterate the staged words with a division-free (row, column) mapping: 8 rows x 32 columns per pass of the block
 #define MB_FOR_WORDS(r, j, i)                                   \
-    for (int r = threadIdx.x >> 5; r < rows; r += 8)            \
+    for (int r = threadIdx.x >> 5; r < rows; r += MB_THREADS / 32) \
         for (int j = threadIdx.x & 31, i = r * ww + j; j < ww; j += 32, i += 32)
 
 // dynamic LDS: two buffers of rows*ww u64
@@ -210,13 +210,13 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
     const int nout_rows = min(MB_STRIP, P.h - y0);
     if (out_bits) {
         u64* fo = out_bits + (size_t)frame * P.h * ww;
-        for (int r = threadIdx.x >> 5; r < nout_rows; r += 8)
+        for (int r = threadIdx.x >> 5; r < nout_rows; r += MB_THREADS / 32)
             for (int j = threadIdx.x & 31; j < ww; j += 32) fo[(size_t)(y0 + r) * ww + j] = A[(P.halo_top + r) * ww + j];
     }
     if (out_mask) {
         uint8_t* fm = out_mask + (size_t)frame * P.h * P.w;
         const int gpr = ww * 4;  // 16-px groups per row
-        for (int r = threadIdx.x >> 7; r < nout_rows; r += 2) {
+        for (int r = threadIdx.x >> 7; r < nout_rows; r += MB_THREADS / 128) {
             uint8_t* drow = fm + (size_t)(y0 + r) * P.w;
             const bool vec_ok = (((uintptr_t)drow) & 15) == 0;
             const u64* arow = A + (P.halo_top + r) * ww;
@@ -293,13 +293,13 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __rest
     const int nout_rows = min(MB_STRIP, h - y0);
     if (out_bits) {
         u64* fo = out_bits + (size_t)frame * h * ww;
-        for (int r = threadIdx.x >> 5; r < nout_rows; r += 8)
+        for (int r = threadIdx.x >> 5; r < nout_rows; r += MB_THREADS / 32)
             for (int j = threadIdx.x & 31; j < ww; j += 32) fo[(size_t)(y0 + r) * ww + j] = A[(HALO + r) * ww + j];
     }
     if (out_mask) {
         uint8_t* fm = out_mask + (size_t)frame * h * w;
         const int gpr = ww * 4;
-        for (int r = threadIdx.x >> 7; r < nout_rows; r += 2) {
+        for (int r = threadIdx.x >> 7; r < nout_rows; r += MB_THREADS / 128) {
             uint8_t* drow = fm + (size_t)(y0 + r) * w;
             const bool vec_ok = (((uintptr_t)drow) & 15) == 0;
             const u64* arow = A + (HALO + r) * ww;

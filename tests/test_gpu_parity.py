@@ -358,3 +358,76 @@ def test_percentile_and_auto_distance(vp, oracle):
     d2, sq = oracle.color_distance(split, (100, 150, 60), wn, 0)
     thr = min(np.percentile(d2.astype(np.float64), 20), 500.0 ** 2)
     assert np.array_equal(mask, oracle.inrange(d2, 0.0, float(np.float32(thr)))) and 0.18 < (mask > 0).mean() < 0.22
+
+
+def test_chain_streams_option_is_result_neutral(vp, oracle):
+    """VP_OPT_CHAIN_STREAMS splits a batch over internal streams (fork/join): identical results for 1..4."""
+    from vision.utils.chain import run_chain
+    frames = np.stack([F.s1_buoy(i, 256, 144) for i in range(13)])
+    morph = [(2, 5, 5), (3, 5, 5)]
+    ctx = vp.default_context()
+    ref = None
+    try:
+        for s in (1, 2, 3, 4):
+            ctx.set_option(vp.OPT_CHAIN_STREAMS, s)
+            out = run_chain(frames, 0, (0, 150, 0), (255, 255, 255), morph, max_labels=64)
+            if ref is None:
+                ref = out
+                th, cl, n, lab, st, ce = _oracle_chain(oracle, frames[12], 0, (0, 150, 0), (255, 255, 255), morph, 2)
+                assert np.array_equal(out["labels"][12], lab) and out["nlabels"][12] == n
+            else:
+                for k in ("threshed", "cleaned", "labels", "stats", "nlabels"):
+                    assert np.array_equal(out[k], ref[k]), (s, k)
+    finally:
+        ctx.set_option(vp.OPT_CHAIN_STREAMS, 1)
+    with pytest.raises(vp.VpError):
+        ctx.set_option(vp.OPT_CHAIN_STREAMS, 9)
+
+
+def test_very_wide_image(vp, oracle):
+    """8192 px wide = 128 words per row: beyond the 64-KB LDS budget of the specialised morphology kernels (runtime-plan
+    kernel with a larger LDS carve-out) and close to the strip-local labelling limit."""
+    from vision.utils import feature, transform as T
+    rng = np.random.default_rng(8)
+    m = F.random_mask(rng, 70, 8192, 0.7)
+    k = T.rect_kernel(5)
+    opened = T.morph_remove_noise(m, k)
+    assert np.array_equal(opened, oracle.morph(oracle.OPEN, m, k, fast=True))
+    n, lab, st, ce = feature.connected_components(opened, max_labels=20000)
+    on, olab, ost, oce = oracle.ccl(opened, 2)
+    assert n == on and np.array_equal(lab, olab) and np.array_equal(st, ost[:len(st)])
+    got = feature.find_contours(opened, 1, 2)
+    exp = oracle.find_contours(opened, 1, 2)
+    assert len(got) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got, exp))
+
+
+def test_c_abi_argument_checks(vp):
+    """Every entry point answers bad arguments with VP_ERR_INVALID (-1) and a message — never a crash or an exception."""
+    import ctypes as C
+    L, ctx = vp.lib(), vp.default_context()
+    img = np.zeros((4, 4, 3), np.uint8)
+    out = np.zeros((4, 4), np.uint8)
+    lo = np.zeros(3, np.int32)
+    assert L.vp_cvt_color_u8(ctx.handle, 99, vp.ptr(img), 12, 4, 4, vp.ptr(img), None) == -1
+    assert L.vp_cvt_color_u8(ctx.handle, 0, None, 12, 4, 4, vp.ptr(img), None) == -1
+    assert L.vp_cvt_color_u8(ctx.handle, 0, vp.ptr(img), 5, 4, 4, vp.ptr(img), None) == -1      # stride < row bytes
+    assert L.vp_inrange_u8(ctx.handle, vp.ptr(img), 12, 4, 4, 2, vp.ptr(lo), vp.ptr(lo), vp.ptr(out)) == -1
+    assert L.vp_morph_u8(ctx.handle, 7, vp.ptr(out), 4, 4, 1, None, 0, 0, -1, -1, 1, vp.ptr(out)) == -1
+    assert L.vp_morph_u8(ctx.handle, 0, vp.ptr(out), 4, 4, 1, vp.ptr(out), 3, 3, 5, 5, 1, vp.ptr(out)) == -1   # anchor outside the kernel
+    n = C.c_int32()
+    assert L.vp_ccl_u8(ctx.handle, vp.ptr(out), 4, 4, 4, 3, None, None, None, 8, C.byref(n)) == -1             # unknown numbering
+    assert L.vp_ccl_u8(ctx.handle, vp.ptr(out), 4, 4, 4, 2, None, None, None, 0, C.byref(n)) == -1             # max_labels < 1
+    desc = vp.make_chain_desc(0, 4, 0, (0, 0, 0), (255, 255, 255))
+    bufs = vp.ChainBuffers()
+    assert L.vp_chain_run(ctx.handle, C.byref(desc), C.byref(bufs), 1) == -1
+    desc = vp.make_chain_desc(4, 4, 0, (0, 0, 0), (255, 255, 255))
+    assert L.vp_chain_run(ctx.handle, C.byref(desc), C.byref(bufs), 1) == -1                                   # no input buffer
+    assert b"bgr" in L.vp_last_error(ctx.handle)
+    assert L.vp_chain_run(None, C.byref(desc), C.byref(bufs), 1) == -1
+    assert L.vp_set_option(ctx.handle, 77, 1) == -1
+    with pytest.raises(TypeError):
+        from vision.utils import color
+        color.bgr_to_lab(np.zeros((4, 4, 3), np.float64))
+    with pytest.raises(ValueError):
+        from vision.utils import color
+        color.bgr_to_lab(np.zeros((4, 4), np.uint8))
