@@ -186,7 +186,34 @@ def main():
                 "chain_frac": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS, 4)}
 
     cpu = None
+    real_cv2 = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:   # a real OpenCV (third-party, not reference code) gives the reference's own CPU path; never the facade of this repo
+            import cv2 as _cv2
+            if "vision" not in (getattr(_cv2, "__file__", "") or "") and hasattr(_cv2, "connectedComponentsWithStats"):
+                real_cv2 = _cv2
+        except Exception:
+            real_cv2 = None
+    if real_cv2 is not None:
+        cv2 = real_cv2
+        cv2.setNumThreads(1)
+        k5 = cv2.getStructuringElement(cv2.MORPH_RECT, (5, 5))
+        done, t_start = 0, time.perf_counter()
+        while True:
+            f = distinct[done % len(distinct)]
+            lab = cv2.cvtColor(f, cv2.COLOR_BGR2LAB)                      # modules/red_buoy.py:21 via utils/color.py:21-22
+            _, a, _ = cv2.split(lab)
+            th = cv2.inRange(a, 150, 255)                                 # utils/color.py:121
+            cl = cv2.morphologyEx(cv2.morphologyEx(th, cv2.MORPH_OPEN, k5), cv2.MORPH_CLOSE, k5)   # utils/transform.py:129,146
+            cv2.connectedComponentsWithStats(cl, connectivity=8, ltype=cv2.CV_32S)
+            done += 1
+            if time.perf_counter() - t_start >= args.cpu_seconds:
+                break
+        dt = time.perf_counter() - t_start
+        cpu = {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": f"{done} S1 1080p frames through cv2 {cv2.__version__} (cvtColor, split, inRange, morphologyEx x2, "
+                         f"connectedComponentsWithStats; setNumThreads(1), {dt:.1f} s); host has {os.cpu_count()} cores"}
+    elif rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         orc.lib()
         done, t_start = 0, time.perf_counter()

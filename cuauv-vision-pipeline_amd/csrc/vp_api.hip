@@ -199,6 +199,20 @@ int vp_dev_free(vp_ctx* ctx, void* p)
     VP_HIP(ctx, hipFree(p));
     return VP_OK;
 }
+int vp_host_alloc(vp_ctx* ctx, size_t bytes, void** p)
+{
+    if (!ctx || !p) return VP_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return vp_fail(ctx, VP_ERR_NOMEM, "hipHostMalloc", e);
+    return VP_OK;
+}
+int vp_host_free(vp_ctx* ctx, void* p)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipHostFree(p));
+    return VP_OK;
+}
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     if (!ctx) return VP_ERR_INVALID;

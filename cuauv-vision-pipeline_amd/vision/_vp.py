@@ -77,6 +77,8 @@ _SIGS = {
     "vp_chain_algorithmic_bytes": (C.c_uint64, [C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
     "vp_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vp_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vp_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vp_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vp_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
@@ -174,6 +176,20 @@ def default_context(device=0):
         ctx = Context(device)
         _ctxs[key] = ctx
     return ctx
+
+
+def pinned_empty(ctx, shape, dtype):
+    """numpy array over page-locked host memory (freed when the array is garbage collected)."""
+    import weakref
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    check(lib().vp_host_alloc(ctx.handle, max(nbytes, 1), C.byref(p)), ctx.handle)
+    buf = (C.c_ubyte * max(nbytes, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    handle, addr = ctx.handle, p.value
+    weakref.finalize(buf, lambda: lib().vp_host_free(handle, addr))
+    return arr
 
 
 def ptr(a):

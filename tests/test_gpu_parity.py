@@ -431,3 +431,21 @@ def test_c_abi_argument_checks(vp):
     with pytest.raises(ValueError):
         from vision.utils import color
         color.bgr_to_lab(np.zeros((4, 4), np.uint8))
+
+
+def test_chain_runner_pinned_staging(vp, oracle):
+    """Host-fed chain through page-locked staging buffers (vp_host_alloc): same results as the oracle, reusable across runs."""
+    from vision.utils.chain import ChainRunner
+    frames = np.stack([F.s1_buoy(i, 256, 144) for i in range(4)])
+    morph = [(2, 5, 5), (3, 5, 5)]
+    r = ChainRunner(4, 144, 256, 0, (0, 150, 0), (255, 255, 255), morph, max_labels=64, want=("cleaned", "labels", "stats"))
+    for rep in range(2):
+        r.input[:] = frames if rep == 0 else frames[::-1]
+        out = r.run()
+        src = frames if rep == 0 else frames[::-1]
+        for i in range(4):
+            th, cl, n, lab, st, ce = _oracle_chain(oracle, src[i], 0, (0, 150, 0), (255, 255, 255), morph, 2)
+            assert np.array_equal(out["cleaned"][i], cl) and out["nlabels"][i] == n
+            assert np.array_equal(out["labels"][i], lab) and np.array_equal(out["stats"][i][:n], st)
+            assert np.array_equal(out["centroids"][i][:n].view(np.uint64), ce.view(np.uint64))
+    assert "threshed" not in out
