@@ -27,7 +27,7 @@ def build_libvp(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     out = os.path.join(LIBDIR, "libvp.so")
     srcs = [os.path.join(CSRC, s) for s in VP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "vp_internal.h"), os.path.join(HERE, "..", "include", "vp.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("vp_")] + [os.path.join(HERE, "..", "include", "vp.h")]
     if not force and not _stale(out, deps):
         return out
     cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",

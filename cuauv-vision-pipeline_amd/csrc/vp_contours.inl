@@ -131,52 +131,77 @@ __global__ __launch_bounds__(1024) void k_ct_rank(const u64* __restrict__ startm
     if (tid == 0) out[f].n_contours = (int32_t)total;
 }
 
-struct ct_window { u64 c[3]; u32 l, r; int y, j; };   // rows y-1..y+1 of word column j, + edge bits of the neighbour columns
+// 8x8-pixel tile of the mask in one register: bit (8*r + c) = pixel (ty + r, tx + c); pixels outside the image are 0.
+// A trace step probes the 3x3 neighbourhood of the current pixel with shifts on this register and only goes back to memory
+// when the neighbourhood leaves the tile.
+struct ct_tile { u64 bits; int ty, tx; };
 
-__device__ __forceinline__ void ct_load(const ccl_geom& G, const u64* __restrict__ fb, int y, int j, ct_window& W)
+__device__ __forceinline__ void ct_tile_load(const ccl_geom& G, const u64* __restrict__ fb, int ty, int tx, ct_tile& T)
 {
-    W.y = y; W.j = j; W.l = 0; W.r = 0;
+    T.ty = ty; T.tx = tx;
+    const int j0 = tx >> 6;            // arithmetic shift: tx may be negative (floor)
+    const int sh = tx & 63;
+    // branch-free: clamped addresses, all 16 loads in flight together, out-of-image parts masked afterwards
+    const int ja = min(max(j0, 0), G.ww - 1), jb = min(max(j0 + 1, 0), G.ww - 1);
+    const u64 ma = (j0 >= 0 && j0 < G.ww) ? ~0ull : 0ull;
+    const u64 mb = (sh > 56 && j0 + 1 >= 0 && j0 + 1 < G.ww) ? ~0ull : 0ull;
+    u64 lo[8], hi[8];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int yy = y + k - 1;
-        u64 c = 0, l = 0, r = 0;
-        if (yy >= 0 && yy < G.h) {
-            const u64* row = fb + (size_t)yy * G.ww;
-            c = row[j];
-            if (j > 0) l = row[j - 1] >> 63;
-            if (j + 1 < G.ww) r = row[j + 1] & 1ull;
-        }
-        W.c[k] = c;
-        W.l |= (u32)l << k;
-        W.r |= (u32)r << k;
+    for (int r = 0; r < 8; r++) {
+        const int yc = min(max(ty + r, 0), G.h - 1);
+        const u64* row = fb + (size_t)yc * G.ww;
+        lo[r] = row[ja];
+        hi[r] = row[jb];
     }
+    u64 acc = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = ty + r;
+        const u64 my = (y >= 0 && y < G.h) ? ~0ull : 0ull;
+        u64 v = (lo[r] & ma) >> sh;
+        v |= sh ? ((hi[r] & mb) << (64 - sh)) : 0ull;
+        acc |= (v & my & 0xffull) << (8 * r);
+    }
+    T.bits = acc;
 }
-// pixel (W.y + dy, x + dx) with x in word column W.j
-__device__ __forceinline__ bool ct_probe(const ct_window& W, int x, int dy, int dx)
+__device__ __forceinline__ bool ct_tile_probe(const ct_tile& T, int y, int x)
 {
-    const int k = dy + 1, b = (x & 63) + dx;
-    if (b < 0) return (W.l >> k) & 1u;
-    if (b > 63) return (W.r >> k) & 1u;
-    return (W.c[k] >> b) & 1ull;
+    return (T.bits >> (8 * (y - T.ty) + (x - T.tx))) & 1ull;
+}
+// (re)place the tile around (y, x): the pixel sits one step from the trailing edge of the direction it is moving in, so a
+// straight run gets ~5 steps out of one load
+__device__ __forceinline__ void ct_tile_place(const ccl_geom& G, const u64* __restrict__ fb, int y, int x, int dy, int dx, ct_tile& T)
+{
+    const int oy = dy > 0 ? 1 : (dy < 0 ? 6 : 3);
+    const int ox = dx > 0 ? 1 : (dx < 0 ? 6 : 3);
+    ct_tile_load(G, fb, y - oy, x - ox, T);
+}
+__device__ __forceinline__ bool ct_tile_covers(const ct_tile& T, int y, int x)   // 3x3 neighbourhood inside the tile
+{
+    const unsigned ry = (unsigned)(y - T.ty - 1), rx = (unsigned)(x - T.tx - 1);
+    return ry <= 5u && rx <= 5u;
 }
 
 // Suzuki-Abe trace of one border (imgproc/src/contours.cpp icvFetchContour), counting or writing points.
 template <bool WRITE>
 __device__ int ct_trace(const ccl_geom& G, const u64* __restrict__ fb, int y0, int x0, bool is_hole, int method, int32_t* __restrict__ pts)
 {
-    const int dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dy8[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-    ct_window W;
-    ct_load(G, fb, y0, x0 >> 6, W);
+    // 8-neighbourhood deltas {E, NE, N, NW, W, SW, S, SE} packed 2 bits each (value + 1): a table indexed at run time would live
+    // in memory and cost a load per probe
+#define dx8(s) ((int)((0x901Au >> (2 * (s))) & 3u) - 1)
+#define dy8(s) ((int)((0xA901u >> (2 * (s))) & 3u) - 1)
+    ct_tile T;
+    ct_tile_place(G, fb, y0, x0, 0, 0, T);
     int s, s_end;
     s_end = s = is_hole ? 0 : 4;
     bool found;
-    do { s = (s - 1) & 7; found = ct_probe(W, x0, dy8[s], dx8[s]); } while (!found && s != s_end);
+    do { s = (s - 1) & 7; found = ct_tile_probe(T, y0 + dy8(s), x0 + dx8(s)); } while (!found && s != s_end);
     int n = 0;
     if (s == s_end) {
         if (WRITE) { pts[0] = x0; pts[1] = y0; }
         return 1;
     }
-    const int x1 = x0 + dx8[s], y1 = y0 + dy8[s];   // i1
+    const int x1 = x0 + dx8(s), y1 = y0 + dy8(s);   // i1
     int x3 = x0, y3 = y0, x4 = x0, y4 = y0;
     int prev_s = s ^ 4;
     // a border visits a pixel at most once per incoming direction: bound the walk so that a corrupted image cannot
@@ -186,9 +211,9 @@ __device__ int ct_trace(const ccl_geom& G, const u64* __restrict__ fb, int y0, i
         s_end = s;
         while (s < 15) {
             ++s;
-            x4 = x3 + dx8[s & 7];
-            y4 = y3 + dy8[s & 7];
-            if (ct_probe(W, x3, dy8[s & 7], dx8[s & 7])) break;
+            x4 = x3 + dx8(s & 7);
+            y4 = y3 + dy8(s & 7);
+            if (ct_tile_probe(T, y4, x4)) break;
         }
         s &= 7;
         if (s != prev_s || method == 1) {
@@ -198,10 +223,12 @@ __device__ int ct_trace(const ccl_geom& G, const u64* __restrict__ fb, int y0, i
         }
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
         x3 = x4; y3 = y4;
-        if (y3 != W.y || (x3 >> 6) != W.j) ct_load(G, fb, y3, x3 >> 6, W);
+        if (!ct_tile_covers(T, y3, x3)) ct_tile_place(G, fb, y3, x3, dy8(s), dx8(s), T);
         s = (s + 4) & 7;
     }
     return n;
+#undef dx8
+#undef dy8
 }
 
 // grid (ceil(h*ww/64), n), 64 threads: thread = one word of the start bitmap; a thread traces the borders starting in its word
