@@ -678,7 +678,7 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int 
     const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
     const int mc = max_contours > 0 ? max_contours : 1;
     const long long mp = max_points > 0 ? max_points : 1;
-    VP_TRY(vp_ws_reserve(ctx, vp_align(npx) + vp_align(bitbytes) + vp_contours_ws_bytes(w, h, 1) + 4 * vp_align((size_t)mc * 4) + vp_align((size_t)mc) +
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx) + vp_align(bitbytes) + vp_contours_ws_bytes(w, h, 1, mc) + 2 * vp_align((size_t)mc * 4) + vp_align((size_t)mc) +
                                   vp_align((size_t)mp * 8) + 8192));
     TAKE(d_src, uint8_t*, npx);
     TAKE(d_bits, u64*, bitbytes);

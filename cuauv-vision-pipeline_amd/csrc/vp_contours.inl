@@ -10,8 +10,7 @@
 //   * order: by start pixel, raster order, newest (= last) first;
 //   * each border is the Suzuki-Abe trace from its start pixel, which depends on the binary image only.
 // So: two union-find passes (foreground 8-conn, background 4-conn, both with first-pixel ids = VP_CCL_PIXEL), a
-// bitmap of start pixels + popcount prefix for the order, and one wave per border for the sequential trace
-// (counting pass, exclusive scan of the counts, writing pass).
+// bitmap of start pixels + popcount prefix for the order, and segment-parallel border following (below).
 //
 // Known divergence (documented in DESIGN.md): OpenCV's RETR_EXTERNAL decides "inside a hole" from the sign of the
 // last mark left of the start pixel, which differs from the topological rule when a one-pixel-thick wall pixel was
@@ -64,18 +63,22 @@ __device__ __forceinline__ void ct_root_pixel(const ccl_geom& G, const u64* __re
     x = ((w >> ((2 * x2) & 63)) & 1ull) ? 2 * x2 : 2 * x2 + 1;
 }
 
-// seeds: start-pixel bitmap (same layout as a bit image) + hole bitmap.
+// seeds: bitmaps in the layout of a bit image.  startmap = start pixel of every border of the image (every cycle of the
+// border-following map gets exactly one), holemap = it is a hole border, selmap = the retrieval mode returns it.
 // grid (ceil(nw32/256), n): thread = one 32-bit word of the root bitmaps.
 __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, ccl_geom Gf, ccl_geom Gb, const u32* __restrict__ fg_flags,
                                                   const u32* __restrict__ bg_flags, const u32* __restrict__ bg_parent,
-                                                  const u32* __restrict__ outside, int mode, u64* __restrict__ startmap, u64* __restrict__ holemap)
+                                                  const u32* __restrict__ outside, int mode, u64* __restrict__ startmap, u64* __restrict__ holemap,
+                                                  u64* __restrict__ selmap)
 {
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (t >= Gf.nw32) return;
     const int f = blockIdx.y;
-    const u64* fb = bits + (size_t)f * Gf.h * Gf.ww;
-    u64* sm = startmap + (size_t)f * Gf.h * Gf.ww;
-    u64* hm = holemap + (size_t)f * Gf.h * Gf.ww;
+    const size_t fo = (size_t)f * Gf.h * Gf.ww;
+    const u64* fb = bits + fo;
+    u64* sm = startmap + fo;
+    u64* hm = holemap + fo;
+    u64* sel = selmap + fo;
     const u32* bp = bg_parent + (size_t)f * Gb.nids;
     const u32* out = outside + (size_t)f * Gb.nw32;
     u32 m = fg_flags[(size_t)f * Gf.nw32 + t];
@@ -92,36 +95,107 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
             for (u32 q = bp[r]; q != r; q = bp[r]) r = q;
             keep = (out[r >> 5] >> (r & 31)) & 1u;
         }
-        if (keep) atomicOr((unsigned long long*)&sm[y * Gf.ww + (x >> 6)], 1ull << (x & 63));
+        const size_t wi = (size_t)y * Gf.ww + (x >> 6);
+        atomicOr((unsigned long long*)&sm[wi], 1ull << (x & 63));
+        if (keep) atomicOr((unsigned long long*)&sel[wi], 1ull << (x & 63));
     }
-    if (mode == 1) {   // RETR_LIST: hole borders
-        u32 hb = bg_flags[(size_t)f * Gb.nw32 + t] & ~out[t];
-        while (hb) {
-            const int b = __ffs((int)hb) - 1;
-            hb &= hb - 1;
-            int y, x;
-            ct_root_pixel(Gb, fb, t * 32 + b, y, x);
-            const int xs = x - 1;   // a hole never touches column 0
-            atomicOr((unsigned long long*)&sm[y * Gf.ww + (xs >> 6)], 1ull << (xs & 63));
-            atomicOr((unsigned long long*)&hm[y * Gf.ww + (xs >> 6)], 1ull << (xs & 63));
-        }
+    u32 hb = bg_flags[(size_t)f * Gb.nw32 + t] & ~out[t];   // hole borders: background regions that do not reach the frame
+    while (hb) {
+        const int b = __ffs((int)hb) - 1;
+        hb &= hb - 1;
+        int y, x;
+        ct_root_pixel(Gb, fb, t * 32 + b, y, x);
+        const int xs = x - 1;   // a hole never touches column 0
+        const size_t wi = (size_t)y * Gf.ww + (xs >> 6);
+        atomicOr((unsigned long long*)&sm[wi], 1ull << (xs & 63));
+        atomicOr((unsigned long long*)&hm[wi], 1ull << (xs & 63));
+        if (mode == 1) atomicOr((unsigned long long*)&sel[wi], 1ull << (xs & 63));
     }
 }
 
-// per frame: popcount prefix over the start bitmap -> list of border starts in raster order
-// starts[f][rank] = pixel index (y*w + x) | hole << 31      (one block per frame; the bitmap is small)
-__global__ __launch_bounds__(1024) void k_ct_rank(const u64* __restrict__ startmap, const u64* __restrict__ holemap, int nwords, int ww, int w,
-                                                  u32* __restrict__ starts, int max_contours, ct_frame_out* __restrict__ out)
+// ---- segment-parallel border following --------------------------------------------------------------------------------
+// A border is a cycle of states (pixel, s) of the Suzuki-Abe follower, s = direction of the pixel it came from; the next state
+// depends on the 3x3 neighbourhood only: s' = first foreground neighbour counter-clockwise after s, move there, s = s' + 4.
+// Between s and s' the follower sweeps over background neighbours.  Every crack (edge between a foreground pixel and a
+// 4-adjacent background pixel) is swept by exactly one state of exactly one border, and that state can be written down from
+// the crack alone: s = first foreground neighbour clockwise from the crack's direction.  So the states that sweep a W or E
+// crack (and, to cut long flat edges, an N or S crack at x % 8 == 0) are enumerable with bit operations - the "heads" - and
+// they cut every border into short segments that are followed independently, one thread each:
+//   k_ct_headmaps   4 head bitmaps per word (a state that sweeps several eligible cracks belongs to the first one swept)
+//   k_ct_prefix     popcount prefix -> dense head index; same kernel ranks the selected start pixels (cv2's contour order)
+//   k_ct_headfill   head list (pixel, type), terminal marks cleared
+//   k_ct_starts     start pixel of every border -> its start state -> the head that owns it = the terminal of that cycle
+//   k_ct_seg<false> follow each segment to the next head: node[k] = (next head, points emitted)
+//   k_ct_jump       pointer jumping on (next, distance) pairs until every head points at its terminal
+//   k_ct_offsets    per contour: length = distance of the terminal around its cycle; exclusive scan
+//   k_ct_seg<true>  follow each segment again, writing its points at offset[contour] + (length - distance to terminal)
+// OpenCV's start rule (icvFetchContour: first neighbour clockwise from W for an outer border, from E for a hole border) is
+// the head rule for the W / E crack of the start pixel, and its CHAIN_APPROX_SIMPLE filter (keep a point when the direction
+// changes) is local to a state: s' != s ^ 4.
+#define CT_TERM 0x80000000u
+#define CT_NONE 0xffffffffu
+#define CT_UNSEL 0xfffffffeu
+#define CT_EL_NS 0x0101010101010101ull   // N / S cracks are heads only in columns x % 8 == 0
+#define CT_JUMP_ROUNDS 40
+
+struct ct_aux { u32 nheads; u32 nsel; };
+
+__host__ __device__ inline size_t ct_hcap(int w, int h) { const size_t npx = (size_t)w * h; return (npx + npx / 4 + 64 + 63) / 64 * 64; }
+
+// neighbour bitmaps of word (y, j): bit b of f[d] = neighbour of pixel (y, 64j + b) in direction d of {E, NE, N, NW, W, SW, S, SE}
+__device__ __forceinline__ void ct_neighbours(const ccl_geom& G, const u64* __restrict__ fb, int y, int j, u64& c, u64 f[8])
+{
+    const bool up = y > 0, dn = y + 1 < G.h, lf = j > 0, rt = j + 1 < G.ww;
+    const u64* row = fb + (size_t)y * G.ww + j;
+    const u64 cm = row[0];
+    const u64 cl = lf ? row[-1] : 0ull, cr = rt ? row[1] : 0ull;
+    const u64 um = up ? row[-G.ww] : 0ull, ul = (up && lf) ? row[-G.ww - 1] : 0ull, ur = (up && rt) ? row[-G.ww + 1] : 0ull;
+    const u64 dm = dn ? row[G.ww] : 0ull, dl = (dn && lf) ? row[G.ww - 1] : 0ull, dr = (dn && rt) ? row[G.ww + 1] : 0ull;
+    c = cm;
+    f[0] = (cm >> 1) | (cr << 63);
+    f[4] = (cm << 1) | (cl >> 63);
+    f[2] = um; f[1] = (um >> 1) | (ur << 63); f[3] = (um << 1) | (ul >> 63);
+    f[6] = dm; f[7] = (dm >> 1) | (dr << 63); f[5] = (dm << 1) | (dl >> 63);
+}
+
+// head bitmaps, 4 per word: [W, E, N, S].  A crack's state owns the head unless, going clockwise from the crack towards the
+// state's s, another eligible crack comes first (that one is swept earlier).
+__global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps)
+{
+    const int nwords = G.h * G.ww;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nwords) return;
+    const int f = blockIdx.y;
+    const u64* fb = bits + (size_t)f * nwords;
+    const int y = idx / G.ww, j = idx - y * G.ww;
+    u64 c, n[8];
+    ct_neighbours(G, fb, y, j, c, n);
+    const u64 el = CT_EL_NS;
+    u64 hw = 0, he = 0, hn = 0, hs = 0;
+    if (c) {
+        hw = c & ~n[4] & (n[3] | n[2] | (~el & (n[1] | n[0])));
+        he = c & ~n[0] & (n[7] | n[6] | (~el & (n[5] | n[4])));
+        hn = c & ~n[2] & el & (n[1] | n[0]);
+        hs = c & ~n[6] & el & (n[5] | n[4]);
+    }
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(hmaps + ((size_t)f * nwords + idx) * 4);
+    o[0] = make_ulonglong2(hw, he);
+    o[1] = make_ulonglong2(hn, hs);
+}
+
+// per frame: exclusive prefix of the popcounts of `nm` bitmaps per word -> base[word], total -> *total (stride tstride u32)
+__global__ __launch_bounds__(1024) void k_ct_prefix(const u64* __restrict__ maps, int nm, int nwords, u32* __restrict__ base, u32* __restrict__ total_out,
+                                                    int tstride)
 {
     __shared__ u32 wsum[16];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u64* sm = startmap + (size_t)f * nwords;
-    const u64* hm = holemap + (size_t)f * nwords;
-    u32* st = starts + (size_t)f * max_contours;
+    const u64* m = maps + (size_t)f * nwords * nm;
+    u32* bs = base + (size_t)f * nwords;
     const int per = (nwords + 1023) / 1024;
     const int lo = min(tid * per, nwords), hi = min(lo + per, nwords);
     u32 cnt = 0;
-    for (int i = lo; i < hi; i++) cnt += (u32)__popcll(sm[i]);
+    for (int i = lo; i < hi; i++)
+        for (int t = 0; t < nm; t++) cnt += (u32)__popcll(m[(size_t)i * nm + t]);
     u32 inc = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
@@ -130,87 +204,89 @@ __global__ __launch_bounds__(1024) void k_ct_rank(const u64* __restrict__ startm
     u32 woff = 0, total = 0;
     for (int k = 0; k < 16; k++) { if (k < wv) woff += wsum[k]; total += wsum[k]; }
     u32 run = woff + inc - cnt;
-    if (cnt) {
-        for (int i = lo; i < hi; i++) {
-            u64 m = sm[i];
-            if (!m) continue;
-            const u64 hb = hm[i];
-            const int y = i / ww, j = i - y * ww;
-            while (m) {
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (run < (u32)max_contours) st[run] = (u32)(y * w + 64 * j + b) | (((hb >> b) & 1ull) ? 0x80000000u : 0u);
-                run++;
-            }
-        }
+    for (int i = lo; i < hi; i++) {
+        bs[i] = run;
+        for (int t = 0; t < nm; t++) run += (u32)__popcll(m[(size_t)i * nm + t]);
     }
-    if (tid == 0) out[f].n_contours = (int32_t)total;
+    if (tid == 0) total_out[(size_t)f * tstride] = total;
 }
 
-// ---- sequential trace of one border by one wave ----------------------------------------------------------------------
-// All 64 lanes run the same trace (uniform control flow); lane 0 writes.  What the other lanes buy is the window: a
-// CTW_ROWS x 64*CTW_WORDS pixel piece of the mask around the current pixel, loaded by the whole wave in one round trip to
-// memory and kept in LDS, so that a trace step never waits on HBM/L2 - only every >= 64 steps, when the border leaves
-// the window.  Inside the window the 3x3 neighbourhoods come from an 8x8 tile held in one register.
-#define CTW_ROWS 128
-#define CTW_WORDS 4
-
-struct ct_win { int y0, j0; };   // origin: row y0, word column j0 (either may lie outside the image: zero-filled)
-
-__device__ __forceinline__ void ct_win_load(const ccl_geom& G, const u64* __restrict__ fb, int y, int x, ct_win& W, u64* lds)
+// dense index of head (word idx, bit b, type t)
+__device__ __forceinline__ u32 ct_head_index(const u64* __restrict__ hm, const u32* __restrict__ hbase, int idx, int b, int t)
 {
-    W.y0 = y - CTW_ROWS / 2;
-    W.j0 = (x - 96) >> 6;          // x - 64*j0 in [96, 160): at least 96 pixels either side
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < CTW_ROWS / 64; k++) {
-        const int r = (int)threadIdx.x + 64 * k, yy = W.y0 + r;
-        const bool yin = yy >= 0 && yy < G.h;
-        const u64* row = fb + (size_t)min(max(yy, 0), G.h - 1) * G.ww;
-        u64 v[CTW_WORDS];
-#pragma unroll
-        for (int c = 0; c < CTW_WORDS; c++) v[c] = row[min(max(W.j0 + c, 0), G.ww - 1)];
-#pragma unroll
-        for (int c = 0; c < CTW_WORDS; c++) {
-            const int j = W.j0 + c;
-            lds[r * CTW_WORDS + c] = (yin && j >= 0 && j < G.ww) ? v[c] : 0ull;
-        }
-    }
-    __syncthreads();
+    const ulonglong2 m01 = reinterpret_cast<const ulonglong2*>(hm + (size_t)idx * 4)[0];
+    const ulonglong2 m23 = reinterpret_cast<const ulonglong2*>(hm + (size_t)idx * 4)[1];
+    const u64 low = (1ull << b) - 1ull;
+    u32 k = hbase[idx];
+    const u64 mt = t == 0 ? m01.x : (t == 1 ? m01.y : (t == 2 ? m23.x : m23.y));
+    if (t > 0) k += (u32)__popcll(m01.x);
+    if (t > 1) k += (u32)__popcll(m01.y);
+    if (t > 2) k += (u32)__popcll(m23.x);
+    return k + (u32)__popcll(mt & low);
 }
 
-// 8x8-pixel tile in one register: bit (8*r + c) = pixel (ty + r, tx + c).  The tile must lie inside the window.
+// head list: head_pix[k] = pixel index | type << 29 (the follower needs both); hrank[k] = CT_NONE (not a terminal)
+__global__ __launch_bounds__(256) void k_ct_headfill(ccl_geom G, const u64* __restrict__ hmaps, const u32* __restrict__ hbase, u32* __restrict__ head_pix,
+                                                     u32* __restrict__ hrank, size_t hcap)
+{
+    const int nwords = G.h * G.ww;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nwords) return;
+    const int f = blockIdx.y;
+    const u64* hm = hmaps + ((size_t)f * nwords + idx) * 4;
+    const ulonglong2 m01 = reinterpret_cast<const ulonglong2*>(hm)[0];
+    const ulonglong2 m23 = reinterpret_cast<const ulonglong2*>(hm)[1];
+    if (!(m01.x | m01.y | m23.x | m23.y)) return;
+    const int y = idx / G.ww, j = idx - y * G.ww;
+    u32 k = hbase[(size_t)f * nwords + idx];
+    u32* hp = head_pix + (size_t)f * hcap;
+    u32* hr = hrank + (size_t)f * hcap;
+    const u32 pix0 = (u32)(y * G.w + 64 * j);
+    const u64 mm[4] = {m01.x, m01.y, m23.x, m23.y};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        u64 m = mm[t];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            hp[k] = (pix0 + (u32)b) | ((u32)t << 29);
+            hr[k] = CT_NONE;
+            k++;
+        }
+    }
+}
+
+// ---- the follower ----
+// 8x8-pixel tile of the mask in one register pair: bit (8*r + c) = pixel (ty + r, tx + c); pixels outside the image are 0.
 struct ct_tile { u64 bits; int ty, tx; };
 
-__device__ __forceinline__ bool ct_win_holds(const ct_win& W, int ty, int tx)
-{
-    return (unsigned)(ty - W.y0) <= (unsigned)(CTW_ROWS - 8) && (unsigned)(tx - 64 * W.j0) <= (unsigned)(64 * CTW_WORDS - 8);
-}
-__device__ __forceinline__ void ct_tile_fetch(const u64* lds, const ct_win& W, int ty, int tx, ct_tile& T)
+__device__ __forceinline__ void ct_tile_load(const ccl_geom& G, const u64* __restrict__ fb, int ty, int tx, ct_tile& T)
 {
     T.ty = ty; T.tx = tx;
-    const int ry = ty - W.y0, rx = tx - 64 * W.j0;
-    const int j = rx >> 6, sh = rx & 63, j1 = min(j + 1, CTW_WORDS - 1);
+    const int j0 = tx >> 6;            // arithmetic shift: tx may be negative (floor)
+    const int sh = tx & 63;
+    // branch-free: clamped addresses, all 16 loads in flight together, out-of-image parts masked afterwards
+    const int ja = min(max(j0, 0), G.ww - 1), jb = min(max(j0 + 1, 0), G.ww - 1);
+    const u64 ma = (j0 >= 0 && j0 < G.ww) ? ~0ull : 0ull;
+    const u64 mb = (sh > 56 && j0 + 1 >= 0 && j0 + 1 < G.ww) ? ~0ull : 0ull;
     u64 lo[8], hi[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) { lo[r] = lds[(ry + r) * CTW_WORDS + j]; hi[r] = lds[(ry + r) * CTW_WORDS + j1]; }
+    for (int r = 0; r < 8; r++) {
+        const int yc = min(max(ty + r, 0), G.h - 1);
+        const u64* row = fb + (size_t)yc * G.ww;
+        lo[r] = row[ja];
+        hi[r] = row[jb];
+    }
     u64 acc = 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        u64 v = lo[r] >> sh;
-        v |= sh ? (hi[r] << (64 - sh)) : 0ull;
-        acc |= (v & 0xffull) << (8 * r);
+        const int y = ty + r;
+        const u64 my = (y >= 0 && y < G.h) ? ~0ull : 0ull;
+        u64 v = (lo[r] & ma) >> sh;
+        v |= sh ? ((hi[r] & mb) << (64 - sh)) : 0ull;
+        acc |= (v & my & 0xffull) << (8 * r);
     }
     T.bits = acc;
-}
-// (re)place the tile around (y, x): the pixel sits one step from the trailing edge of the direction it is moving in, so a
-// straight run gets ~5 steps out of one fetch
-__device__ __forceinline__ void ct_tile_place(const ccl_geom& G, const u64* __restrict__ fb, u64* lds, ct_win& W, int y, int x, int dy, int dx, ct_tile& T)
-{
-    const int ty = y - (dy > 0 ? 1 : (dy < 0 ? 6 : 3));
-    const int tx = x - (dx > 0 ? 1 : (dx < 0 ? 6 : 3));
-    if (!ct_win_holds(W, ty, tx)) ct_win_load(G, fb, y, x, W, lds);
-    ct_tile_fetch(lds, W, ty, tx, T);
 }
 __device__ __forceinline__ bool ct_tile_covers(const ct_tile& T, int y, int x)   // 3x3 neighbourhood inside the tile
 {
@@ -225,100 +301,195 @@ __device__ __forceinline__ u32 ct_ring(const ct_tile& T, int y, int x)
     // row above: bit0 -> NW(3), bit1 -> N(2), bit2 -> NE(1): a 3-bit reversal, looked up in a nibble table
     return ((0xE6A2C480u >> (4 * a)) & 0xFu) | (m >> 2) | ((m & 1u) << 4) | (b << 5);
 }
-
-// Suzuki-Abe trace of one border (imgproc/src/contours.cpp icvFetchContour), counting or writing points.
-template <bool WRITE>
-__device__ int ct_trace(const ccl_geom& G, const u64* __restrict__ fb, u64* lds, int y0, int x0, bool is_hole, int method, int32_t* __restrict__ pts)
-{
-    // 8-neighbourhood deltas {E, NE, N, NW, W, SW, S, SE} packed 2 bits each (value + 1): a table indexed at run time would live
-    // in memory and cost a load per probe
+// 8-neighbourhood deltas packed 2 bits each (value + 1): a table indexed at run time would live in memory
 #define dx8(s) ((int)((0x901Au >> (2 * (s))) & 3u) - 1)
 #define dy8(s) ((int)((0xA901u >> (2 * (s))) & 3u) - 1)
-    const bool writer = threadIdx.x == 0;
-    ct_win W;
-    ct_tile T;
-    ct_win_load(G, fb, y0, x0, W, lds);
-    ct_tile_fetch(lds, W, y0 - 3, x0 - 3, T);
-    u32 R = ct_ring(T, y0, x0);
-    if (!R) {   // single pixel
-        if (WRITE && writer) { pts[0] = x0; pts[1] = y0; }
-        return 1;
-    }
-    // first neighbour clockwise from W (outer border) or from E (hole border): the pixel the border "comes from"
-    int s = is_hole ? 0 : 4;
-    do { s = (s - 1) & 7; } while (!((R >> s) & 1u));
-    const int x1 = x0 + dx8(s), y1 = y0 + dy8(s);   // i1
-    int x3 = x0, y3 = y0;
-    int prev_s = s ^ 4;
-    int n = 0;
-    // a border visits a pixel at most once per incoming direction: bound the walk so that a corrupted image cannot
-    // keep the wave alive forever
-    long long guard = 8ll * G.w * G.h + 16;
-    for (; guard > 0; guard--) {
-        // first neighbour counter-clockwise after direction s
-        const u32 q = (R | (R << 8)) >> (s + 1);
-        s = (s + __ffs((int)q)) & 7;
-        const int x4 = x3 + dx8(s), y4 = y3 + dy8(s);
-        if (s != prev_s || method == 1) {
-            if (WRITE && writer) { pts[2 * n] = x3; pts[2 * n + 1] = y3; }
-            n++;
-            prev_s = s;
-        }
-        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
-        x3 = x4; y3 = y4;
-        if (!ct_tile_covers(T, y3, x3)) ct_tile_place(G, fb, lds, W, y3, x3, dy8(s), dx8(s), T);
-        R = ct_ring(T, y3, x3);
-        s = (s + 4) & 7;
-    }
-    return n;
-#undef dx8
-#undef dy8
-}
 
-// grid (CT_TRACE_BLOCKS, n), one wave per block: a wave traces borders blockIdx.x, blockIdx.x + gridDim.x, ...
-#define CT_TRACE_BLOCKS 256
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_ct_trace(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ starts,
-                                                 const ct_frame_out* __restrict__ info, int method,
-                                                 int32_t* __restrict__ counts, uint8_t* __restrict__ is_hole_out,
-                                                 const int32_t* __restrict__ offsets, int32_t* __restrict__ points, int max_contours,
-                                                 long long max_points)
+// first foreground neighbour clockwise from direction d (ring must be non-zero)
+__device__ __forceinline__ int ct_first_cw(u32 R, int d)
 {
-    __shared__ u64 win[CTW_ROWS * CTW_WORDS];
+    const u32 rr = ((R | (R << 8)) >> d) & 0xfeu;   // bit i = direction d + i, i = 1..7
+    return (d + (31 - __clz((int)rr))) & 7;
+}
+// state (s, sweep length t = number of background neighbours swept before s') at column x: type of the head that owns it
+// (0 W, 1 E, 2 N, 3 S) or -1
+__device__ __forceinline__ int ct_head_type(int s, int t, int x)
+{
+    const int iw = (3 - s) & 7, ie = (7 - s) & 7, in = (1 - s) & 7, is = (5 - s) & 7;
+    const bool ns = (x & 7) == 0;
+    int best = 8, type = -1;
+    if (iw < t) { best = iw; type = 0; }
+    if (ie < t && ie < best) { best = ie; type = 1; }
+    if (ns && in < t && in < best) { best = in; type = 2; }
+    if (ns && is < t && is < best) { best = is; type = 3; }
+    return type;
+}
+
+// start pixel of every border -> terminal head.  starts[r] = pixel | hole << 31 and shead[r] = head index (CT_NONE: single
+// pixel) for the selected borders in raster order; hrank[head] = r, or CT_UNSEL for a border the mode does not return.
+__global__ __launch_bounds__(256) void k_ct_starts(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ startmap,
+                                                   const u64* __restrict__ holemap, const u64* __restrict__ selmap, const u32* __restrict__ sbase,
+                                                   const u64* __restrict__ hmaps, const u32* __restrict__ hbase, u32* __restrict__ hrank, size_t hcap,
+                                                   u32* __restrict__ starts, u32* __restrict__ shead, int max_contours)
+{
+    const int nwords = G.h * G.ww;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nwords) return;
     const int f = blockIdx.y;
-    const int K = min(info[f].n_contours, max_contours);
-    const u64* fb = bits + (size_t)f * G.h * G.ww;
-    for (int rank = blockIdx.x; rank < K; rank += gridDim.x) {
-        const u32 st = starts[(size_t)f * max_contours + rank];
-        const bool hole = st >> 31;
-        const int pix = (int)(st & 0x7fffffffu);
-        const int y = pix / G.w, x = pix - y * G.w;
-        if (!WRITE) {
-            const int cnt = ct_trace<false>(G, fb, win, y, x, hole, method, nullptr);
-            if (threadIdx.x == 0) {
-                counts[(size_t)f * max_contours + rank] = cnt;
-                is_hole_out[(size_t)f * max_contours + rank] = hole ? 1 : 0;
+    const size_t fo = (size_t)f * nwords;
+    u64 sm = startmap[fo + idx];
+    if (!sm) return;
+    const u64 hm = holemap[fo + idx], sel = selmap[fo + idx];
+    const u64* fb = bits + fo;
+    const int y = idx / G.ww, j = idx - y * G.ww;
+    u32 r = sbase[fo + idx];
+    while (sm) {
+        const int b = __ffsll((long long)sm) - 1;
+        sm &= sm - 1;
+        const int x = 64 * j + b;
+        const bool hole = (hm >> b) & 1ull, selected = (sel >> b) & 1ull;
+        ct_tile T;
+        ct_tile_load(G, fb, y - 3, x - 3, T);
+        const u32 R = ct_ring(T, y, x);
+        u32 head = CT_NONE;
+        if (R) {
+            const int s = ct_first_cw(R, hole ? 0 : 4);
+            const u32 q = (R | (R << 8)) >> (s + 1);
+            const int t = __ffs((int)q) - 1;
+            const int type = ct_head_type(s, t, x);   // >= 0: the sweep crosses the W (outer) / E (hole) crack
+            if (type >= 0) {
+                head = ct_head_index(hmaps + fo * 4, hbase + fo, idx, b, type);
+                hrank[(size_t)f * hcap + head] = selected ? r : CT_UNSEL;
             }
-        } else {
-            const long long off = offsets[(size_t)f * max_contours + rank];
-            const int cnt = counts[(size_t)f * max_contours + rank];
-            if (off + cnt <= max_points) ct_trace<true>(G, fb, win, y, x, hole, method, points + 2 * ((size_t)f * max_points + off));
+        }
+        if (selected) {
+            if ((int)r < max_contours) {
+                starts[(size_t)f * max_contours + r] = (u32)(y * G.w + x) | (hole ? 0x80000000u : 0u);
+                shead[(size_t)f * max_contours + r] = head;
+            }
+            r++;
         }
     }
 }
 
-// per frame: exclusive scan of counts[0..K) -> offsets, total -> out[f].n_points (one block per frame)
-__global__ __launch_bounds__(256) void k_ct_offsets(const int32_t* __restrict__ counts, int32_t* __restrict__ offsets, ct_frame_out* __restrict__ out, int max_contours)
+// one thread per head: follow the border from the head's state to the next head.
+//   !WRITE: node[k] = (next head | CT_TERM if that is a terminal) << 32 | points emitted
+//    WRITE: the points go to their final place (see k_ct_offsets)
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ hmaps, const u32* __restrict__ hbase,
+                                                const u32* __restrict__ head_pix, const u32* __restrict__ hrank, size_t hcap,
+                                                const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, int method,
+                                                const int32_t* __restrict__ offsets, int32_t* __restrict__ points, int max_contours,
+                                                long long max_points)
+{
+    const int f = blockIdx.y;
+    const int nwords = G.h * G.ww;
+    const size_t fo = (size_t)f * nwords;
+    const u64* fb = bits + fo;
+    const u64* hm = hmaps + fo * 4;
+    const u32* hb = hbase + fo;
+    const u32* hr = hrank + (size_t)f * hcap;
+    unsigned long long* nd = node + (size_t)f * hcap;
+    const u32 H = aux[f].nheads;
+    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < H; k += gridDim.x * 256) {
+        int32_t* out = nullptr;
+        if (WRITE) {
+            const unsigned long long v = nd[k];
+            const u32 J = (u32)(v >> 32);
+            if (!(J & CT_TERM)) continue;               // did not converge (never seen; see CT_JUMP_ROUNDS)
+            const u32 T = J & ~CT_TERM;
+            const u32 r = hr[T];
+            if (r >= (u32)max_contours) continue;       // CT_UNSEL, or beyond the caller's capacity
+            const u32 total = (u32)nd[T];
+            const long long base = offsets[(size_t)f * max_contours + r];
+            if (base + (long long)total > max_points) continue;
+            const u32 off = (k == T) ? 0u : total - (u32)v;
+            out = points + 2 * ((size_t)f * max_points + base + off);
+        }
+        const u32 hp = head_pix[(size_t)f * hcap + k];
+        const int pix = (int)(hp & 0x1fffffffu), type = (int)(hp >> 29);
+        int y = pix / G.w, x = pix - y * G.w;
+        ct_tile T;
+        ct_tile_load(G, fb, y - 3, x - 3, T);
+        u32 R = ct_ring(T, y, x);
+        int s = ct_first_cw(R, type == 0 ? 4 : (type == 1 ? 0 : (type == 2 ? 2 : 6)));
+        u32 cnt = 0, succ = k;
+        bool first = true;
+        // a border visits a pixel at most once per incoming direction: bound the walk so that a corrupted image cannot
+        // keep the wave alive forever
+        for (long long guard = 8ll * G.w * G.h + 16; guard > 0; guard--) {
+            const u32 q = (R | (R << 8)) >> (s + 1);
+            const int t = __ffs((int)q) - 1;
+            if (!first) {
+                const int ht = ct_head_type(s, t, x);
+                if (ht >= 0) { succ = ct_head_index(hm, hb, y * G.ww + (x >> 6), x & 63, ht); break; }
+            }
+            first = false;
+            const int s2 = (s + 1 + t) & 7;
+            if (s2 != (s ^ 4) || method == 1) {
+                if (WRITE) { out[2 * cnt] = x; out[2 * cnt + 1] = y; }
+                cnt++;
+            }
+            x += dx8(s2); y += dy8(s2);
+            s = (s2 + 4) & 7;
+            if (!ct_tile_covers(T, y, x)) {
+                const int dy = dy8(s2), dx = dx8(s2);
+                ct_tile_load(G, fb, y - (dy > 0 ? 1 : (dy < 0 ? 6 : 3)), x - (dx > 0 ? 1 : (dx < 0 ? 6 : 3)), T);
+            }
+            R = ct_ring(T, y, x);
+        }
+        if (!WRITE) {
+            const u32 term = (hr[succ] != CT_NONE) ? CT_TERM : 0u;
+            nd[k] = ((unsigned long long)(succ | term) << 32) | cnt;
+        }
+    }
+}
+
+// per frame: pointer jumping.  node = (J, D): D points lie between this head and head J along the border.  A pair read in one
+// 64-bit load is always a consistent (older or newer) statement of that invariant, so the rounds need no double buffering.
+__global__ __launch_bounds__(1024) void k_ct_jump(const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, size_t hcap)
+{
+    const int f = blockIdx.x;
+    const u32 H = aux[f].nheads;
+    unsigned long long* nd = node + (size_t)f * hcap;
+    for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
+        int changed = 0;
+        for (u32 k = threadIdx.x; k < H; k += 1024) {
+            const unsigned long long v = __hip_atomic_load(nd + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 J = (u32)(v >> 32);
+            if (J & CT_TERM) continue;
+            const unsigned long long v2 = __hip_atomic_load(nd + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(nd + k, (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            changed = 1;
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+}
+
+// per frame: contour lengths from the terminals, exclusive scan -> offsets, total -> out[f].n_points; single-pixel contours are
+// written here (one block per frame)
+__global__ __launch_bounds__(256) void k_ct_offsets(ccl_geom G, const ct_aux* __restrict__ aux, const u32* __restrict__ starts, const u32* __restrict__ shead,
+                                                    const unsigned long long* __restrict__ node, size_t hcap, int32_t* __restrict__ counts,
+                                                    uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
+                                                    ct_frame_out* __restrict__ out, int max_contours, long long max_points)
 {
     __shared__ u32 wsum[4];
     __shared__ u32 carry;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int K = min(out[f].n_contours, max_contours);
+    const int nsel = (int)aux[f].nsel;
+    const int K = min(nsel, max_contours);
     if (tid == 0) carry = 0;
     __syncthreads();
     for (int base = 0; base < K; base += 256) {
         const int i = base + tid;
-        const u32 v = i < K ? (u32)counts[(size_t)f * max_contours + i] : 0u;
+        u32 v = 0, st = 0, sh = 0;
+        if (i < K) {
+            st = starts[(size_t)f * max_contours + i];
+            sh = shead[(size_t)f * max_contours + i];
+            v = (sh == CT_NONE) ? 1u : (u32)node[(size_t)f * hcap + sh];
+            counts[(size_t)f * max_contours + i] = (int32_t)v;
+            is_hole_out[(size_t)f * max_contours + i] = (uint8_t)(st >> 31);
+        }
         u32 inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
@@ -326,43 +497,71 @@ __global__ __launch_bounds__(256) void k_ct_offsets(const int32_t* __restrict__ 
         __syncthreads();
         u32 woff = 0;
         for (int k = 0; k < wv; k++) woff += wsum[k];
-        if (i < K) offsets[(size_t)f * max_contours + i] = (int32_t)(carry + woff + inc - v);
+        if (i < K) {
+            const u32 off = carry + woff + inc - v;
+            offsets[(size_t)f * max_contours + i] = (int32_t)off;
+            if (sh == CT_NONE && (long long)off + 1 <= max_points) {
+                const int pix = (int)(st & 0x7fffffffu);
+                const int y = pix / G.w;
+                int32_t* p = points + 2 * ((size_t)f * max_points + off);
+                p[0] = pix - y * G.w; p[1] = y;
+            }
+        }
         __syncthreads();
         if (tid == 255) carry += woff + inc;
         __syncthreads();
     }
-    if (tid == 0) out[f].n_points = (int32_t)carry;
+    if (tid == 0) { out[f].n_contours = nsel; out[f].n_points = (int32_t)carry; }
 }
+#undef dx8
+#undef dy8
 
-size_t vp_contours_ws_bytes(int w, int h, int n)
+size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
 {
     const size_t nids = vp_ccl_nids(w, h);
     const size_t words = (size_t)n * h * vp_ww(w);
-    return 2 * vp_align(nids * 4 * n) + 3 * vp_align(nids / 8 * n) + 2 * vp_align(words * 8) + vp_align(words * 4) + vp_align(sizeof(ct_frame_out) * n) + 4096;
+    const size_t hcap = ct_hcap(w, h) * n;
+    return 2 * vp_align(nids * 4 * n) + 3 * vp_align(nids / 8 * n) + 3 * vp_align(words * 8) + vp_align(words * 32) + 2 * vp_align(words * 4) +
+           2 * vp_align(hcap * 4) + vp_align(hcap * 8) + 2 * vp_align((size_t)n * max_contours * 4) + vp_align(sizeof(ct_aux) * n) + 8192;
 }
 
-// d_counts / d_is_hole: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are stored
-// in discovery order (raster order of the start pixel); cv2 returns them reversed — the caller reverses.
+// d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
+// stored in discovery order (raster order of the start pixel); cv2 returns them reversed - the caller reverses.
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info)
 {
     if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
     if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
+    if ((size_t)w * h >= (1u << 29)) return vp_fail(ctx, VP_ERR_INVALID, "contours: image too large");
     ccl_geom Gf, Gb;
     ccl_make_geom(Gf, w, h, VP_CCL_PIXEL, 0, 0);
     ccl_make_geom(Gb, w, h, VP_CCL_PIXEL, 1, 1);
     const size_t nids = Gf.nids;
-    const size_t words = (size_t)n * h * Gf.ww;
+    const int nwords = h * Gf.ww;
+    const size_t words = (size_t)n * nwords;
+    const size_t hcap = ct_hcap(w, h);
     u32* fg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
     u32* bg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
     u32* fg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
     u32* bg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
     u32* outside = (u32*)vp_ws_take(ctx, nids / 8 * n);
-    u64* startmap = (u64*)vp_ws_take(ctx, words * 8);
-    u64* holemap = (u64*)vp_ws_take(ctx, words * 8);
+    u64* maps3 = (u64*)vp_ws_take(ctx, 3 * vp_align(words * 8));   // startmap, holemap, selmap: cleared together
+    u64* hmaps = (u64*)vp_ws_take(ctx, words * 32);
+    u32* hbase = (u32*)vp_ws_take(ctx, words * 4);
+    u32* sbase = (u32*)vp_ws_take(ctx, words * 4);
+    u32* head_pix = (u32*)vp_ws_take(ctx, hcap * n * 4);
+    u32* hrank = (u32*)vp_ws_take(ctx, hcap * n * 4);
+    unsigned long long* node = (unsigned long long*)vp_ws_take(ctx, hcap * n * 8);
     u32* starts = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
-    if (!fg_parent || !bg_parent || !fg_flags || !bg_flags || !outside || !startmap || !holemap || !starts)
+    u32* shead = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
+    ct_aux* aux = (ct_aux*)vp_ws_take(ctx, sizeof(ct_aux) * n);
+    if (!fg_parent || !bg_parent || !fg_flags || !bg_flags || !outside || !maps3 || !hmaps || !hbase || !sbase || !head_pix || !hrank || !node ||
+        !starts || !shead || !aux)
         return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
+    const size_t mstride = vp_align(words * 8) / 8;
+    u64* startmap = maps3;
+    u64* holemap = maps3 + mstride;
+    u64* selmap = maps3 + 2 * mstride;
     hipStream_t s = ctx->stream;
     ct_frame_out* info = reinterpret_cast<ct_frame_out*>(d_info);
     int rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
@@ -370,18 +569,25 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags);
     if (rc != VP_OK) return rc;
     VP_HIP(ctx, hipMemsetAsync(outside, 0, nids / 8 * n, s));
-    VP_HIP(ctx, hipMemsetAsync(startmap, 0, words * 8, s));
-    VP_HIP(ctx, hipMemsetAsync(holemap, 0, words * 8, s));
+    VP_HIP(ctx, hipMemsetAsync(maps3, 0, 3 * mstride * 8, s));
     vp_prof_scope ps(ctx, VPK_OTHER);
+    const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
+    const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, 4096), (unsigned)n);
+    hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps);
+    hipLaunchKernelGGL(k_ct_prefix, dim3((unsigned)n), dim3(1024), 0, s, hmaps, 4, nwords, hbase, &aux->nheads, 2);
+    hipLaunchKernelGGL(k_ct_headfill, wgrid, dim3(256), 0, s, Gf, hmaps, hbase, head_pix, hrank, hcap);
     hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gb, bg_parent, outside);
     hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
-                       outside, mode, startmap, holemap);
-    hipLaunchKernelGGL(k_ct_rank, dim3((unsigned)n), dim3(1024), 0, s, startmap, holemap, h * Gf.ww, Gf.ww, w, starts, max_contours, info);
-    const dim3 tgrid((unsigned)min(max_contours, CT_TRACE_BLOCKS), (unsigned)n);
-    hipLaunchKernelGGL((k_ct_trace<false>), tgrid, dim3(64), 0, s, d_bits, Gf, starts, info, method, d_counts, d_is_hole, d_offsets, d_points,
+                       outside, mode, startmap, holemap, selmap);
+    hipLaunchKernelGGL(k_ct_prefix, dim3((unsigned)n), dim3(1024), 0, s, selmap, 1, nwords, sbase, &aux->nsel, 2);
+    hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, sbase, hmaps, hbase, hrank, hcap, starts, shead,
+                       max_contours);
+    hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
                        max_contours, max_points);
-    hipLaunchKernelGGL(k_ct_offsets, dim3((unsigned)n), dim3(256), 0, s, d_counts, d_offsets, info, max_contours);
-    hipLaunchKernelGGL((k_ct_trace<true>), tgrid, dim3(64), 0, s, d_bits, Gf, starts, info, method, d_counts, d_is_hole, d_offsets, d_points,
+    hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), 0, s, aux, node, hcap);
+    hipLaunchKernelGGL(k_ct_offsets, dim3((unsigned)n), dim3(256), 0, s, Gf, aux, starts, shead, node, hcap, d_counts, d_is_hole, d_offsets, d_points, info,
+                       max_contours, max_points);
+    hipLaunchKernelGGL((k_ct_seg<true>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
                        max_contours, max_points);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
