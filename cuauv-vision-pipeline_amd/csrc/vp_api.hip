@@ -96,6 +96,7 @@ int vp_destroy(vp_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->hstage) hipHostFree(ctx->hstage);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
@@ -251,6 +252,18 @@ void* vp_ws_take(vp_ctx* ctx, size_t bytes)
     if (off + bytes > ctx->ws_cap) return nullptr;
     ctx->ws_off = off + bytes;
     return ctx->ws + off;
+}
+
+void* vp_hstage(vp_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->hstage_cap) return ctx->hstage;
+    if (ctx->hstage) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->hstage); ctx->hstage = nullptr; ctx->hstage_cap = 0; }
+    const size_t cap = (bytes + (1u << 20) - 1) >> 20 << 20;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    ctx->hstage = (uint8_t*)p;
+    ctx->hstage_cap = cap;
+    return p;
 }
 
 #define TAKE(var, type, bytes)                                                   \
@@ -678,40 +691,56 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int 
     const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
     const int mc = max_contours > 0 ? max_contours : 1;
     const long long mp = max_points > 0 ? max_points : 1;
-    VP_TRY(vp_ws_reserve(ctx, vp_align(npx) + vp_align(bitbytes) + vp_contours_ws_bytes(w, h, 1, mc) + 2 * vp_align((size_t)mc * 4) + vp_align((size_t)mc) +
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx) + vp_align(bitbytes) + vp_contours_ws_bytes(w, h, 1, mc) + vp_align(16 + (size_t)mc * 9) +
                                   vp_align((size_t)mp * 8) + 8192));
     TAKE(d_src, uint8_t*, npx);
     TAKE(d_bits, u64*, bitbytes);
-    TAKE(d_counts, int32_t*, (size_t)mc * 4);
-    TAKE(d_offsets, int32_t*, (size_t)mc * 4);
-    TAKE(d_hole, uint8_t*, (size_t)mc);
+    // result header, one block so that one copy brings it back: info[2] (16 B) | counts[mc] | offsets[mc] | is_hole[mc]
+    const size_t hdr_bytes = 16 + (size_t)mc * 9;
+    TAKE(d_hdr, uint8_t*, hdr_bytes);
     TAKE(d_points, int32_t*, (size_t)mp * 8);
-    TAKE(d_info, int32_t*, 8);
+    int32_t* d_info = reinterpret_cast<int32_t*>(d_hdr);
+    int32_t* d_counts = reinterpret_cast<int32_t*>(d_hdr + 16);
+    int32_t* d_offsets = d_counts + mc;
+    uint8_t* d_hole = reinterpret_cast<uint8_t*>(d_offsets + mc);
     VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
     VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
     VP_TRY(vpk_find_contours(ctx, d_bits, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info));
-    int32_t info[2] = {0, 0};
-    VP_TRY(d2h(ctx, info, d_info, 8));
+    // the header and the first points come back under one synchronisation; longer point lists take a second copy
+    const size_t spec_pts = points ? (size_t)std::min<long long>(mp, 8192) : 0;
+    const size_t hdr_pad = vp_align(hdr_bytes);
+    uint8_t* hs = (uint8_t*)vp_hstage(ctx, hdr_pad + spec_pts * 8);
+    if (!hs) return vp_fail(ctx, VP_ERR_NOMEM, "pinned staging");
+    VP_TRY(d2h(ctx, hs, d_hdr, hdr_bytes));
+    if (spec_pts) VP_TRY(d2h(ctx, hs + hdr_pad, d_points, spec_pts * 8));
     VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *n_contours = info[0];
-    if (info[0] > max_contours) {   // the point total is only known for the contours that were traced
-        *n_points = (int64_t)info[1] > max_points ? (int64_t)info[1] : max_points;
+    const int32_t* info = reinterpret_cast<const int32_t*>(hs);
+    const int K = info[0];
+    const int64_t P = info[1];
+    *n_contours = K;
+    if (K > max_contours) {   // the point total is only known for the contours that were traced
+        *n_points = P > max_points ? P : max_points;
         return VP_OK;
     }
-    *n_points = info[1];
-    if (info[1] > max_points || info[0] == 0) return VP_OK;
-    const int K = info[0];
-    std::vector<int32_t> hc(K), ho(K), hp((size_t)info[1] * 2);
+    *n_points = P;
+    if (P > max_points || K == 0) return VP_OK;
+    std::vector<int32_t> hc(K), ho(K);
     std::vector<uint8_t> hh(K);
-    VP_TRY(d2h(ctx, hc.data(), d_counts, (size_t)K * 4));
-    VP_TRY(d2h(ctx, ho.data(), d_offsets, (size_t)K * 4));
-    VP_TRY(d2h(ctx, hh.data(), d_hole, (size_t)K));
-    VP_TRY(d2h(ctx, hp.data(), d_points, (size_t)info[1] * 8));
-    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(hc.data(), hs + 16, (size_t)K * 4);
+    memcpy(ho.data(), hs + 16 + (size_t)mc * 4, (size_t)K * 4);
+    memcpy(hh.data(), hs + 16 + (size_t)mc * 8, (size_t)K);
+    const int32_t* hp = reinterpret_cast<const int32_t*>(hs + hdr_pad);
+    if (points && (size_t)P > spec_pts) {
+        hs = (uint8_t*)vp_hstage(ctx, (size_t)P * 8 + 256);
+        if (!hs) return vp_fail(ctx, VP_ERR_NOMEM, "pinned staging");
+        VP_TRY(d2h(ctx, hs, d_points, (size_t)P * 8));
+        VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hp = reinterpret_cast<const int32_t*>(hs);
+    }
     // device order = discovery order; cv2 hands contours back newest first
     size_t o = 0;
     for (int k = K - 1, j = 0; k >= 0; k--, j++) {
-        if (points) memcpy(points + 2 * o, hp.data() + 2 * (size_t)ho[k], (size_t)hc[k] * 8);
+        if (points) memcpy(points + 2 * o, hp + 2 * (size_t)ho[k], (size_t)hc[k] * 8);
         o += (size_t)hc[k];
         if (counts) counts[j] = hc[k];
         if (is_hole) is_hole[j] = hh[k];

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
 // crack (and, to cut long flat edges, an N or S crack at x % 8 == 0) are enumerable with bit operations - the "heads" - and
 // they cut every border into short segments that are followed independently, one thread each:
 //   k_ct_headmaps   4 head bitmaps per word (a state that sweeps several eligible cracks belongs to the first one swept)
-//   k_ct_prefix     popcount prefix -> dense head index; same kernel ranks the selected start pixels (cv2's contour order)
-//   k_ct_headfill   head list (pixel, type), terminal marks cleared
+//   k_ct_prefix     popcount prefix -> dense head index + head list (pixel, type), terminal marks cleared; the same kernel
+//                   ranks the selected start pixels (cv2's contour order)
 //   k_ct_starts     start pixel of every border -> its start state -> the head that owns it = the terminal of that cycle
 //   k_ct_seg<false> follow each segment to the next head: node[k] = (next head, points emitted)
 //   k_ct_jump       pointer jumping on (next, distance) pairs until every head points at its terminal
@@ -160,55 +160,97 @@ __device__ __forceinline__ void ct_neighbours(const ccl_geom& G, const u64* __re
 
 // head bitmaps, 4 per word: [W, E, N, S].  A crack's state owns the head unless, going clockwise from the crack towards the
 // state's s, another eligible crack comes first (that one is swept earlier).
-__global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps)
+// block sum of per-thread counts -> partsum[f][blockIdx.x] (grid.x blocks of 256 words per frame)
+__device__ __forceinline__ void ct_block_sum(u32 c, u32* __restrict__ partsum)
+{
+    __shared__ u32 ws4[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) ws4[wv] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) partsum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ws4[0] + ws4[1] + ws4[2] + ws4[3];
+}
+
+__global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps, u32* __restrict__ partsum)
 {
     const int nwords = G.h * G.ww;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nwords) return;
     const int f = blockIdx.y;
-    const u64* fb = bits + (size_t)f * nwords;
-    const int y = idx / G.ww, j = idx - y * G.ww;
-    u64 c, n[8];
-    ct_neighbours(G, fb, y, j, c, n);
-    const u64 el = CT_EL_NS;
-    u64 hw = 0, he = 0, hn = 0, hs = 0;
-    if (c) {
-        hw = c & ~n[4] & (n[3] | n[2] | (~el & (n[1] | n[0])));
-        he = c & ~n[0] & (n[7] | n[6] | (~el & (n[5] | n[4])));
-        hn = c & ~n[2] & el & (n[1] | n[0]);
-        hs = c & ~n[6] & el & (n[5] | n[4]);
+    u32 cnt = 0;
+    if (idx < nwords) {
+        const u64* fb = bits + (size_t)f * nwords;
+        const int y = idx / G.ww, j = idx - y * G.ww;
+        u64 c, n[8];
+        ct_neighbours(G, fb, y, j, c, n);
+        const u64 el = CT_EL_NS;
+        u64 hw = 0, he = 0, hn = 0, hs = 0;
+        if (c) {
+            hw = c & ~n[4] & (n[3] | n[2] | (~el & (n[1] | n[0])));
+            he = c & ~n[0] & (n[7] | n[6] | (~el & (n[5] | n[4])));
+            hn = c & ~n[2] & el & (n[1] | n[0]);
+            hs = c & ~n[6] & el & (n[5] | n[4]);
+        }
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(hmaps + ((size_t)f * nwords + idx) * 4);
+        o[0] = make_ulonglong2(hw, he);
+        o[1] = make_ulonglong2(hn, hs);
+        cnt = (u32)(__popcll(hw) + __popcll(he) + __popcll(hn) + __popcll(hs));
     }
-    ulonglong2* o = reinterpret_cast<ulonglong2*>(hmaps + ((size_t)f * nwords + idx) * 4);
-    o[0] = make_ulonglong2(hw, he);
-    o[1] = make_ulonglong2(hn, hs);
+    ct_block_sum(cnt, partsum);
 }
 
-// per frame: exclusive prefix of the popcounts of `nm` bitmaps per word -> base[word], total -> *total (stride tstride u32)
-__global__ __launch_bounds__(1024) void k_ct_prefix(const u64* __restrict__ maps, int nm, int nwords, u32* __restrict__ base, u32* __restrict__ total_out,
-                                                    int tstride)
+// popcount of one bitmap per word, summed per block of 256 words
+__global__ __launch_bounds__(256) void k_ct_partsum(const u64* __restrict__ map, int nwords, u32* __restrict__ partsum)
 {
-    __shared__ u32 wsum[16];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u64* m = maps + (size_t)f * nwords * nm;
-    u32* bs = base + (size_t)f * nwords;
-    const int per = (nwords + 1023) / 1024;
-    const int lo = min(tid * per, nwords), hi = min(lo + per, nwords);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    ct_block_sum(idx < nwords ? (u32)__popcll(map[(size_t)blockIdx.y * nwords + idx]) : 0u, partsum);
+}
+
+// exclusive prefix of the popcounts of `nm` bitmaps per word -> base[word]; total -> total_out[f * tstride].
+// grid (ceil(nwords/256), n): block b adds up the block sums before it, then scans its 256 words.
+__global__ __launch_bounds__(256) void k_ct_prefix(const u64* __restrict__ maps, int nm, int nwords, const u32* __restrict__ partsum,
+                                                   u32* __restrict__ base, u32* __restrict__ total_out, int tstride, int w, int ww,
+                                                   u32* __restrict__ head_pix, u32* __restrict__ hrank, size_t hcap)
+{
+    __shared__ u32 wsum[4], wtot[4];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32* ps = partsum + (size_t)f * gridDim.x;
+    u32 c = 0;
+    for (int q = tid; q < (int)blockIdx.x; q += 256) c += ps[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) wtot[wv] = c;
+    const int i = blockIdx.x * 256 + tid;
     u32 cnt = 0;
-    for (int i = lo; i < hi; i++)
-        for (int t = 0; t < nm; t++) cnt += (u32)__popcll(m[(size_t)i * nm + t]);
+    if (i < nwords)
+        for (int t = 0; t < nm; t++) cnt += (u32)__popcll(maps[((size_t)f * nwords + i) * nm + t]);
     u32 inc = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    u32 woff = 0, total = 0;
-    for (int k = 0; k < 16; k++) { if (k < wv) woff += wsum[k]; total += wsum[k]; }
-    u32 run = woff + inc - cnt;
-    for (int i = lo; i < hi; i++) {
-        bs[i] = run;
-        for (int t = 0; t < nm; t++) run += (u32)__popcll(m[(size_t)i * nm + t]);
+    const u32 carry = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    u32 woff = 0;
+    for (int k = 0; k < wv; k++) woff += wsum[k];
+    if (i < nwords) base[(size_t)f * nwords + i] = carry + woff + inc - cnt;
+    if (head_pix && cnt) {   // head list: head_pix[k] = pixel index | type << 29; hrank[k] = CT_NONE (not a terminal)
+        const int y = i / ww, j = i - y * ww;
+        const u32 pix0 = (u32)(y * w + 64 * j);
+        u32 k = carry + woff + inc - cnt;
+        u32* hp = head_pix + (size_t)f * hcap;
+        u32* hr = hrank + (size_t)f * hcap;
+        for (int t = 0; t < 4; t++) {
+            u64 m = maps[((size_t)f * nwords + i) * 4 + t];
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                hp[k] = (pix0 + (u32)b) | ((u32)t << 29);
+                hr[k] = CT_NONE;
+                k++;
+            }
+        }
     }
-    if (tid == 0) total_out[(size_t)f * tstride] = total;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) total_out[(size_t)f * tstride] = carry + wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // dense index of head (word idx, bit b, type t)
@@ -223,37 +265,6 @@ __device__ __forceinline__ u32 ct_head_index(const u64* __restrict__ hm, const u
     if (t > 1) k += (u32)__popcll(m01.y);
     if (t > 2) k += (u32)__popcll(m23.x);
     return k + (u32)__popcll(mt & low);
-}
-
-// head list: head_pix[k] = pixel index | type << 29 (the follower needs both); hrank[k] = CT_NONE (not a terminal)
-__global__ __launch_bounds__(256) void k_ct_headfill(ccl_geom G, const u64* __restrict__ hmaps, const u32* __restrict__ hbase, u32* __restrict__ head_pix,
-                                                     u32* __restrict__ hrank, size_t hcap)
-{
-    const int nwords = G.h * G.ww;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nwords) return;
-    const int f = blockIdx.y;
-    const u64* hm = hmaps + ((size_t)f * nwords + idx) * 4;
-    const ulonglong2 m01 = reinterpret_cast<const ulonglong2*>(hm)[0];
-    const ulonglong2 m23 = reinterpret_cast<const ulonglong2*>(hm)[1];
-    if (!(m01.x | m01.y | m23.x | m23.y)) return;
-    const int y = idx / G.ww, j = idx - y * G.ww;
-    u32 k = hbase[(size_t)f * nwords + idx];
-    u32* hp = head_pix + (size_t)f * hcap;
-    u32* hr = hrank + (size_t)f * hcap;
-    const u32 pix0 = (u32)(y * G.w + 64 * j);
-    const u64 mm[4] = {m01.x, m01.y, m23.x, m23.y};
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        u64 m = mm[t];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            hp[k] = (pix0 + (u32)b) | ((u32)t << 29);
-            hr[k] = CT_NONE;
-            k++;
-        }
-    }
 }
 
 // ---- the follower ----
@@ -447,11 +458,32 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
 
 // per frame: pointer jumping.  node = (J, D): D points lie between this head and head J along the border.  A pair read in one
 // 64-bit load is always a consistent (older or newer) statement of that invariant, so the rounds need no double buffering.
+// Up to CTJ_LDS heads the table lives in LDS for the rounds.
+#define CTJ_LDS 8192
 __global__ __launch_bounds__(1024) void k_ct_jump(const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, size_t hcap)
 {
+    __shared__ unsigned long long tab[CTJ_LDS];
     const int f = blockIdx.x;
     const u32 H = aux[f].nheads;
     unsigned long long* nd = node + (size_t)f * hcap;
+    if (H <= CTJ_LDS) {
+        for (u32 k = threadIdx.x; k < H; k += 1024) tab[k] = nd[k];
+        __syncthreads();
+        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
+            int changed = 0;
+            for (u32 k = threadIdx.x; k < H; k += 1024) {
+                const unsigned long long v = tab[k];
+                const u32 J = (u32)(v >> 32);
+                if (J & CT_TERM) continue;
+                const unsigned long long v2 = tab[J];
+                tab[k] = (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2);
+                changed = 1;
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+        for (u32 k = threadIdx.x; k < H; k += 1024) nd[k] = tab[k];
+        return;
+    }
     for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
         int changed = 0;
         for (u32 k = threadIdx.x; k < H; k += 1024) {
@@ -522,7 +554,7 @@ size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
     const size_t words = (size_t)n * h * vp_ww(w);
     const size_t hcap = ct_hcap(w, h) * n;
     return 2 * vp_align(nids * 4 * n) + 3 * vp_align(nids / 8 * n) + 3 * vp_align(words * 8) + vp_align(words * 32) + 2 * vp_align(words * 4) +
-           2 * vp_align(hcap * 4) + vp_align(hcap * 8) + 2 * vp_align((size_t)n * max_contours * 4) + vp_align(sizeof(ct_aux) * n) + 8192;
+           2 * vp_align(hcap * 4) + vp_align(hcap * 8) + 2 * vp_align((size_t)n * max_contours * 4) + vp_align(sizeof(ct_aux) * n) + 2 * vp_align(words / 64 + 4 * n) + 8192;
 }
 
 // d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
@@ -555,7 +587,10 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     u32* starts = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
     u32* shead = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
     ct_aux* aux = (ct_aux*)vp_ws_take(ctx, sizeof(ct_aux) * n);
-    if (!fg_parent || !bg_parent || !fg_flags || !bg_flags || !outside || !maps3 || !hmaps || !hbase || !sbase || !head_pix || !hrank || !node ||
+    const size_t nparts = (size_t)(nwords + 255) / 256;
+    u32* partsum = (u32*)vp_ws_take(ctx, nparts * n * 4);
+    u32* partsum2 = (u32*)vp_ws_take(ctx, nparts * n * 4);
+    if (!partsum || !partsum2 || !fg_parent || !bg_parent || !fg_flags || !bg_flags || !outside || !maps3 || !hmaps || !hbase || !sbase || !head_pix || !hrank || !node ||
         !starts || !shead || !aux)
         return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
     const size_t mstride = vp_align(words * 8) / 8;
@@ -573,13 +608,13 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     vp_prof_scope ps(ctx, VPK_OTHER);
     const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
     const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, 4096), (unsigned)n);
-    hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps);
-    hipLaunchKernelGGL(k_ct_prefix, dim3((unsigned)n), dim3(1024), 0, s, hmaps, 4, nwords, hbase, &aux->nheads, 2);
-    hipLaunchKernelGGL(k_ct_headfill, wgrid, dim3(256), 0, s, Gf, hmaps, hbase, head_pix, hrank, hcap);
+    hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum);
+    hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
     hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gb, bg_parent, outside);
     hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
                        outside, mode, startmap, holemap, selmap);
-    hipLaunchKernelGGL(k_ct_prefix, dim3((unsigned)n), dim3(1024), 0, s, selmap, 1, nwords, sbase, &aux->nsel, 2);
+    hipLaunchKernelGGL(k_ct_partsum, wgrid, dim3(256), 0, s, selmap, nwords, partsum2);
+    hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, selmap, 1, nwords, partsum2, sbase, &aux->nsel, 2, w, Gf.ww, (u32*)nullptr, (u32*)nullptr, hcap);
     hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, sbase, hmaps, hbase, hrank, hcap, starts, shead,
                        max_contours);
     hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,

@@ -35,6 +35,8 @@ struct vp_ctx {
     uint8_t* ws;      // grow-only device workspace, carved per call
     size_t ws_cap;
     size_t ws_off;
+    uint8_t* hstage;  // grow-only pinned host staging for small results (contour lists)
+    size_t hstage_cap;
     int num_cu;
     int chain_streams;            // sub-batches of a chain run on this many internal streams (>= 1)
     hipStream_t aux[4];
@@ -64,6 +66,7 @@ struct vp_prof_scope {
 // ---- workspace ---------------------------------------------------------------------------
 int vp_ws_reserve(vp_ctx* ctx, size_t bytes);               // may reallocate (synchronises)
 void* vp_ws_take(vp_ctx* ctx, size_t bytes);                // 256-B aligned carve; NULL if exhausted
+void* vp_hstage(vp_ctx* ctx, size_t bytes);                 // pinned host staging of at least `bytes` (NULL: out of memory)
 static inline size_t vp_align(size_t n, size_t a = 256) { return (n + a - 1) / a * a; }
 int vp_fail(vp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 #define VP_HIP(ctx, call)                                                   \
