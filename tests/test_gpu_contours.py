@@ -122,3 +122,75 @@ def test_contour_helpers_on_gpu_contours(vp, oracle):
     mo = oracle.contour_moments(c)
     assert feature.contour_area(c) == mo["area"]
     assert feature.contour_centroid(c) == (int(mo["m10"] / max(1e-10, mo["m00"])), int(mo["m01"] / max(1e-10, mo["m00"])))
+
+
+def test_thin_and_periodic_structures(vp, oracle):
+    """Patterns that stress the segment-parallel follower: states that sweep several cracks at once (line tips), states that
+    sweep none (inner corners), flat edges longer than the 8-column head spacing at every alignment, word boundaries."""
+    yy, xx = np.mgrid[0:96, 0:200]
+    pats = [
+        ((xx + yy) % 2 == 0),                                  # checkerboard: one diagonal-connected component with many holes
+        ((xx % 4 == 0) | (yy % 4 == 0)),                       # 1-px grid
+        ((xx + yy) % 7 == 0),                                  # diagonal lines
+        ((xx - yy) % 5 == 0) | (yy == 48),                     # anti-diagonals crossed by a line
+        (yy % 3 == 0) & (xx > 2) & (xx < 197),                 # long horizontal 1-px lines
+        (xx % 3 == 0) & (yy > 2) & (yy < 93),                  # long vertical 1-px lines
+        (np.abs(xx - 100) + np.abs(yy - 48) <= 40) & (np.abs(xx - 100) + np.abs(yy - 48) >= 38),   # diamond outline
+        ((xx // 2 + yy // 2) % 2 == 0),                        # 2x2 checkerboard
+    ]
+    for p in pats:
+        m = np.where(p, 255, 0).astype(np.uint8)
+        for mode in (0, 1):
+            _check(vp, oracle, m, mode, 2)
+            _check(vp, oracle, m, mode, 1)
+        _check(vp, oracle, 255 - m, 1, 2)
+    for x0 in range(57, 73):                                    # rectangles at every alignment around a word boundary
+        for wd in (1, 2, 7, 8, 9, 17):
+            m = np.zeros((12, 160), np.uint8)
+            m[3:9, x0:x0 + wd] = 255
+            m[5:7, x0 + 2:x0 + wd - 2] = 0
+            _check(vp, oracle, m, 1, 1)
+            _check(vp, oracle, m, 0, 2)
+
+
+def test_many_heads_global_jump_path_and_capacity_retry(vp, oracle):
+    """More than 8192 heads per frame (pointer jumping in global memory instead of LDS) and more contours / points than the
+    mirror's first-guess capacities (the call is repeated with the reported totals)."""
+    rng = np.random.default_rng(21)
+    m = F.random_mask(rng, 200, 300, 0.5)
+    _check(vp, oracle, m, 1, 2)
+    _check(vp, oracle, m, 1, 1)
+    m = F.random_mask(rng, 150, 700, 0.35)
+    _check(vp, oracle, m, 1, 1)
+
+
+def test_full_size_frame_properties(vp, oracle):
+    """1080p: noise in RETR_LIST mode against the oracle, plus properties that need no oracle: every contour point is a
+    foreground pixel, CHAIN_APPROX_NONE neighbours are 8-adjacent, SIMPLE is a subsequence of NONE with the same start."""
+    from vision.utils import feature
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:1080, 0:1920]
+    m = np.zeros((1080, 1920), np.uint8)
+    for _ in range(60):
+        cx, cy, r = rng.uniform(0, 1920), rng.uniform(0, 1080), rng.uniform(5, 200)
+        m[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 255
+    for _ in range(25):
+        cx, cy, r = rng.uniform(0, 1920), rng.uniform(0, 1080), rng.uniform(3, 60)
+        m[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 0
+    m[500:503, :] = 255                                         # a line across the whole frame, touching both sides
+    for mode in (0, 1):
+        _check(vp, oracle, m, mode, 2)
+    none = feature.find_contours(m, 1, 1)
+    simple = feature.find_contours(m, 1, 2)
+    assert len(none) == len(simple)
+    for a, b in zip(none, simple):
+        a, b = a.reshape(-1, 2), b.reshape(-1, 2)
+        assert (m[a[:, 1], a[:, 0]] == 255).all()
+        if len(a) > 1:
+            d = np.abs(np.diff(np.vstack([a, a[:1]]), axis=0))
+            assert d.max() == 1
+        assert tuple(a[0]) == tuple(b[0])
+        ia = {tuple(p) for p in a}
+        assert all(tuple(p) in ia for p in b)
+    noise = F.random_mask(rng, 1080, 1920, 0.5)
+    _check(vp, oracle, noise, 1, 2)
