@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the chain + contours side measurement")
     ap.add_argument("--max-labels", type=int, default=256)
     return ap.parse_args()
 
@@ -157,6 +158,30 @@ def main():
     fps = n_gpus * B * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # ---- extra (not `value`): the same chain followed by cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) on the cleaned
+    # mask of every frame (modules/red_buoy.py:36-38), batch resident in HBM, rank-local rate
+    extras = {}
+    if not args.no_extras:
+        cdesc = _vp.make_contour_desc("cleaned", _vp.RETR_EXTERNAL, _vp.CHAIN_APPROX_SIMPLE, 64, 8192)
+        carr = {"info": torch.zeros((B, 2), dtype=torch.int32, device="cuda"), "counts": torch.zeros((B, 64), dtype=torch.int32, device="cuda"),
+                "offsets": torch.zeros((B, 64), dtype=torch.int32, device="cuda"), "is_hole": torch.zeros((B, 64), dtype=torch.uint8, device="cuda"),
+                "points": torch.zeros((B, 8192, 2), dtype=torch.int32, device="cuda")}
+        cb = _vp.ContourBuffers()
+        for k_, v_ in carr.items():
+            setattr(cb, k_, v_.data_ptr())
+        ksteps = max(1, min(args.steps, 10))
+        ctx.chain_run_contours(desc, bufs, cdesc, cb, B)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(ksteps):
+            ctx.chain_run_contours(desc, bufs, cdesc, cb, B)
+        sync()
+        dt = time.perf_counter() - t0
+        info = carr["info"].cpu().numpy()
+        extras["chain_plus_outer_contours"] = {"frames_per_s_per_gpu": round(B * ksteps / dt, 1), "ms_per_step": round(1e3 * dt / ksteps, 4),
+                                               "steps": ksteps, "contours_per_frame": [int(info[:, 0].min()), int(info[:, 0].max())],
+                                               "points_per_frame": [int(info[:, 1].min()), int(info[:, 1].max())]}
+
     # HBM-side bytes per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
     # separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py); collected at batch 128
     traffic_tab = {}
@@ -240,7 +265,7 @@ def main():
                        "outputs": "threshold mask u8, cleaned mask u8, labels i32, stats/centroids", "max_labels": args.max_labels,
                        "labels_per_frame_seen": [int(n_labels_seen.min()), int(n_labels_seen.max())]},
             "algorithmic_bytes_per_frame": alg_bytes_step // B,
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "extras": extras,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

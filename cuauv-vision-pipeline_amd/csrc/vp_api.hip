@@ -775,7 +775,9 @@ static size_t chain_ws_bytes(const vp_chain_desc* d, int n)
 }
 
 // core: all pointers device; workspace already reserved and not yet carved past `ctx->ws_off`
-static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffers* b, int n)
+#define CT_GROUP 16   // frames per contour pass: bounds the contour workspace (about 50 MB per 1080p frame)
+static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffers* b, int n, const vp_contour_desc* cd = nullptr,
+                      const vp_contour_buffers* cb = nullptr)
 {
     const int w = d->width, h = d->height;
     const size_t bitbytes = (size_t)n * h * vp_ww(w) * 8;
@@ -798,8 +800,9 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
         rect_se k = {se.kw, se.kh, se.ax, se.ay};
         if (stages_for_op(st, d->morph_op[i], k) != VP_OK) return vp_fail(ctx, VP_ERR_INVALID, "chain: op");
     }
-    const bool need_clean_bits = d->ccl == 1;
+    const bool need_clean_bits = d->ccl == 1 || (cd && cd->source == 1);
     const u64* ccl_bits = bits_t;
+    const u64* clean_bits = bits_t;   // no morphology: the cleaned mask is the threshold mask
     vp_ccl_ws ws;
     memset(&ws, 0, sizeof ws);
     if (d->ccl) {
@@ -812,13 +815,38 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
         } else {
             // bits_t must survive when CCL labels the threshold mask; run_bit_stages only reads its input
             VP_TRY(run_bit_stages(ctx, st, bits_t, bits_b, w, h, n, need_clean_bits ? bits_a : nullptr, b->cleaned));
-            if (need_clean_bits) ccl_bits = bits_a;
+            if (need_clean_bits) clean_bits = bits_a;
+            if (d->ccl == 1) ccl_bits = bits_a;
         }
     }
     if (d->ccl) {
         VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
                        b->nlabels ? b->nlabels : d_nl));
     }
+    if (cd) {
+        const u64* src = cd->source == 1 ? clean_bits : bits_t;
+        const size_t fw = (size_t)h * vp_ww(w);
+        const size_t mc = (size_t)cd->max_contours;
+        const size_t mark = ctx->ws_off;
+        for (int f0 = 0; f0 < n; f0 += CT_GROUP) {
+            const int g = std::min(CT_GROUP, n - f0);
+            ctx->ws_off = mark;   // every group reuses the same scratch (stream order keeps them apart)
+            VP_TRY(vpk_find_contours(ctx, src + (size_t)f0 * fw, w, h, g, cd->mode, cd->method, cb->counts + f0 * mc, cb->is_hole + f0 * mc,
+                                     cb->offsets + f0 * mc, cb->points + 2 * (size_t)f0 * (size_t)cd->max_points, cd->max_contours,
+                                     cd->max_points, cb->info + 2 * (size_t)f0));
+        }
+    }
+    return VP_OK;
+}
+
+static int check_cdesc(vp_ctx* ctx, const vp_contour_desc* cd, const vp_contour_buffers* cb)
+{
+    if (!cd || !cb) return vp_fail(ctx, VP_ERR_INVALID, "contours: descriptor");
+    if (cd->source != 1 && cd->source != 2) return vp_fail(ctx, VP_ERR_INVALID, "contours: source");
+    if (cd->mode != VP_RETR_EXTERNAL && cd->mode != VP_RETR_LIST) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
+    if (cd->method != VP_CHAIN_APPROX_NONE && cd->method != VP_CHAIN_APPROX_SIMPLE) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
+    if (cd->max_contours <= 0 || cd->max_points <= 0) return vp_fail(ctx, VP_ERR_INVALID, "contours: capacity");
+    if (!cb->info || !cb->counts || !cb->offsets || !cb->is_hole || !cb->points) return vp_fail(ctx, VP_ERR_INVALID, "contours: buffers");
     return VP_OK;
 }
 
@@ -900,6 +928,70 @@ int vp_chain_run_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buf
         if (host->centroids) VP_TRY(d2h(ctx, host->centroids, d.centroids, n * ml * 16));
         if (host->nlabels) VP_TRY(d2h(ctx, host->nlabels, d.nlabels, (size_t)n * 4));
     }
+    return vp_synchronize(ctx);
+}
+
+int vp_chain_run_contours(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* dev, const vp_contour_desc* cdesc,
+                          const vp_contour_buffers* cdev, int n_frames)
+{
+    VP_TRY(check_ctx(ctx));
+    VP_TRY(check_desc(ctx, desc, n_frames));
+    VP_TRY(check_cdesc(ctx, cdesc, cdev));
+    if (!dev || !dev->bgr) return vp_fail(ctx, VP_ERR_INVALID, "chain: bgr");
+    VP_TRY(vp_ws_reserve(ctx, chain_ws_bytes(desc, n_frames) + 4 * 65536 +
+                                  vp_contours_ws_bytes(desc->width, desc->height, std::min(n_frames, CT_GROUP), cdesc->max_contours)));
+    return chain_core(ctx, desc, dev, n_frames, cdesc, cdev);
+}
+
+int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* host, const vp_contour_desc* cdesc,
+                               const vp_contour_buffers* chost, int n)
+{
+    VP_TRY(check_ctx(ctx));
+    VP_TRY(check_desc(ctx, desc, n));
+    VP_TRY(check_cdesc(ctx, cdesc, chost));
+    if (!host || !host->bgr) return vp_fail(ctx, VP_ERR_INVALID, "chain: bgr");
+    const size_t npx = (size_t)n * desc->width * desc->height;
+    const size_t ml = (size_t)(desc->ccl ? desc->max_labels : 1);
+    const size_t mc = (size_t)cdesc->max_contours, mp = (size_t)cdesc->max_points;
+    VP_TRY(vp_ws_reserve(ctx, chain_ws_bytes(desc, n) + vp_align(npx * 3) + 2 * vp_align(npx) + vp_align(npx * 4) + vp_align(n * ml * 20) +
+                                  vp_align(n * ml * 16) + vp_align((size_t)n * 4) + vp_align((size_t)n * 8) + 2 * vp_align(n * mc * 4) +
+                                  vp_align(n * mc) + vp_align(n * mp * 8) + 16384 +
+                                  vp_contours_ws_bytes(desc->width, desc->height, std::min(n, CT_GROUP), cdesc->max_contours)));
+    vp_chain_buffers d;
+    memset(&d, 0, sizeof d);
+    TAKE(d_bgr, uint8_t*, npx * 3);
+    d.bgr = d_bgr;
+    if (host->threshed) { d.threshed = (uint8_t*)vp_ws_take(ctx, npx); if (!d.threshed) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+    if (host->cleaned) { d.cleaned = (uint8_t*)vp_ws_take(ctx, npx); if (!d.cleaned) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+    if (desc->ccl) {
+        if (host->labels) { d.labels = (int32_t*)vp_ws_take(ctx, npx * 4); if (!d.labels) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+        if (host->stats) { d.stats = (int32_t*)vp_ws_take(ctx, n * ml * 20); if (!d.stats) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+        if (host->centroids) { d.centroids = (double*)vp_ws_take(ctx, n * ml * 16); if (!d.centroids) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
+        d.nlabels = (int32_t*)vp_ws_take(ctx, (size_t)n * 4);
+        if (!d.nlabels) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
+    }
+    vp_contour_buffers c;
+    c.info = (int32_t*)vp_ws_take(ctx, (size_t)n * 8);
+    c.counts = (int32_t*)vp_ws_take(ctx, n * mc * 4);
+    c.offsets = (int32_t*)vp_ws_take(ctx, n * mc * 4);
+    c.is_hole = (uint8_t*)vp_ws_take(ctx, n * mc);
+    c.points = (int32_t*)vp_ws_take(ctx, n * mp * 8);
+    if (!c.info || !c.counts || !c.offsets || !c.is_hole || !c.points) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
+    VP_TRY(h2d(ctx, d_bgr, host->bgr, npx * 3));
+    VP_TRY(chain_core(ctx, desc, &d, n, cdesc, &c));
+    if (host->threshed) VP_TRY(d2h(ctx, host->threshed, d.threshed, npx));
+    if (host->cleaned) VP_TRY(d2h(ctx, host->cleaned, d.cleaned, npx));
+    if (desc->ccl) {
+        if (host->labels) VP_TRY(d2h(ctx, host->labels, d.labels, npx * 4));
+        if (host->stats) VP_TRY(d2h(ctx, host->stats, d.stats, n * ml * 20));
+        if (host->centroids) VP_TRY(d2h(ctx, host->centroids, d.centroids, n * ml * 16));
+        if (host->nlabels) VP_TRY(d2h(ctx, host->nlabels, d.nlabels, (size_t)n * 4));
+    }
+    VP_TRY(d2h(ctx, chost->info, c.info, (size_t)n * 8));
+    VP_TRY(d2h(ctx, chost->counts, c.counts, n * mc * 4));
+    VP_TRY(d2h(ctx, chost->offsets, c.offsets, n * mc * 4));
+    VP_TRY(d2h(ctx, chost->is_hole, c.is_hole, n * mc));
+    VP_TRY(d2h(ctx, chost->points, c.points, n * mp * 8));
     return vp_synchronize(ctx);
 }
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, 
 // One block per (frame, strip of CL_ROWS rows).
 // dynamic LDS: lbits[nw] u64 | wbase[nw + 2] u32 | lparent[CAP] | lgid[CAP] | lmin[CAP]
 __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
-                                                   u32* __restrict__ flags, int strips)
+                                                   u32* __restrict__ flags, int strips, int cap)
 {
     extern __shared__ __attribute__((aligned(16))) u64 cl_lds[];
     __shared__ u32 wsum[4];
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
     const u64* fb = bits + (size_t)frame * G.h * ww;
     CL_FOR_WORDS(r, j, i) lbits[i] = ccl_word(G, fb, (y0 + r) * ww + j, j);
     __syncthreads();
-    ccl_local_strip(G, lbits, wbase, lparent, lparent + CL_CAP, lparent + 2 * CL_CAP, wsum, &total_s, y0, nrows, strip, strips, fb,
-                    parent + (size_t)frame * G.nids, flags + (size_t)frame * G.nw32);
+    ccl_local_strip(G, lbits, wbase, lparent, lparent + cap, lparent + 2 * cap, wsum, &total_s, y0, nrows, strip, strips, fb,
+                    parent + (size_t)frame * G.nids, flags + (size_t)frame * G.nw32, (u32)cap);
 }
 
 // vertical unions across strip boundaries: grid (strips - 1, n), block = 64 threads over the words of the row
@@ -522,9 +522,13 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
     hipStream_t s = ctx->stream;
     const int strips = (h + CL_ROWS - 1) / CL_ROWS;
     const size_t nwmax = (size_t)CL_ROWS * G.ww;
-    const size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + (size_t)3 * CL_CAP * 4;
+    // the background of a mask is mostly full words: every word of every row is a segment, so the inverted pass needs room
+    // for all of them plus the fragments around the foreground
+    size_t cap = G.invert ? (size_t)nwmax + 1024 : CL_CAP;
+    size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + 3 * cap * 4;
+    if (lds_local > 64 * 1024 && G.invert) { cap = CL_CAP; lds_local = nwmax * 8 + (nwmax + 2) * 4 + 3 * cap * 4; }
     if (lds_local <= 64 * 1024) {
-        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips); }
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips, (int)cap); }
         if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags); }
     } else {
         { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)G.nw32 * 4 * n, s)); }

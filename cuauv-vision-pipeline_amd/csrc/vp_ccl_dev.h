@@ -113,7 +113,7 @@ __device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, con
 
 // ---- strip-local union-find in LDS ------------------------------------------------------------------
 #define CL_ROWS 32
-#define CL_CAP 512    // segments per strip handled in LDS; denser strips fall back to global memory
+#define CL_CAP 512    // default segments per strip handled in LDS (foreground); denser strips fall back to global memory
 
 __device__ __forceinline__ u32 lds_find(volatile u32* p, u32 x)
 {
@@ -148,11 +148,11 @@ __device__ __forceinline__ void lds_unite(u32* p, u32 a, u32 b)
 // lbits[nrows][ww]; called by all 256 threads of a block.  Resolves the strip's components entirely in LDS and writes
 // parent[id] = smallest id of the segment's strip-local component (init + link in one pass); clears the strip's slice
 // of the root bitmap and marks the strip-local representatives.  wbase needs nrows*ww + 2 words, lparent / lgid / lmin
-// CL_CAP words each, wsum 4 words and total_s 1 word of LDS.  fb = the frame's bit image in global memory (only the
+// `cap` words each, wsum 4 words and total_s 1 word of LDS.  fb = the frame's bit image in global memory (only the
 // dense-strip fallback reads it, for rows of this strip).
 __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lbits, u32* wbase, u32* lparent, u32* lgid, u32* lmin,
                                                 u32* wsum, u32* total_s, int y0, int nrows, int strip, int strips,
-                                                const u64* __restrict__ fb, u32* __restrict__ gp, u32* __restrict__ gf)
+                                                const u64* __restrict__ fb, u32* __restrict__ gp, u32* __restrict__ gf, u32 cap = CL_CAP)
 {
     const int ww = G.ww;
     const int tid = threadIdx.x;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
     __syncthreads();
     const u32 S = *total_s;
     if (S == 0) return;
-    if (S > CL_CAP) {
+    if (S > cap) {
         // dense strip: same algorithm in global memory, restricted to this strip's rows
         CL_FOR_WORDS(r, j, i) {
             u64 st = lbits[i] & ~(lbits[i] << 1);

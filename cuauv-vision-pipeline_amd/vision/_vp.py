@@ -41,6 +41,16 @@ class ChainBuffers(C.Structure):
                 ("stats", C.c_void_p), ("centroids", C.c_void_p), ("nlabels", C.c_void_p)]
 
 
+class ContourDesc(C.Structure):
+    _fields_ = [("source", C.c_int32), ("mode", C.c_int32), ("method", C.c_int32), ("max_contours", C.c_int32),
+                ("max_points", C.c_int64)]
+
+
+class ContourBuffers(C.Structure):
+    _fields_ = [("info", C.c_void_p), ("counts", C.c_void_p), ("offsets", C.c_void_p), ("is_hole", C.c_void_p),
+                ("points", C.c_void_p)]
+
+
 _lib = None
 _lock = threading.Lock()
 _ctxs = {}
@@ -74,6 +84,10 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
     "vp_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
+    "vp_chain_run_contours": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.POINTER(ContourDesc),
+                                        C.POINTER(ContourBuffers), C.c_int]),
+    "vp_chain_run_contours_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.POINTER(ContourDesc),
+                                             C.POINTER(ContourBuffers), C.c_int]),
     "vp_chain_algorithmic_bytes": (C.c_uint64, [C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
     "vp_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vp_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -167,6 +181,13 @@ class Context:
     def chain_run_host(self, desc, bufs, n):
         check(lib().vp_chain_run_host(self.handle, C.byref(desc), C.byref(bufs), int(n)), self.handle)
 
+    def chain_run_contours(self, desc, bufs, cdesc, cbufs, n):
+        check(lib().vp_chain_run_contours(self.handle, C.byref(desc), C.byref(bufs), C.byref(cdesc), C.byref(cbufs), int(n)), self.handle)
+
+    def chain_run_contours_host(self, desc, bufs, cdesc, cbufs, n):
+        check(lib().vp_chain_run_contours_host(self.handle, C.byref(desc), C.byref(bufs), C.byref(cdesc), C.byref(cbufs), int(n)),
+              self.handle)
+
 
 def default_context(device=0):
     """Per-(thread, device) context: ModuleBase runs process() on a non-main thread (core/base.py:701-703)."""
@@ -223,3 +244,37 @@ def make_chain_desc(width, height, color_mode, lo, hi, morph=(), ccl=1, numberin
         d.morph_iter[i] = int(m[3]) if len(m) > 3 else 1
     d.ccl, d.numbering, d.max_labels = int(ccl), int(numbering), int(max_labels)
     return d
+
+
+def make_contour_desc(source="cleaned", mode=0, method=2, max_contours=64, max_points=8192):
+    d = ContourDesc()
+    d.source = {"cleaned": 1, "threshed": 2}[source] if isinstance(source, str) else int(source)
+    d.mode, d.method, d.max_contours, d.max_points = int(mode), int(method), int(max_contours), int(max_points)
+    return d
+
+
+def contour_arrays(alloc, n, cdesc):
+    """(dict of numpy arrays, ContourBuffers) for n frames; alloc(shape, dtype) -> array (plain or pinned)."""
+    mc, mp = int(cdesc.max_contours), int(cdesc.max_points)
+    arrs = {"info": alloc((n, 2), np.int32), "counts": alloc((n, mc), np.int32), "offsets": alloc((n, mc), np.int32),
+            "is_hole": alloc((n, mc), np.uint8), "points": alloc((n, mp, 2), np.int32)}
+    b = ContourBuffers()
+    for k, a in arrs.items():
+        setattr(b, k, a.ctypes.data)
+    return arrs, b
+
+
+def contour_lists(arrs, cdesc):
+    """Per frame: (tuple of (N,1,2) int32 contours in cv2's order = newest first, uint8 hole flags), or None for a frame whose
+    contours did not fit the capacities (arrs["info"][f] then tells the sizes needed)."""
+    out = []
+    mc, mp = int(cdesc.max_contours), int(cdesc.max_points)
+    for f in range(arrs["info"].shape[0]):
+        k, npts = int(arrs["info"][f, 0]), int(arrs["info"][f, 1])
+        if k > mc or npts > mp:
+            out.append(None)
+            continue
+        cnt, off, pts = arrs["counts"][f], arrs["offsets"][f], arrs["points"][f]
+        cs = tuple(pts[off[i]:off[i] + cnt[i]].reshape(-1, 1, 2).copy() for i in range(k - 1, -1, -1))
+        out.append((cs, arrs["is_hole"][f, :k][::-1].copy()))
+    return out

@@ -7,7 +7,10 @@ from vision import _vp
 
 
 def run_chain(frames, color_mode, lo, hi, morph=(), ccl=1, numbering=_vp.CCL_BLOCK2X2, max_labels=256,
-              want=("threshed", "cleaned", "labels", "stats")):
+              want=("threshed", "cleaned", "labels", "stats"), contours=None):
+    """contours: None, or a dict for _vp.make_contour_desc (source "cleaned" | "threshed", mode, method, max_contours,
+    max_points): out["contours"][f] = (contours in cv2 order, hole flags) as utils/feature.py:5-40 would return for frame f;
+    capacities grow and the call repeats when a frame needs more."""
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     if frames.ndim == 3:
         frames = frames[None]
@@ -36,7 +39,19 @@ def run_chain(frames, color_mode, lo, hi, morph=(), ccl=1, numbering=_vp.CCL_BLO
         out["nlabels"] = np.zeros((n,), np.int32)
         bufs.nlabels = out["nlabels"].ctypes.data
     ctx = _vp.default_context()
-    ctx.chain_run_host(desc, bufs, n)
+    if contours is None:
+        ctx.chain_run_host(desc, bufs, n)
+        return out
+    cdesc = _vp.make_contour_desc(**contours)
+    while True:
+        arrs, cb = _vp.contour_arrays(lambda shape, dt: np.zeros(shape, dt), n, cdesc)
+        ctx.chain_run_contours_host(desc, bufs, cdesc, cb, n)
+        need_c, need_p = int(arrs["info"][:, 0].max()), int(arrs["info"][:, 1].max())
+        if need_c <= cdesc.max_contours and need_p <= cdesc.max_points:
+            break
+        cdesc.max_contours = max(cdesc.max_contours, 2 * need_c)
+        cdesc.max_points = max(cdesc.max_points, 2 * need_p)
+    out["contours"] = _vp.contour_lists(arrs, cdesc)
     return out
 
 
@@ -47,7 +62,7 @@ class ChainRunner:
     6.2 MB/frame upload; full masks + labels add 12.4 MB/frame of download."""
 
     def __init__(self, n, height, width, color_mode, lo, hi, morph=(), ccl=1, numbering=_vp.CCL_BLOCK2X2, max_labels=256,
-                 want=("stats",), device=0):
+                 want=("stats",), device=0, contours=None):
         self.ctx = _vp.Context(device)
         self.n, self.h, self.w = int(n), int(height), int(width)
         self.desc = _vp.make_chain_desc(width, height, color_mode, lo, hi, morph, ccl, numbering, max_labels)
@@ -64,6 +79,15 @@ class ChainRunner:
                 self.out[name] = _vp.pinned_empty(self.ctx, shape, dt)
                 setattr(self.bufs, name, self.out[name].ctypes.data)
 
+        self.cdesc = None
+        if contours is not None:
+            self.cdesc = _vp.make_contour_desc(**contours)
+            self.carrs, self.cbufs = _vp.contour_arrays(lambda shape, dt: _vp.pinned_empty(self.ctx, shape, dt), n, self.cdesc)
+
     def run(self):
-        self.ctx.chain_run_host(self.desc, self.bufs, self.n)
+        if self.cdesc is None:
+            self.ctx.chain_run_host(self.desc, self.bufs, self.n)
+        else:
+            self.ctx.chain_run_contours_host(self.desc, self.bufs, self.cdesc, self.cbufs, self.n)
+            self.out["contours"] = _vp.contour_lists(self.carrs, self.cdesc)   # None where a frame exceeded the capacities
         return self.out

@@ -171,6 +171,36 @@ int vp_chain_run_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buf
  * written + 4 B/px labels), for roofline accounting. */
 uint64_t vp_chain_algorithmic_bytes(const vp_chain_desc* desc, const vp_chain_buffers* bufs, int n_frames);
 
+/* ---- chain + contours for the whole batch ------------------------------------------------
+ * What modules/red_buoy.py:36-38 (`outer_contours(cleaned)`) and modules/bins.py:27 (`outer_contours`
+ * after the morphology) do per frame, for n frames in one launch sequence: the chain above, then
+ * cv2.findContours semantics (utils/feature.py:5-40) on the cleaned or the threshold mask. */
+typedef struct vp_contour_desc {
+    int32_t source;        /* 1 = the cleaned mask, 2 = the threshold mask */
+    int32_t mode;          /* VP_RETR_EXTERNAL or VP_RETR_LIST */
+    int32_t method;        /* VP_CHAIN_APPROX_NONE or VP_CHAIN_APPROX_SIMPLE */
+    int32_t max_contours;  /* capacity per frame */
+    int64_t max_points;    /* capacity per frame */
+} vp_contour_desc;
+
+typedef struct vp_contour_buffers {  /* device pointers (vp_chain_run_contours) / host pointers (.._host) */
+    int32_t* info;         /* (n,2): contours found in the frame; points of the contours that fit */
+    int32_t* counts;       /* (n,max_contours) points per contour, in discovery order = raster order of
+                              the start pixel; cv2 returns the reverse order */
+    int32_t* offsets;      /* (n,max_contours) first point of the contour within the frame's point list */
+    uint8_t* is_hole;      /* (n,max_contours) */
+    int32_t* points;       /* (n,max_points,2) (x,y) */
+} vp_contour_buffers;
+
+/* Contours beyond max_contours are counted in info[.][0] but not traced; a contour whose points
+ * would pass max_points is skipped (info[.][1] still counts them), so a caller can repeat with
+ * larger capacities.  Enqueues and returns without synchronising. */
+int vp_chain_run_contours(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* dev, const vp_contour_desc* cdesc,
+                          const vp_contour_buffers* cdev, int n_frames);
+/* Host buffers: H2D, chain, contours, D2H, synchronised on return. */
+int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* host, const vp_contour_desc* cdesc,
+                               const vp_contour_buffers* chost, int n_frames);
+
 /* ---- device memory helpers (so a host program needs no HIP binding of its own) --------- */
 int vp_dev_alloc(vp_ctx* ctx, size_t bytes, void** dev_ptr);
 int vp_dev_free(vp_ctx* ctx, void* dev_ptr);

@@ -194,3 +194,47 @@ def test_full_size_frame_properties(vp, oracle):
         assert all(tuple(p) in ia for p in b)
     noise = F.random_mask(rng, 1080, 1920, 0.5)
     _check(vp, oracle, noise, 1, 2)
+
+
+@pytest.mark.parametrize("source,mode", [("cleaned", 0), ("threshed", 1)])
+def test_chain_with_contours_batch(vp, oracle, source, mode):
+    """vp_chain_run_contours_host: the whole red_buoy body (modules/red_buoy.py:21-38) for a batch - per frame the same
+    contours as the oracle's chain followed by its border following; more frames than one contour pass (16) handles."""
+    from vision import _vp
+    from vision.utils import chain
+    n, h, w = 19, 144, 256
+    frames = np.stack([F.s1_buoy(i, w, h) if i % 3 else F.s2_bins(i, w, h) for i in range(n)])
+    morph = ((_vp.MORPH_OPEN, 5, 5), (_vp.MORPH_CLOSE, 5, 5))
+    out = chain.run_chain(frames, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), morph, ccl=1, want=("cleaned", "threshed", "stats"),
+                          contours=dict(source=source, mode=mode, method=2, max_contours=4, max_points=64))   # forces a capacity retry
+    assert len(out["contours"]) == n
+    k = np.ones((5, 5), np.uint8)
+    for f in range(n):
+        th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(frames[f])[:, :, 1]), 150, 255)
+        cl = oracle.morph(oracle.CLOSE, oracle.morph(oracle.OPEN, th, k, fast=True), k, fast=True)
+        assert np.array_equal(out["threshed"][f], th) and np.array_equal(out["cleaned"][f], cl)
+        exp, eh = oracle.find_contours(cl if source == "cleaned" else th, mode, 2, with_holes=True)
+        got, gh = out["contours"][f]
+        assert _same(got, exp), f
+        assert np.array_equal(gh, eh)
+    # without CCL and without mask outputs the contours are the same
+    out2 = chain.run_chain(frames, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), morph, ccl=0, want=(),
+                           contours=dict(source=source, mode=mode, method=2, max_contours=256, max_points=1 << 14))
+    for f in range(n):
+        assert _same(out2["contours"][f][0], out["contours"][f][0])
+
+
+def test_chain_runner_contours_pinned(vp, oracle):
+    from vision import _vp
+    from vision.utils import chain
+    n, h, w = 3, 144, 256
+    r = chain.ChainRunner(n, h, w, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), ((_vp.MORPH_OPEN, 3, 3),), ccl=0, want=(),
+                          contours=dict(source="cleaned", mode=0, method=1, max_contours=128, max_points=1 << 14))
+    for i in range(n):
+        r.input[i] = F.s1_buoy(i, w, h)
+    out = r.run()
+    k = np.ones((3, 3), np.uint8)
+    for f in range(n):
+        th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(r.input[f])[:, :, 1]), 150, 255)
+        cl = oracle.morph(oracle.OPEN, th, k, fast=True)
+        assert _same(out["contours"][f][0], oracle.find_contours(cl, 0, 1))
