@@ -197,10 +197,12 @@ def test_full_size_frame_properties(vp, oracle):
 
 
 @pytest.mark.parametrize("source,mode", [("cleaned", 0), ("threshed", 1)])
-def test_chain_with_contours_batch(vp, oracle, source, mode):
+def test_chain_with_contours_batch(vp, oracle, source, mode, monkeypatch):
     """vp_chain_run_contours_host: the whole red_buoy body (modules/red_buoy.py:21-38) for a batch - per frame the same
-    contours as the oracle's chain followed by its border following; more frames than one contour pass (16) handles."""
+    contours as the oracle's chain followed by its border following; the scratch budget is set so low that the batch takes
+    several contour passes."""
     from vision import _vp
+    monkeypatch.setenv("VP_CT_SCRATCH_MB", "6")
     from vision.utils import chain
     n, h, w = 19, 144, 256
     frames = np.stack([F.s1_buoy(i, w, h) if i % 3 else F.s2_bins(i, w, h) for i in range(n)])
