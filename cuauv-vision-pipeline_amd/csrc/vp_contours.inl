@@ -607,7 +607,9 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     VP_HIP(ctx, hipMemsetAsync(maps3, 0, 3 * mstride * 8, s));
     vp_prof_scope ps(ctx, VPK_OTHER);
     const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
-    const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, 4096), (unsigned)n);
+    // heads per frame are not known on the host: a fixed number of blocks per frame walks the head list (a real mask has a few
+    // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
+    const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
     hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum);
     hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
     hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gb, bg_parent, outside);
