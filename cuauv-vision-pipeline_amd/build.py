@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
-VP_SOURCES = ["vp_api.hip", "vp_color.hip", "vp_morph.hip", "vp_ccl.hip", "vp_tables.cpp"]
+VP_SOURCES = ["vp_api.hip", "vp_color.hip", "vp_morph.hip", "vp_ccl.hip", "vp_balance.hip", "vp_tables.cpp"]
 
 
 def _stale(target, deps):
@@ -54,8 +54,22 @@ def build_libcmf(force=False, verbose=False):
     return out
 
 
+def build_libbalance(force=False, verbose=False):
+    """libauv-color-balance.so: the reference's process_frame entry (color_balance.hpp:9-14) bound to libvp."""
+    out = os.path.join(LIBDIR, "libauv-color-balance.so")
+    src = os.path.join(CSRC, "color_balance_shim.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "color_balance_c.h"), os.path.join(HERE, "..", "include", "vp.h"), os.path.join(LIBDIR, "libvp.so")]
+    if not force and not _stale(out, deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", src, "-o", out, "-L" + LIBDIR, "-lvp", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force=False, verbose=False):
-    return [build_libvp(force, verbose), build_libcmf(force, verbose)]
+    return [build_libvp(force, verbose), build_libcmf(force, verbose), build_libbalance(force, verbose)]
 
 
 if __name__ == "__main__":

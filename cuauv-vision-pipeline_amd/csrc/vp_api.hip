@@ -444,7 +444,7 @@ int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src, size_t src_stride
 {
     VP_TRY(check_ctx(ctx));
     if (!src || w <= 0 || h <= 0 || h > 65535) return vp_fail(ctx, VP_ERR_INVALID, "vp_cvt_color_u8 arguments");
-    if (code < VP_BGR2LAB || code > VP_GRAY2BGR) return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
+    if (code < VP_BGR2LAB || code > VP_HSV2BGR) return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
     const int scn = code == VP_GRAY2BGR ? 1 : 3, dcn = code == VP_BGR2GRAY ? 1 : 3;
     if (src_stride < (size_t)w * scn) return vp_fail(ctx, VP_ERR_INVALID, "src_stride");
     const size_t npx = (size_t)w * h;
@@ -458,11 +458,41 @@ int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src, size_t src_stride
     for (int c = 0; c < 3; c++)
         if (hp[c]) { dp[c] = (uint8_t*)vp_ws_take(ctx, npx); if (!dp[c]) return vp_fail(ctx, VP_ERR_NOMEM, "workspace"); }
     VP_TRY(h2d_rows(ctx, d_src, (size_t)w * scn, src, src_stride, (size_t)w * scn, h));
-    VP_TRY(vpk_cvt_color(ctx, code, d_src, (size_t)w * scn, w, h, dst_i ? d_dst : nullptr, dp[0], dp[1], dp[2]));
+    if (code == VP_HSV2BGR) {
+        if (planes) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "HSV2BGR: split planes");
+        VP_TRY(vpk_hsv2bgr(ctx, d_src, npx, d_dst));
+    } else {
+        VP_TRY(vpk_cvt_color(ctx, code, d_src, (size_t)w * scn, w, h, dst_i ? d_dst : nullptr, dp[0], dp[1], dp[2]));
+    }
     if (dst_i) VP_TRY(d2h(ctx, dst_i, d_dst, npx * dcn));
     for (int c = 0; c < 3; c++)
         if (hp[c]) VP_TRY(d2h(ctx, hp[c], dp[c], npx));
     return vp_synchronize(ctx);
+}
+
+int vp_color_balance_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int flags, int hblocks, int vblocks, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || hblocks <= 0 || vblocks <= 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_color_balance_u8 arguments");
+    const size_t npx = (size_t)w * h;
+    const size_t tiles = (flags & VP_CB_EQUALIZE_RGB) ? (size_t)hblocks * vblocks : 1;
+    if (tiles > 1024) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: too many tiles");
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx * 3) + vp_balance_ws_bytes(1, (int)tiles) + 4096));
+    TAKE(d_img, uint8_t*, npx * 3);
+    VP_TRY(h2d(ctx, d_img, src, npx * 3));
+    VP_TRY(vpk_color_balance(ctx, d_img, d_img, w, h, 1, flags, hblocks, vblocks));
+    VP_TRY(d2h(ctx, dst, d_img, npx * 3));
+    return vp_synchronize(ctx);
+}
+
+int vp_color_balance_dev(vp_ctx* ctx, const uint8_t* src, uint8_t* dst, int w, int h, int n, int flags, int hblocks, int vblocks)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || n <= 0 || hblocks <= 0 || vblocks <= 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_color_balance_dev arguments");
+    const size_t tiles = (flags & VP_CB_EQUALIZE_RGB) ? (size_t)hblocks * vblocks : 1;
+    if (tiles > 1024) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: too many tiles");
+    VP_TRY(vp_ws_reserve(ctx, vp_balance_ws_bytes(n, (int)tiles) + 4096));
+    return vpk_color_balance(ctx, src, dst, w, h, n, flags, hblocks, vblocks);
 }
 
 int vp_cvt_bgr2lab_f32(vp_ctx* ctx, const float* src, int w, int h, float* dst)

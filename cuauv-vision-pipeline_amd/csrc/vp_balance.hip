@@ -1,0 +1,414 @@
+// Colour balance on the GPU: utils/color_correction/color_balance.cpp:343-780 `process_frame` (called by
+// modules/color_balance.py:93-110 `balance`, modules/preprocessor.py:87-88) and the 8-bit HSV -> BGR conversion it uses.
+//
+// The reference walks the frame nine times on one core (split, three histogram passes, clips, running means, gains, merge,
+// cvtColor, two more histogram passes, stretch, cvtColor back, split, merge).  Every per-pixel step of it is a function of
+// the pixel's own channel values once a handful of frame statistics are known, so here a frame is read three times and
+// written once:
+//   k_cb_hist      B/G/R histograms per equalisation tile (one pass)
+//   k_cb_plan1     per frame: percentile clip bounds, channel means, per-tile colour-cast gains, RGB contrast stretch
+//                  -> one 256-entry table per (tile, channel)             (double precision, one block per frame)
+//   k_cb_hsvhist   table lookup -> BGR2HSV (OpenCV's integer form) -> S and V histograms (second pass)
+//   k_cb_plan2     S / V percentile bounds -> stretch tables
+//   k_cb_apply     table lookup -> BGR2HSV -> S/V tables -> HSV2BGR (OpenCV's float form) -> store (third pass)
+// 12 B/px of algorithmic traffic with the HSV stage (3 reads + 1 write of the frame), 9 B/px without it.
+//
+// The reference's running mean (avg += (x - avg) / count, cpp:452-467) is replaced by the exact sum / count: it differs by
+// rounding noise of ~1e-13 relative, which can only matter where gain * value lands within that distance of an integer
+// (never observed).
+#include "vp_internal.h"
+
+#define CB_MAX_TILES 1024
+
+struct cb_params {
+    int w, h, n;
+    int flags;
+    int hb, vb;      // tiles per row / column (already validated: they divide w / h)
+    int bw, bh;      // tile size
+};
+
+struct HsvTab { int32_t sdiv[256]; int32_t hdiv[256]; };
+
+__device__ __forceinline__ void cb_bgr2hsv(const HsvTab& t, int b, int g, int r, int& H, int& S, int& V)
+{
+    const int v = max(max(b, g), r), vmin = min(min(b, g), r), diff = v - vmin;
+    S = (diff * t.sdiv[v] + 2048) >> 12;
+    int hh = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    hh = (hh * t.hdiv[diff] + 2048) >> 12;
+    hh += hh < 0 ? 180 : 0;
+    H = hh < 0 ? 0 : (hh > 255 ? 255 : hh);
+    V = v;
+}
+
+__device__ __forceinline__ int cb_sat_round(float x)   // cv::saturate_cast<uchar>(float): round half to even, clamp
+{
+    const int v = (int)rintf(x);
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// OpenCV color_hsv.simd.hpp HSV2RGB_b -> HSV2RGB_f, vector arithmetic form (v - v*s, v - (v*s)*h, (v - v*s) + (v*s)*h), hrange 180.
+// Built with -ffp-contract=off: every product and sum rounds separately, as the universal intrinsics do.
+__device__ __forceinline__ void cb_hsv2bgr(int H, int S, int V, int& b, int& g, int& r)
+{
+    float h = (float)H * (6.f / 180.f);
+    const float s = (float)S * (1.f / 255.f), v = (float)V * (1.f / 255.f);
+    const float pre = truncf(h);
+    h = h - pre;
+    const float vs = v * s;
+    const float vsh = vs * h;
+    const float t1 = v - vs, t2 = v - vsh, t3 = (v - vs) + vsh;
+    float sec = truncf(pre * (1.0f / 6.0f));
+    sec = pre - sec * 6.0f;
+    const int sector = (int)sec;
+    // (b, g, r) = tab[{1,3,0}, {1,0,2}, {3,0,1}, {0,2,1}, {0,1,3}, {2,1,0}][sector], tab = {v, t1, t2, t3}
+    float fb, fg, fr;
+    switch (sector) {
+    case 0: fb = t1; fg = t3; fr = v; break;
+    case 1: fb = t1; fg = v; fr = t2; break;
+    case 2: fb = t3; fg = v; fr = t1; break;
+    case 3: fb = v; fg = t2; fr = t1; break;
+    case 4: fb = v; fg = t1; fr = t3; break;
+    default: fb = t2; fg = t1; fr = v; break;
+    }
+    b = cb_sat_round(fb * 255.f);
+    g = cb_sat_round(fg * 255.f);
+    r = cb_sat_round(fr * 255.f);
+}
+
+__device__ __forceinline__ int cb_tile_of(const cb_params& P, size_t pix_in_frame)
+{
+    const int y = (int)(pix_in_frame / (size_t)P.w), x = (int)(pix_in_frame - (size_t)y * P.w);
+    return (y / P.bh) * P.hb + x / P.bw;
+}
+
+// ---- pass 1: histograms -------------------------------------------------------------------------------------------------
+// grid (blocks, n); a block walks groups of 4 pixels (12 bytes = 3 dwords) of its frame.  hist: [n][tiles][3][256]
+template <bool TILED>
+__global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src, cb_params P, u32* __restrict__ hist)
+{
+    __shared__ u32 lh[4][3][256];   // one copy per wave: natural images concentrate on few bins
+    const int f = blockIdx.y, tid = threadIdx.x, wv = tid >> 6;
+    const size_t npx = (size_t)P.w * P.h;
+    const uint8_t* fs = src + (size_t)f * npx * 3;
+    u32* fh = hist + (size_t)f * P.hb * P.vb * 768;
+    if (!TILED) {
+        for (int i = tid; i < 4 * 768; i += 256) (&lh[0][0][0])[i] = 0;
+        __syncthreads();
+    }
+    const size_t ngroups = npx / 4;
+    const u32* s32 = reinterpret_cast<const u32*>(fs);
+    for (size_t gidx = (size_t)blockIdx.x * 256 + tid; gidx < ngroups; gidx += (size_t)gridDim.x * 256) {
+        const u32 a = s32[3 * gidx], b = s32[3 * gidx + 1], c = s32[3 * gidx + 2];
+        const u32 px[4][3] = {{a & 255, (a >> 8) & 255, (a >> 16) & 255}, {a >> 24, b & 255, (b >> 8) & 255},
+                              {(b >> 16) & 255, b >> 24, c & 255}, {(c >> 8) & 255, (c >> 16) & 255, c >> 24}};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (TILED) {
+                u32* th = fh + (size_t)cb_tile_of(P, 4 * gidx + k) * 768;
+                atomicAdd(th + px[k][0], 1u); atomicAdd(th + 256 + px[k][1], 1u); atomicAdd(th + 512 + px[k][2], 1u);
+            } else {
+                atomicAdd(&lh[wv][0][px[k][0]], 1u); atomicAdd(&lh[wv][1][px[k][1]], 1u); atomicAdd(&lh[wv][2][px[k][2]], 1u);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid < (int)(npx & 3)) {   // tail pixels of the frame
+        const size_t p = (npx & ~(size_t)3) + tid;
+        if (TILED) {
+            u32* th = fh + (size_t)cb_tile_of(P, p) * 768;
+            atomicAdd(th + fs[3 * p], 1u); atomicAdd(th + 256 + fs[3 * p + 1], 1u); atomicAdd(th + 512 + fs[3 * p + 2], 1u);
+        } else {
+            atomicAdd(&lh[wv][0][fs[3 * p]], 1u); atomicAdd(&lh[wv][1][fs[3 * p + 1]], 1u); atomicAdd(&lh[wv][2][fs[3 * p + 2]], 1u);
+        }
+    }
+    if (!TILED) {
+        __syncthreads();
+        for (int i = tid; i < 768; i += 256) {
+            const u32 v = (&lh[0][0][0])[i] + (&lh[1][0][0])[i] + (&lh[2][0][0])[i] + (&lh[3][0][0])[i];
+            if (v) atomicAdd(fh + i, v);
+        }
+    }
+}
+
+// ---- plan 1 -----------------------------------------------------------------------------------------------------------------
+// cpp:111-139 percentile_min_max on a histogram
+__device__ void cb_percentile(const u32* __restrict__ counts, size_t n, int& mn, int& mx)
+{
+    int low_bound = (int)(0.002f * (float)n);
+    int high_bound = (int)n - (int)(0.998f * (float)n);
+    mn = 0; mx = 255;
+    for (int i = 0; i < 256; i++) {
+        if (low_bound < (int)counts[i]) { mn = i; break; }
+        low_bound -= (int)counts[i];
+    }
+    for (int i = 255; i >= 0; i--) {
+        if (high_bound < (int)counts[i]) { mx = i; break; }
+        high_bound -= (int)counts[i];
+    }
+}
+__device__ __forceinline__ int cb_cast_u8(double v)   // (unsigned char)double as gcc/x86-64 does it: cvttsd2si (0x80000000 when out of range / NaN), low byte
+{
+    int i;
+    if (!(v > -2147483649.0 && v < 2147483648.0)) i = (int)0x80000000;
+    else i = (int)v;
+    return i & 0xff;
+}
+__device__ __forceinline__ int cb_constrain(double v) { return v < 0 ? 0 : (v > 255 ? 255 : cb_cast_u8(v)); }
+
+struct cb_plan {      // per frame, device
+    int lo[3], hi[3];             // B, G, R clip bounds (cpp:398-425)
+    double avg[3];                // channel means after clipping (cpp:427-429)
+    int s_lo, s_hi, v_lo, v_hi;   // cpp:619-629
+};
+
+// one block per frame.  lut: [n][tiles][3][256] u8 (B, G, R)
+__global__ __launch_bounds__(256) void k_cb_plan1(cb_params P, const u32* __restrict__ hist, cb_plan* __restrict__ plans, uint8_t* __restrict__ lut)
+{
+    __shared__ u32 gh[3][256];
+    __shared__ cb_plan pl;
+    __shared__ double tsum[3];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int tiles = P.hb * P.vb;
+    const size_t npx = (size_t)P.w * P.h;
+    const u32* fh = hist + (size_t)f * tiles * 768;
+    for (int i = tid; i < 768; i += 256) {
+        u32 s = 0;
+        for (int t = 0; t < tiles; t++) s += fh[(size_t)t * 768 + i];
+        (&gh[0][0])[i] = s;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        int mn = 255, mx = 0;
+        if (P.flags & VP_CB_EXTREMA_CLIPPING) cb_percentile(gh[tid], npx, mn, mx);
+        else {
+            for (int i = 0; i < 256; i++) if (gh[tid][i]) { mn = i; break; }
+            for (int i = 255; i >= 0; i--) if (gh[tid][i]) { mx = i; break; }
+        }
+        unsigned long long s = 0;
+        for (int i = 0; i < 256; i++) s += (unsigned long long)min(max(i, mn), mx) * gh[tid][i];
+        pl.lo[tid] = mn; pl.hi[tid] = mx;
+        pl.avg[tid] = (double)s / (double)npx;
+    }
+    __syncthreads();
+    // reference order of the triples is (r, g, b); channel index here is 0 B, 1 G, 2 R
+    const double b_avg = pl.avg[0], g_avg = pl.avg[1], r_avg = pl.avg[2];
+    // RGB contrast stretch (cpp:545-597): which channel is min / mid / max by mean, then three linear maps
+    double ratio[3] = {1, 1, 1};
+    int cmin[3] = {0, 0, 0};
+    if (P.flags & VP_CB_RGB_CONTRAST) {
+        int mxc, mdc, mnc;
+        if (r_avg > g_avg) {
+            if (r_avg > b_avg) { mxc = 2; if (g_avg > b_avg) { mdc = 1; mnc = 0; } else { mdc = 0; mnc = 1; } }
+            else { mxc = 0; mdc = 2; mnc = 1; }
+        } else {
+            if (g_avg > b_avg) { mxc = 1; if (r_avg > b_avg) { mdc = 2; mnc = 0; } else { mdc = 0; mnc = 2; } }
+            else { mxc = 0; mdc = 1; mnc = 2; }
+        }
+        const double desired_max = (double)((pl.hi[mnc] + pl.hi[mdc] + pl.hi[mxc]) / 3);
+        ratio[mnc] = (desired_max - pl.lo[mnc]) / (double)(pl.hi[mnc] - pl.lo[mnc]);
+        ratio[mdc] = (desired_max - 0.0) / (double)(pl.hi[mdc] - pl.lo[mdc]);
+        ratio[mxc] = (pl.hi[mxc] - 0.0) / (double)(pl.hi[mxc] - pl.lo[mxc]);
+        cmin[0] = pl.lo[0]; cmin[1] = pl.lo[1]; cmin[2] = pl.lo[2];
+    }
+    for (int t = 0; t < tiles; t++) {
+        // tile means of the clipped channels (cpp:452-467, exact form)
+        __syncthreads();
+        if (tid < 3) {
+            const u32* th = fh + (size_t)t * 768 + tid * 256;
+            unsigned long long s = 0, c = 0;
+            for (int i = 0; i < 256; i++) { s += (unsigned long long)min(max(i, pl.lo[tid]), pl.hi[tid]) * th[i]; c += th[i]; }
+            tsum[tid] = c ? (double)s / (double)c : 0.0;
+        }
+        __syncthreads();
+        double lb = tsum[0], lg = tsum[1], lr = tsum[2];
+        double gain[3] = {1, 1, 1};
+        if (P.flags & VP_CB_EQUALIZE_RGB) {
+            if (fabs(lr - r_avg) > r_avg / 6 || fabs(lb - b_avg) > b_avg / 6 || fabs(lg - g_avg) > g_avg / 6) { lr = r_avg; lb = b_avg; lg = g_avg; }
+            if (lr > lg && lr > lb) { gain[1] = lr / lg; gain[0] = lr / lb; }           // red cast: lift G and B
+            else if (lg > lr && lg > lb) { gain[2] = lg / lr; gain[0] = lg / lb; }      // green cast: lift R and B
+            else { gain[2] = lb / lr; gain[1] = lb / lg; }                              // blue cast (and ties): lift R and G
+        }
+        const bool red = lr > lg && lr > lb, green = !red && (lg > lr && lg > lb);
+        uint8_t* tl = lut + ((size_t)f * tiles + t) * 768;
+        for (int c = 0; c < 3; c++) {
+            int v = min(max(tid, pl.lo[c]), pl.hi[c]);   // clip (no-op without extrema clipping: the value lies inside)
+            if (P.flags & VP_CB_EQUALIZE_RGB) {
+                const bool lifted = red ? (c != 2) : (green ? (c != 1) : (c != 0));
+                if (lifted) {
+                    if (P.flags & VP_CB_ADAPTIVE_CAST) v = cb_constrain(v * (pow((255. - v) / 255., 0.25) * (gain[c] - 1.) + 1.));
+                    else v = cb_constrain(v * gain[c]);
+                }
+            }
+            if (P.flags & VP_CB_RGB_CONTRAST) v = cb_cast_u8((v - cmin[c]) * ratio[c]);
+            tl[c * 256 + tid] = (uint8_t)v;
+        }
+    }
+    if (tid == 0) { pl.s_lo = 0; pl.s_hi = 255; pl.v_lo = 0; pl.v_hi = 255; plans[f] = pl; }
+}
+
+// ---- pass 2: S / V histograms of the table-mapped frame ---------------------------------------------------------------------
+template <bool TILED>
+__global__ __launch_bounds__(256) void k_cb_hsvhist(const uint8_t* __restrict__ src, cb_params P, vp_tables tab, const uint8_t* __restrict__ lut,
+                                                    u32* __restrict__ svhist)
+{
+    __shared__ HsvTab ht;
+    __shared__ uint8_t ll[768];
+    __shared__ u32 lh[4][2][256];
+    const int f = blockIdx.y, tid = threadIdx.x, wv = tid >> 6;
+    const int tiles = P.hb * P.vb;
+    const size_t npx = (size_t)P.w * P.h;
+    const uint8_t* fs = src + (size_t)f * npx * 3;
+    const uint8_t* fl = lut + (size_t)f * tiles * 768;
+    ht.sdiv[tid] = tab.sdiv[tid]; ht.hdiv[tid] = tab.hdiv[tid];
+    for (int i = tid; i < 768; i += 256) ll[i] = fl[i];
+    for (int i = tid; i < 4 * 512; i += 256) (&lh[0][0][0])[i] = 0;
+    __syncthreads();
+    for (size_t p = (size_t)blockIdx.x * 256 + tid; p < npx; p += (size_t)gridDim.x * 256) {
+        int b = fs[3 * p], g = fs[3 * p + 1], r = fs[3 * p + 2];
+        if (TILED) { const uint8_t* tl = fl + (size_t)cb_tile_of(P, p) * 768; b = tl[b]; g = tl[256 + g]; r = tl[512 + r]; }
+        else { b = ll[b]; g = ll[256 + g]; r = ll[512 + r]; }
+        int H, S, V;
+        cb_bgr2hsv(ht, b, g, r, H, S, V);
+        atomicAdd(&lh[wv][0][S], 1u);
+        atomicAdd(&lh[wv][1][V], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < 512; i += 256) {
+        const u32 v = (&lh[0][0][0])[i] + (&lh[1][0][0])[i] + (&lh[2][0][0])[i] + (&lh[3][0][0])[i];
+        if (v) atomicAdd(svhist + (size_t)f * 512 + i, v);
+    }
+}
+
+// S / V clip bounds and stretch tables (cpp:619-660).  svlut: [n][2][256]
+__global__ __launch_bounds__(256) void k_cb_plan2(cb_params P, const u32* __restrict__ svhist, cb_plan* __restrict__ plans, uint8_t* __restrict__ svlut)
+{
+    __shared__ int bounds[4];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const size_t npx = (size_t)P.w * P.h;
+    if (tid < 2) cb_percentile(svhist + (size_t)f * 512 + tid * 256, npx, bounds[2 * tid], bounds[2 * tid + 1]);
+    __syncthreads();
+    for (int c = 0; c < 2; c++) {
+        const int lo = bounds[2 * c], hi = bounds[2 * c + 1];
+        int v = min(max(tid, lo), hi);
+        if (hi != lo) v = ((v - lo) * 255) / (hi - lo);   // the reference divides by zero here (SIGFPE); the channel stays as clipped
+        svlut[(size_t)f * 512 + c * 256 + tid] = (uint8_t)v;
+    }
+    if (tid == 0) { plans[f].s_lo = bounds[0]; plans[f].s_hi = bounds[1]; plans[f].v_lo = bounds[2]; plans[f].v_hi = bounds[3]; }
+}
+
+// ---- pass 3: apply --------------------------------------------------------------------------------------------------------
+template <bool TILED, bool HSV>
+__global__ __launch_bounds__(256) void k_cb_apply(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, cb_params P, vp_tables tab,
+                                                  const uint8_t* __restrict__ lut, const uint8_t* __restrict__ svlut)
+{
+    __shared__ HsvTab ht;
+    __shared__ uint8_t ll[768];
+    __shared__ uint8_t sl[512];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int tiles = P.hb * P.vb;
+    const size_t npx = (size_t)P.w * P.h;
+    const uint8_t* fs = src + (size_t)f * npx * 3;
+    uint8_t* fd = dst + (size_t)f * npx * 3;
+    const uint8_t* fl = lut + (size_t)f * tiles * 768;
+    if (HSV) {
+        ht.sdiv[tid] = tab.sdiv[tid]; ht.hdiv[tid] = tab.hdiv[tid];
+        for (int i = tid; i < 512; i += 256) sl[i] = svlut[(size_t)f * 512 + i];
+    }
+    for (int i = tid; i < 768; i += 256) ll[i] = fl[i];
+    __syncthreads();
+    const size_t ngroups = npx / 4;
+    const u32* s32 = reinterpret_cast<const u32*>(fs);
+    u32* d32 = reinterpret_cast<u32*>(fd);
+    auto one = [&](size_t p, int& b, int& g, int& r) {
+        if (TILED) { const uint8_t* tl = fl + (size_t)cb_tile_of(P, p) * 768; b = tl[b]; g = tl[256 + g]; r = tl[512 + r]; }
+        else { b = ll[b]; g = ll[256 + g]; r = ll[512 + r]; }
+        if (HSV) {
+            int H, S, V;
+            cb_bgr2hsv(ht, b, g, r, H, S, V);
+            cb_hsv2bgr(H, sl[S], sl[256 + V], b, g, r);
+        }
+    };
+    for (size_t gidx = (size_t)blockIdx.x * 256 + tid; gidx < ngroups; gidx += (size_t)gridDim.x * 256) {
+        const u32 a = s32[3 * gidx], bb = s32[3 * gidx + 1], c = s32[3 * gidx + 2];
+        int px[4][3] = {{(int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255)}, {(int)(a >> 24), (int)(bb & 255), (int)((bb >> 8) & 255)},
+                        {(int)((bb >> 16) & 255), (int)(bb >> 24), (int)(c & 255)}, {(int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24)}};
+#pragma unroll
+        for (int k = 0; k < 4; k++) one(4 * gidx + k, px[k][0], px[k][1], px[k][2]);
+        d32[3 * gidx] = (u32)px[0][0] | ((u32)px[0][1] << 8) | ((u32)px[0][2] << 16) | ((u32)px[1][0] << 24);
+        d32[3 * gidx + 1] = (u32)px[1][1] | ((u32)px[1][2] << 8) | ((u32)px[2][0] << 16) | ((u32)px[2][1] << 24);
+        d32[3 * gidx + 2] = (u32)px[2][2] | ((u32)px[3][0] << 8) | ((u32)px[3][1] << 16) | ((u32)px[3][2] << 24);
+    }
+    if (blockIdx.x == 0 && tid < (int)(npx & 3)) {
+        const size_t p = (npx & ~(size_t)3) + tid;
+        int b = fs[3 * p], g = fs[3 * p + 1], r = fs[3 * p + 2];
+        one(p, b, g, r);
+        fd[3 * p] = (uint8_t)b; fd[3 * p + 1] = (uint8_t)g; fd[3 * p + 2] = (uint8_t)r;
+    }
+}
+
+// HSV -> BGR as an operator (cv2.cvtColor(COLOR_HSV2BGR), 8-bit): packed rows
+__global__ __launch_bounds__(256) void k_hsv2bgr(const uint8_t* __restrict__ src, size_t npx, uint8_t* __restrict__ dst)
+{
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npx; p += (size_t)gridDim.x * 256) {
+        int b, g, r;
+        cb_hsv2bgr(src[3 * p], src[3 * p + 1], src[3 * p + 2], b, g, r);
+        dst[3 * p] = (uint8_t)b; dst[3 * p + 1] = (uint8_t)g; dst[3 * p + 2] = (uint8_t)r;
+    }
+}
+
+int vpk_hsv2bgr(vp_ctx* ctx, const uint8_t* d_src, size_t npx, uint8_t* d_dst)
+{
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    const unsigned blocks = (unsigned)std::min<size_t>((npx + 255) / 256, (size_t)ctx->num_cu * 16);
+    hipLaunchKernelGGL(k_hsv2bgr, dim3(blocks), dim3(256), 0, ctx->stream, d_src, npx, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+size_t vp_balance_ws_bytes(int n, int tiles) { return vp_align((size_t)n * tiles * 768 * 4) + vp_align((size_t)n * 512 * 4) + vp_align((size_t)n * tiles * 768) +
+                                                      vp_align((size_t)n * 512) + vp_align(sizeof(cb_plan) * (size_t)n) + 4096; }
+
+// d_src / d_dst: (n, h, w, 3) packed; d_dst may equal d_src.  Frames must start 4-byte aligned (w*h*3 % 4 == 0 or n == 1).
+int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int flags, int hblocks, int vblocks)
+{
+    if (flags & VP_CB_HSI_CONTRAST) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: hsi_contrast_correct is not implemented");
+    if (hblocks <= 0 || vblocks <= 0) return vp_fail(ctx, VP_ERR_INVALID, "colour balance: tiles");
+    if ((flags & VP_CB_EQUALIZE_RGB) && (w % hblocks || h % vblocks))
+        return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: tiles must divide the frame (the reference wraps rows otherwise)");
+    if (!(flags & VP_CB_EQUALIZE_RGB)) { hblocks = 1; vblocks = 1; }
+    const int tiles = hblocks * vblocks;
+    if (tiles > CB_MAX_TILES) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: too many tiles");
+    const size_t npx = (size_t)w * h;
+    if (n > 1 && (npx * 3) % 4) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: batched frames must be 4-byte aligned");
+    cb_params P = {w, h, n, flags, hblocks, vblocks, w / hblocks, h / vblocks};
+    u32* hist = (u32*)vp_ws_take(ctx, (size_t)n * tiles * 768 * 4);
+    u32* svhist = (u32*)vp_ws_take(ctx, (size_t)n * 512 * 4);
+    uint8_t* lut = (uint8_t*)vp_ws_take(ctx, (size_t)n * tiles * 768);
+    uint8_t* svlut = (uint8_t*)vp_ws_take(ctx, (size_t)n * 512);
+    cb_plan* plans = (cb_plan*)vp_ws_take(ctx, sizeof(cb_plan) * (size_t)n);
+    if (!hist || !svhist || !lut || !svlut || !plans) return vp_fail(ctx, VP_ERR_NOMEM, "colour balance workspace");
+    hipStream_t s = ctx->stream;
+    const bool tiled = tiles > 1, hsv = (flags & VP_CB_HSV_CONTRAST) != 0;
+    // enough blocks to fill the chip, few enough that the per-block table loads and histogram flushes stay small
+    const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((npx / 4 + 255) / 256, std::max<size_t>(8, (size_t)ctx->num_cu * 8 / (size_t)n)));
+    const dim3 grid(bx, (unsigned)n);
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    VP_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)n * tiles * 768 * 4, s));
+    if (tiled) hipLaunchKernelGGL((k_cb_hist<true>), grid, dim3(256), 0, s, d_src, P, hist);
+    else hipLaunchKernelGGL((k_cb_hist<false>), grid, dim3(256), 0, s, d_src, P, hist);
+    hipLaunchKernelGGL(k_cb_plan1, dim3((unsigned)n), dim3(256), 0, s, P, hist, plans, lut);
+    if (hsv) {
+        VP_HIP(ctx, hipMemsetAsync(svhist, 0, (size_t)n * 512 * 4, s));
+        if (tiled) hipLaunchKernelGGL((k_cb_hsvhist<true>), grid, dim3(256), 0, s, d_src, P, ctx->tab, lut, svhist);
+        else hipLaunchKernelGGL((k_cb_hsvhist<false>), grid, dim3(256), 0, s, d_src, P, ctx->tab, lut, svhist);
+        hipLaunchKernelGGL(k_cb_plan2, dim3((unsigned)n), dim3(256), 0, s, P, svhist, plans, svlut);
+    }
+    if (tiled) {
+        if (hsv) hipLaunchKernelGGL((k_cb_apply<true, true>), grid, dim3(256), 0, s, d_src, d_dst, P, ctx->tab, lut, svlut);
+        else hipLaunchKernelGGL((k_cb_apply<true, false>), grid, dim3(256), 0, s, d_src, d_dst, P, ctx->tab, lut, svlut);
+    } else {
+        if (hsv) hipLaunchKernelGGL((k_cb_apply<false, true>), grid, dim3(256), 0, s, d_src, d_dst, P, ctx->tab, lut, svlut);
+        else hipLaunchKernelGGL((k_cb_apply<false, false>), grid, dim3(256), 0, s, d_src, d_dst, P, ctx->tab, lut, svlut);
+    }
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

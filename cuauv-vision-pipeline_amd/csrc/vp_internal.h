@@ -94,6 +94,11 @@ int vpk_bgr2lab_f32(vp_ctx* ctx, const float* d_src, size_t npx, float* d_dst);
 int vpk_color_distance(vp_ctx* ctx, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, size_t npx,
                        const float* color, const float* wts, int skipmask, float* d2, uint8_t* sq);
 
+// ---- colour balance (vp_balance.hip) ----------------------------------------------------------
+int vpk_hsv2bgr(vp_ctx* ctx, const uint8_t* d_src, size_t npx, uint8_t* d_dst);
+size_t vp_balance_ws_bytes(int n, int tiles);
+int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int flags, int hblocks, int vblocks);
+
 // ---- morphology (vp_morph.hip) ---------------------------------------------------------------
 struct vp_bitstage { int dilate; int l, r, u, d; };  // window [-l, r] x [-u, d]
 #define VP_MAX_STAGES 32

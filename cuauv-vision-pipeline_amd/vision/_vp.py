@@ -13,7 +13,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvp.so")
 
-BGR2LAB, BGR2HSV, BGR2GRAY, GRAY2BGR = 0, 1, 2, 3
+BGR2LAB, BGR2HSV, BGR2GRAY, GRAY2BGR, HSV2BGR = 0, 1, 2, 3, 4
+CB_EQUALIZE_RGB, CB_RGB_CONTRAST, CB_HSV_CONTRAST, CB_HSI_CONTRAST, CB_EXTREMA_CLIPPING, CB_ADAPTIVE_CAST = 1, 2, 4, 8, 16, 32
+CB_DEFAULT = CB_EQUALIZE_RGB | CB_HSV_CONTRAST | CB_EXTREMA_CLIPPING
 MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
 SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
 CCL_PIXEL, CCL_BLOCK2X2 = 1, 2
@@ -72,6 +74,8 @@ _SIGS = {
     "vp_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "vp_profile_kernel_name": (C.c_char_p, [C.c_int]),
     "vp_cvt_color_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vp_color_balance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vp_color_balance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vp_cvt_bgr2lab_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vp_order_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "vp_inrange_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

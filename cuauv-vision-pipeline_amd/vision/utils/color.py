@@ -37,17 +37,20 @@ def _convert_colorspace(code: int) -> Callable[[np.ndarray], Tuple[np.ndarray, T
     """utils/color.py:11-23: returns f(mat) -> (converted image, split channels)."""
     scn = 1 if code == _vp.GRAY2BGR else 3
     dcn = 1 if code == _vp.BGR2GRAY else 3
+    want_planes = code != _vp.HSV2BGR
 
     def _inner(mat: np.ndarray):
         mat = _u8_image(mat, scn)
         h, w = mat.shape[:2]
         conv = np.empty((h, w) if dcn == 1 else (h, w, 3), np.uint8)
-        planes = [np.empty((h, w), np.uint8) for _ in range(dcn)] if dcn == 3 else []
+        planes = [np.empty((h, w), np.uint8) for _ in range(dcn)] if (dcn == 3 and want_planes) else []
         arr = (_vp.C.c_void_p * 3)(*[p.ctypes.data for p in planes], *([None] * (3 - len(planes))))
         ctx = _vp.default_context()
         _vp.check(_vp.lib().vp_cvt_color_u8(ctx.handle, code, _vp.ptr(mat), mat.strides[0], w, h, _vp.ptr(conv),
                                             arr if planes else None), ctx.handle)
         # cv2.split of a single-channel image returns a 1-tuple holding a copy
+        if not want_planes:
+            return conv, tuple(np.ascontiguousarray(conv[:, :, c]) for c in range(3))
         return conv, (tuple(planes) if planes else (conv.copy(),))
     return _inner
 
@@ -66,7 +69,7 @@ bgr_to_hls = _unsupported("bgr_to_hls")
 bgr_to_ycrcb = _unsupported("bgr_to_ycrcb")
 bgr_to_luv = _unsupported("bgr_to_luv")
 lab_to_bgr = _unsupported("lab_to_bgr")
-hsv_to_bgr = _unsupported("hsv_to_bgr")
+hsv_to_bgr = _convert_colorspace(_vp.HSV2BGR)
 
 
 def bgr_to_lab_f32(mat: np.ndarray):

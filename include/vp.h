@@ -33,7 +33,7 @@ extern "C" {
 typedef struct vp_ctx vp_ctx;
 
 /* colour conversion codes (values are libvp's own, not cv2's) */
-enum { VP_BGR2LAB = 0, VP_BGR2HSV = 1, VP_BGR2GRAY = 2, VP_GRAY2BGR = 3 };
+enum { VP_BGR2LAB = 0, VP_BGR2HSV = 1, VP_BGR2GRAY = 2, VP_GRAY2BGR = 3, VP_HSV2BGR = 4 };
 /* morphology ops — utils/transform.py:80-164 */
 enum { VP_MORPH_ERODE = 0, VP_MORPH_DILATE = 1, VP_MORPH_OPEN = 2, VP_MORPH_CLOSE = 3, VP_MORPH_GRADIENT = 4 };
 /* structuring element shapes — cv2.MORPH_RECT / MORPH_CROSS / MORPH_ELLIPSE */
@@ -78,7 +78,7 @@ int vp_get_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* h
 /* ---- per-operator API, host pointers --------------------------------------------------- */
 
 /* utils/color.py:11-32 `_convert_colorspace` (cv2.cvtColor + cv2.split): bgr_to_lab, bgr_to_hsv,
- * bgr_to_gray, gray_to_bgr.  src is (h,w,3) (or (h,w) for GRAY2BGR) with `src_stride` bytes per
+ * bgr_to_gray, gray_to_bgr, plus HSV2BGR (color_balance.cpp:669).  src is (h,w,3) (or (h,w) for GRAY2BGR) with `src_stride` bytes per
  * row.  dst_interleaved (tightly packed, may be NULL) receives the converted image; dst_planes[k]
  * (each (h,w) tightly packed, each may be NULL, array may be NULL) receive the split channels. */
 int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src_host, size_t src_stride, int w, int h,
@@ -87,6 +87,19 @@ int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src_host, size_t src_s
 /* Extension (BASELINE north star "LAB floats within 1e-4"; no reference call site converts float images): BGR float32 in
  * [0,1] (h,w,3 tightly packed) -> CIE L*a*b* float32 (L 0..100, a/b about -127..127), analytic sRGB / D65. */
 int vp_cvt_bgr2lab_f32(vp_ctx* ctx, const float* src_host, int w, int h, float* dst_host);
+
+/* utils/color_correction/color_balance.hpp:9-14 `process_frame` (modules/color_balance.py:93-110 `balance`,
+ * modules/preprocessor.py:87-88): colour-cast equalisation, optional RGB / HSV contrast stretch, 0.2 % extrema clipping.
+ * flags = OR of VP_CB_*; the reference's default call is VP_CB_DEFAULT with 1x1 tiles.  Not implemented
+ * (VP_ERR_UNSUPPORTED): VP_CB_HSI_CONTRAST, and tilings that do not divide the frame (the reference wraps into the next
+ * row and processes pixels twice there).  src and dst are (h,w,3) BGR, tightly packed; dst may equal src. */
+enum { VP_CB_EQUALIZE_RGB = 1, VP_CB_RGB_CONTRAST = 2, VP_CB_HSV_CONTRAST = 4, VP_CB_HSI_CONTRAST = 8, VP_CB_EXTREMA_CLIPPING = 16,
+       VP_CB_ADAPTIVE_CAST = 32, VP_CB_DEFAULT = 1 | 4 | 16 };
+int vp_color_balance_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int flags, int horizontal_blocks, int vertical_blocks,
+                        uint8_t* dst_host);
+/* Same on device memory for a batch of n frames ((n,h,w,3), packed; dst may equal src); enqueues and returns. */
+int vp_color_balance_dev(vp_ctx* ctx, const uint8_t* src_dev, uint8_t* dst_dev, int w, int h, int n_frames, int flags,
+                         int horizontal_blocks, int vertical_blocks);
 
 /* utils/color.py:105-121 `range_threshold` / modules/bins.py:16 (cv2.inRange): cn = 1 or 3;
  * lo/hi have cn entries (already rounded to integers); dst is (h,w) 0/255. */

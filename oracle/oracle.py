@@ -26,8 +26,8 @@ _f64p = C.POINTER(C.c_double)
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "vp_oracle.c")
-    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    srcs = [os.path.join(_HERE, f) for f in ("vp_oracle.c", "vp_oracle_balance.c", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -77,6 +77,31 @@ def bgr2lab(bgr):
 
 def bgr2hsv(bgr):
     return _cvt3(lib().orc_bgr2hsv_u8, bgr)
+
+
+def hsv2bgr(hsv, variant=0):
+    """cv2.cvtColor(COLOR_HSV2BGR), 8-bit; variant 0 = vector arithmetic form, 1 = scalar form (see vp_oracle_balance.c)."""
+    hsv = _c(hsv)
+    h, w, _ = hsv.shape
+    out = np.empty_like(hsv)
+    lib().orc_hsv2bgr_u8(_p(hsv, _u8p), C.c_size_t(w * 3), w, h, _p(out, _u8p), C.c_size_t(w * 3), int(variant))
+    return out
+
+
+def color_balance(bgr, equalize_rgb=True, rgb_contrast_correct=False, hsv_contrast_correct=True, hsi_contrast_correct=False,
+                  rgb_extrema_clipping=True, adaptive_cast_correction=False, horizontal_blocks=1, vertical_blocks=1,
+                  mean_mode=0, hsv_variant=0):
+    """modules/color_balance.py:93-110 balance() -> process_frame (utils/color_correction/color_balance.cpp:343-780)."""
+    out = _c(bgr).copy()
+    h, w, _ = out.shape
+    L = lib()
+    L.orc_color_balance.restype = C.c_int
+    rc = L.orc_color_balance(_p(out, _u8p), C.c_size_t(h), C.c_size_t(w), int(equalize_rgb), int(rgb_contrast_correct),
+                             int(hsv_contrast_correct), int(hsi_contrast_correct), int(rgb_extrema_clipping),
+                             int(adaptive_cast_correction), int(horizontal_blocks), int(vertical_blocks), int(mean_mode), int(hsv_variant))
+    if rc != 0:
+        raise ValueError(f"orc_color_balance: {rc}")
+    return out
 
 
 def bgr2gray(bgr):

@@ -1,0 +1,267 @@
+/*
+ * vp_oracle_balance.c — CPU ORACLE, part 2: the colour-balance entry of the reference and the 8-bit HSV -> BGR
+ * conversion it needs.
+ *
+ * TEST INFRASTRUCTURE ONLY (same rules as vp_oracle.c): imported by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg, never by the product.  PARITY UNPINNED: the reference's source for this path
+ * (utils/color_correction/color_balance.cpp) includes <opencv2/opencv.hpp> and misc/utils.h, neither present here,
+ * so it cannot be compiled; it has no tests or vectors.  What follows restates its arithmetic statement by
+ * statement (file:line cited at each step) on top of this oracle's BGR2HSV and the OpenCV HSV2BGR restated below.
+ *
+ * Deliberate, documented departures from a literal reading (each one is a place where the reference's behaviour is
+ * undefined or crashes):
+ *   - `abs(local_avg - avg)` (cpp:472) is taken as fabs() (with only <cmath> in scope the call may resolve to the
+ *     integer abs() and truncate; for the default 1x1 tiling the difference is ~1e-12 either way);
+ *   - (unsigned char) casts of doubles outside [0,255] or NaN (cpp:584-588 with degenerate ranges) follow what gcc
+ *     emits on x86-64: cvttsd2si to int32 (0x80000000 when out of range / NaN), low 8 bits kept;
+ *   - integer division by zero in the HSV stretch (cpp:654-655, s_max == s_min) kills the reference with SIGFPE;
+ *     here the channel is left as clipped;
+ *   - tilings that do not divide the frame (cpp:441-446) make the reference wrap into the next row and process
+ *     pixels twice; restated literally (sequential block order) so the behaviour is at least inspectable.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+void orc_bgr2hsv_u8(const uint8_t* src, size_t sstride, int w, int h, uint8_t* dst, size_t dstride);
+
+static inline uint8_t sat_round_u8(float x)   /* cv::saturate_cast<uchar>(float): cvRound (half to even), clamp */
+{
+    long v = lrintf(x);
+    return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+/* cv2.cvtColor(COLOR_HSV2BGR) on 8-bit input, hrange 180 — OpenCV imgproc/src/color_hsv.simd.hpp HSV2RGB_b:
+ * h, s/255, v/255 as float32 -> HSV2RGB_f -> *255 -> saturate_cast.  HSV2RGB_f has two arithmetic forms:
+ *   variant 0  the universal-intrinsics form used for all full vectors of a row on SIMD builds (HSV2RGB_simd):
+ *              tab1 = v - v*s, tab2 = v - (v*s)*h, tab3 = (v - v*s) + (v*s)*h, sector = trunc(h) mod 6;
+ *   variant 1  the scalar tail form (HSV2RGB_native): tab1 = v*(1-s), tab2 = v*(1-s*h), tab3 = v*(1-s*(1-h)).
+ * They differ in float rounding only; after *255 and rounding to u8 they disagree on a small set of (h,s,v)
+ * (tests count it).  Variant 0 is what the GPU implements. */
+static void hsv2bgr_px(int H, int S, int V, int variant, uint8_t* out)
+{
+    const float hscale = 6.f / 180.f;
+    float h = (float)H, s = (float)S * (1.f / 255.f), v = (float)V * (1.f / 255.f);
+    float tab[4];
+    int sector;
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    if (variant == 0) {
+        h = h * hscale;
+        const float pre = truncf(h);
+        h = h - pre;
+        const float vs = v * s;
+        const float vsh = vs * h;
+        tab[0] = v;
+        tab[1] = v - vs;
+        tab[2] = v - vsh;
+        tab[3] = (v - vs) + vsh;
+        float sec = truncf(pre * (1.0f / 6.0f));
+        sec = pre - sec * 6.0f;
+        sector = (int)sec;
+    } else {
+        if (S == 0) {
+            out[0] = out[1] = out[2] = sat_round_u8(v * 255.f);
+            return;
+        }
+        h *= hscale;
+        h = fmodf(h, 6.f);
+        sector = (int)floorf(h);
+        h -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        tab[0] = v;
+        tab[1] = v * (1.f - s);
+        tab[2] = v * (1.f - s * h);
+        tab[3] = v * (1.f - s * (1.f - h));
+    }
+    out[0] = sat_round_u8(tab[sector_data[sector][0]] * 255.f);
+    out[1] = sat_round_u8(tab[sector_data[sector][1]] * 255.f);
+    out[2] = sat_round_u8(tab[sector_data[sector][2]] * 255.f);
+}
+
+ORC_API void orc_hsv2bgr_u8(const uint8_t* src, size_t sstride, int w, int h, uint8_t* dst, size_t dstride, int variant)
+{
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++, s += 3, d += 3) hsv2bgr_px(s[0], s[1], s[2], variant, d);
+    }
+}
+
+/* ---- utils/color_correction/color_balance.cpp ------------------------------------------------------------ */
+
+static inline uint8_t cast_u8(double v)   /* (unsigned char)double as gcc/x86-64 does it: cvttsd2si, low byte */
+{
+    int32_t i;
+    if (!(v > -2147483649.0 && v < 2147483648.0)) i = INT32_MIN;   /* NaN and out-of-range: "integer indefinite" */
+    else i = (int32_t)v;
+    return (uint8_t)(i & 0xff);
+}
+static inline uint8_t constrain255(double val)   /* cpp:13-23 constrain(val, 0, 255) */
+{
+    if (val < 0) return 0;
+    if (val > 255) return 255;
+    return cast_u8(val);
+}
+static void clip_channel(uint8_t* c, size_t n, int lo, int hi)   /* cpp:25-45 (min/max arrive as unsigned char) */
+{
+    const uint8_t l = (uint8_t)lo, h = (uint8_t)hi;
+    for (size_t i = 0; i < n; i++) {
+        if (c[i] < l) c[i] = l;
+        else if (c[i] > h) c[i] = h;
+    }
+}
+static void percentile_min_max(const uint8_t* c, size_t n, float lower, float upper, int* mn, int* mx)   /* cpp:111-139 */
+{
+    int low_bound = (int)(lower * (float)n);
+    int high_bound = (int)n - (int)(upper * (float)n);
+    int counts[256] = {0};
+    for (size_t i = 0; i < n; i++) counts[c[i]]++;
+    *mn = 0; *mx = 255;
+    for (int i = 0; i < 256; i++) {
+        if (low_bound < counts[i]) { *mn = i; break; }
+        low_bound -= counts[i];
+    }
+    for (int i = 255; i >= 0; i--) {
+        if (high_bound < counts[i]) { *mx = i; break; }
+        high_bound -= counts[i];
+    }
+}
+static double mean_u8(const uint8_t* c, size_t n)   /* cv::mean: exact integer sum / n */
+{
+    uint64_t s = 0;
+    for (size_t i = 0; i < n; i++) s += c[i];
+    return (double)s / (double)n;
+}
+
+/* process_frame(arr, height, width, depth = 3, ...) — cpp:343-780.  hsi_contrast_correct is not restated (returns -4).
+ * mean_mode 0: the running mean of cpp:452-467 literally (avg += (x - avg) / count, row-major inside the tile);
+ * mean_mode 1: the same quantity as an exact sum / count (what a parallel implementation computes; differs from the
+ * running mean by rounding noise of ~1e-13 relative).  hsv_variant: see orc_hsv2bgr_u8. */
+ORC_API int orc_color_balance(uint8_t* arr, size_t height, size_t width, int equalize_rgb, int rgb_contrast_correct,
+                              int hsv_contrast_correct, int hsi_contrast_correct, int rgb_extrema_clipping,
+                              int adaptive_cast_correction, int horizontal_blocks, int vertical_blocks, int mean_mode,
+                              int hsv_variant)
+{
+    if (hsi_contrast_correct) return -4;
+    if (horizontal_blocks <= 0 || vertical_blocks <= 0 || !height || !width) return -1;
+    const size_t n = height * width;
+    uint8_t* bc = (uint8_t*)malloc(n);
+    uint8_t* gc = (uint8_t*)malloc(n);
+    uint8_t* rc = (uint8_t*)malloc(n);
+    for (size_t i = 0; i < n; i++) { bc[i] = arr[3 * i]; gc[i] = arr[3 * i + 1]; rc[i] = arr[3 * i + 2]; }   /* cv::split cpp:372 */
+
+    double r_min, r_max, g_min, g_max, b_min, b_max;
+    if (rgb_extrema_clipping) {   /* cpp:398-419 */
+        int mn, mx;
+        percentile_min_max(rc, n, 0.002f, 0.998f, &mn, &mx); r_min = mn; r_max = mx; clip_channel(rc, n, mn, mx);
+        percentile_min_max(gc, n, 0.002f, 0.998f, &mn, &mx); g_min = mn; g_max = mx; clip_channel(gc, n, mn, mx);
+        percentile_min_max(bc, n, 0.002f, 0.998f, &mn, &mx); b_min = mn; b_max = mx; clip_channel(bc, n, mn, mx);
+    } else {                      /* cv::minMaxLoc cpp:421-425 */
+        uint8_t lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+        const uint8_t* ch[3] = {rc, gc, bc};
+        for (int k = 0; k < 3; k++)
+            for (size_t i = 0; i < n; i++) { if (ch[k][i] < lo[k]) lo[k] = ch[k][i]; if (ch[k][i] > hi[k]) hi[k] = ch[k][i]; }
+        r_min = lo[0]; r_max = hi[0]; g_min = lo[1]; g_max = hi[1]; b_min = lo[2]; b_max = hi[2];
+    }
+    const double r_avg = mean_u8(rc, n), g_avg = mean_u8(gc, n), b_avg = mean_u8(bc, n);   /* cpp:427-429 */
+
+    if (equalize_rgb) {   /* cpp:441-543 */
+        const int block_width = (int)width / horizontal_blocks, block_height = (int)height / vertical_blocks;
+        if (width % (size_t)horizontal_blocks != 0) ++horizontal_blocks;
+        if (height % (size_t)vertical_blocks != 0) ++vertical_blocks;
+        for (int by = 0; by < vertical_blocks; ++by)
+            for (int bx = 0; bx < horizontal_blocks; ++bx) {
+                double lr = 0, lg = 0, lb = 0;
+                int count = 0;
+                uint64_t sr = 0, sg = 0, sb = 0;
+                for (int j = 0; j < block_height; ++j)
+                    for (int i = 0; i < block_width; ++i) {
+                        const size_t ci = ((size_t)by * block_height + j) * width + ((size_t)bx * block_width + i);
+                        if (ci >= n) break;
+                        ++count;
+                        lr += (rc[ci] - lr) / count;
+                        lg += (gc[ci] - lg) / count;
+                        lb += (bc[ci] - lb) / count;
+                        sr += rc[ci]; sg += gc[ci]; sb += bc[ci];
+                    }
+                if (mean_mode == 1 && count > 0) { lr = (double)sr / count; lg = (double)sg / count; lb = (double)sb / count; }
+                if (fabs(lr - r_avg) > r_avg / 6 || fabs(lb - b_avg) > b_avg / 6 || fabs(lg - g_avg) > g_avg / 6) {
+                    lr = r_avg; lb = b_avg; lg = g_avg;
+                }
+                uint8_t *c1, *c2;
+                double gain1, gain2;
+                if (lr > lg && lr > lb) { c1 = gc; c2 = bc; gain1 = lr / lg; gain2 = lr / lb; }          /* red cast */
+                else if (lg > lr && lg > lb) { c1 = rc; c2 = bc; gain1 = lg / lr; gain2 = lg / lb; }     /* green cast */
+                else { c1 = rc; c2 = gc; gain1 = lb / lr; gain2 = lb / lg; }                             /* blue cast (and ties) */
+                for (int j = 0; j < block_height; ++j)
+                    for (int i = 0; i < block_width; ++i) {
+                        const size_t ci = ((size_t)by * block_height + j) * width + ((size_t)bx * block_width + i);
+                        if (ci >= n) break;
+                        if (adaptive_cast_correction) {
+                            c1[ci] = constrain255(c1[ci] * (pow((255. - c1[ci]) / 255., 0.25) * (gain1 - 1.) + 1.));
+                            c2[ci] = constrain255(c2[ci] * (pow((255. - c2[ci]) / 255., 0.25) * (gain2 - 1.) + 1.));
+                        } else {
+                            c1[ci] = constrain255(c1[ci] * gain1);
+                            c2[ci] = constrain255(c2[ci] * gain2);
+                        }
+                    }
+            }
+    }
+
+    if (rgb_contrast_correct) {   /* cpp:545-597 */
+        uint8_t *min_c, *mid_c, *max_c;
+        int min_min, min_max, mid_min, mid_max, max_min, max_max;
+#define SETC(which, chan, lo, hi) do { which##_c = chan; which##_min = (int)(lo); which##_max = (int)(hi); } while (0)
+        if (r_avg > g_avg) {
+            if (r_avg > b_avg) {
+                SETC(max, rc, r_min, r_max);
+                if (g_avg > b_avg) { SETC(mid, gc, g_min, g_max); SETC(min, bc, b_min, b_max); }
+                else { SETC(mid, bc, b_min, b_max); SETC(min, gc, g_min, g_max); }
+            } else { SETC(max, bc, b_min, b_max); SETC(mid, rc, r_min, r_max); SETC(min, gc, g_min, g_max); }
+        } else {
+            if (g_avg > b_avg) {
+                SETC(max, gc, g_min, g_max);
+                if (r_avg > b_avg) { SETC(mid, rc, r_min, r_max); SETC(min, bc, b_min, b_max); }
+                else { SETC(mid, bc, b_min, b_max); SETC(min, rc, r_min, r_max); }
+            } else { SETC(max, bc, b_min, b_max); SETC(mid, gc, g_min, g_max); SETC(min, rc, r_min, r_max); }
+        }
+#undef SETC
+        const double desired_max = (double)((min_max + mid_max + max_max) / 3);
+        const double min_ratio = (desired_max - min_min) / (double)(min_max - min_min);
+        const double mid_ratio = (desired_max - 0.0) / (double)(mid_max - mid_min);
+        const double max_ratio = (max_max - 0.0) / (double)(max_max - max_min);
+        for (size_t i = 0; i < n; i++) {
+            min_c[i] = cast_u8((min_c[i] - min_min) * min_ratio);
+            mid_c[i] = cast_u8((mid_c[i] - mid_min) * mid_ratio);
+            max_c[i] = cast_u8((max_c[i] - max_min) * max_ratio);
+        }
+    }
+
+    if (hsv_contrast_correct) {   /* cpp:599-676 */
+        uint8_t* bgr = (uint8_t*)malloc(n * 3);
+        uint8_t* hsv = (uint8_t*)malloc(n * 3);
+        uint8_t* sc = (uint8_t*)malloc(n);
+        uint8_t* vc = (uint8_t*)malloc(n);
+        for (size_t i = 0; i < n; i++) { bgr[3 * i] = bc[i]; bgr[3 * i + 1] = gc[i]; bgr[3 * i + 2] = rc[i]; }
+        orc_bgr2hsv_u8(bgr, width * 3, (int)width, (int)height, hsv, width * 3);
+        for (size_t i = 0; i < n; i++) { sc[i] = hsv[3 * i + 1]; vc[i] = hsv[3 * i + 2]; }
+        int s_min, s_max, v_min, v_max;
+        percentile_min_max(sc, n, 0.002f, 0.998f, &s_min, &s_max); clip_channel(sc, n, s_min, s_max);
+        percentile_min_max(vc, n, 0.002f, 0.998f, &v_min, &v_max); clip_channel(vc, n, v_min, v_max);
+        for (size_t i = 0; i < n; i++) {
+            if (s_max != s_min) sc[i] = (uint8_t)((((int)sc[i] - s_min) * 255) / (s_max - s_min));
+            if (v_max != v_min) vc[i] = (uint8_t)((((int)vc[i] - v_min) * 255) / (v_max - v_min));
+            hsv[3 * i + 1] = sc[i]; hsv[3 * i + 2] = vc[i];
+        }
+        orc_hsv2bgr_u8(hsv, width * 3, (int)width, (int)height, bgr, width * 3, hsv_variant);
+        for (size_t i = 0; i < n; i++) { bc[i] = bgr[3 * i]; gc[i] = bgr[3 * i + 1]; rc[i] = bgr[3 * i + 2]; }
+        free(bgr); free(hsv); free(sc); free(vc);
+    }
+
+    for (size_t i = 0; i < n; i++) { arr[3 * i] = bc[i]; arr[3 * i + 1] = gc[i]; arr[3 * i + 2] = rc[i]; }   /* cv::merge cpp:777 */
+    free(bc); free(gc); free(rc);
+    return 0;
+}

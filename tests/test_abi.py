@@ -74,3 +74,20 @@ def test_polygon_helpers():
     assert feature.contour_area(sq) == 16.0
     assert feature.contour_centroid(sq) == (4, 4)
     assert feature.contour_centroid(np.array([[[3, 3]]], np.int32)) == (0, 0)  # degenerate: m00 clamped (utils/feature.py:251)
+
+
+def test_color_balance_library_exports_reference_entry():
+    """libauv-color-balance.so (modules/color_balance.py:12) exports process_frame with the reference's argument list
+    (utils/color_correction/color_balance.hpp:9-14); no compute call here."""
+    names = _declared("color_balance_c.h")
+    assert "process_frame" in names
+    lib = C.CDLL(os.path.join(ROOT, "cuauv-vision-pipeline_amd", "lib", "libauv-color-balance.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+    import torch
+    if not torch.cuda.is_available():
+        arr = np.zeros((4, 4, 3), np.uint8)
+        lib.process_frame.restype = C.c_int
+        rc = lib.process_frame(arr.ctypes.data_as(C.c_void_p), C.c_size_t(4), C.c_size_t(4), C.c_size_t(3), True, False, True, False, True, False, 1, 1)
+        assert rc == -2          # VP_ERR_HIP: no device, no CPU path
+        assert lib.process_frame(arr.ctypes.data_as(C.c_void_p), C.c_size_t(4), C.c_size_t(4), C.c_size_t(4), True, False, True, False, True, False, 1, 1) == -1

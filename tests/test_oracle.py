@@ -186,3 +186,53 @@ def test_chain_equals_composition(oracle):
     n, lab, st, ce = oracle.ccl(cl, 2)
     assert out["nlabels"] == n and np.array_equal(out["labels"], lab) and np.array_equal(out["stats"], st)
     assert n >= 2
+
+
+def test_hsv2bgr_known_answers_and_variants(oracle):
+    """cv2.cvtColor(COLOR_HSV2BGR), 8-bit: primaries / greys (the inverses of SURVEY A2's known answers), agreement of the two
+    arithmetic forms of OpenCV's float kernel except on a small counted set, round trip through BGR2HSV within the
+    quantisation of H (2 degrees) and S."""
+    px = np.array([[[0, 255, 255], [60, 255, 255], [120, 255, 255], [0, 0, 255], [0, 0, 0], [15, 76, 200], [30, 255, 255], [90, 255, 128]]], np.uint8)
+    exp = [[0, 0, 255], [0, 255, 0], [255, 0, 0], [255, 255, 255], [0, 0, 0], [140, 170, 200], [0, 255, 255], [128, 128, 0]]
+    for variant in (0, 1):
+        assert oracle.hsv2bgr(px, variant).reshape(-1, 3).tolist() == exp
+    h, s, v = np.meshgrid(np.arange(180), np.arange(0, 256, 3), np.arange(256), indexing="ij")
+    hsv = np.stack([h, s, v], -1).astype(np.uint8).reshape(180, -1, 3)
+    a, b = oracle.hsv2bgr(hsv, 0), oracle.hsv2bgr(hsv, 1)
+    d = np.abs(a.astype(int) - b.astype(int)).max(-1)
+    assert d.max() <= 1 and (d > 0).mean() < 2e-4
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    rt = oracle.hsv2bgr(oracle.bgr2hsv(bgr))
+    assert np.abs(rt.astype(int) - bgr.astype(int)).max() <= 6
+
+
+def test_color_balance_restatement(oracle):
+    """utils/color_correction/color_balance.cpp process_frame: hand-checkable cases of the restatement."""
+    f = F.s1_buoy(0, 160, 90)
+    # every stage off: identity
+    assert np.array_equal(oracle.color_balance(f, equalize_rgb=False, hsv_contrast_correct=False, rgb_extrema_clipping=False), f)
+    # extrema clipping only: each channel clipped to its 0.2 % / 99.8 % histogram bounds (cpp:111-139)
+    out = oracle.color_balance(f, equalize_rgb=False, hsv_contrast_correct=False)
+    n = f.shape[0] * f.shape[1]
+    for c in range(3):
+        ch = np.sort(f[:, :, c].ravel())
+        lo = ch[int(np.float32(0.002) * np.float32(n))]
+        hi = ch[n - 1 - (n - int(np.float32(0.998) * np.float32(n)))]
+        assert out[:, :, c].min() == lo and out[:, :, c].max() == hi
+        assert np.array_equal(out[:, :, c], np.clip(f[:, :, c], lo, hi))
+    # equalisation only, blue cast (B mean largest): R and G are lifted by mean(B)/mean(R), mean(B)/mean(G), truncated; B untouched
+    out = oracle.color_balance(f, hsv_contrast_correct=False, rgb_extrema_clipping=False, mean_mode=1)
+    m = f.reshape(-1, 3).astype(np.float64).mean(0)
+    assert m[0] > m[1] and m[0] > m[2]
+    assert np.array_equal(out[:, :, 0], f[:, :, 0])
+    for c in (1, 2):
+        assert np.array_equal(out[:, :, c], np.minimum(f[:, :, c].astype(np.float64) * (m[0] / m[c]), 255).astype(np.uint8))
+    # the running mean of the reference and the exact mean give the same frame here
+    assert np.array_equal(out, oracle.color_balance(f, hsv_contrast_correct=False, rgb_extrema_clipping=False, mean_mode=0))
+    # HSV stretch: afterwards S and V of the result span the full range (up to the conversion's quantisation)
+    out = oracle.color_balance(f)
+    hsv = oracle.bgr2hsv(out)
+    assert hsv[:, :, 2].max() >= 250 and hsv[:, :, 2].min() <= 5
+    with pytest.raises(ValueError):
+        oracle.color_balance(f, hsi_contrast_correct=True)
