@@ -19,6 +19,7 @@
 #include "vp_internal.h"
 
 #define CB_MAX_TILES 1024
+#define CB_COPIES 16
 
 struct cb_params {
     int w, h, n;
@@ -86,13 +87,15 @@ __device__ __forceinline__ int cb_tile_of(const cb_params& P, size_t pix_in_fram
 template <bool TILED>
 __global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src, cb_params P, u32* __restrict__ hist)
 {
-    __shared__ u32 lh[4][3][256];   // one copy per wave: natural images concentrate on few bins
-    const int f = blockIdx.y, tid = threadIdx.x, wv = tid >> 6;
+    // natural images concentrate on few bins: 16 interleaved copies (bin * 16 + lane % 16) cut same-address atomics of a wave
+    // from 64 lanes to 4 and keep the copies of one bin in different banks
+    __shared__ u32 lh[3][256 * CB_COPIES];
+    const int f = blockIdx.y, tid = threadIdx.x, cp = tid & (CB_COPIES - 1);
     const size_t npx = (size_t)P.w * P.h;
     const uint8_t* fs = src + (size_t)f * npx * 3;
     u32* fh = hist + (size_t)f * P.hb * P.vb * 768;
     if (!TILED) {
-        for (int i = tid; i < 4 * 768; i += 256) (&lh[0][0][0])[i] = 0;
+        for (int i = tid; i < 768 * CB_COPIES; i += 256) (&lh[0][0])[i] = 0;
         __syncthreads();
     }
     const size_t ngroups = npx / 4;
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src
                 u32* th = fh + (size_t)cb_tile_of(P, 4 * gidx + k) * 768;
                 atomicAdd(th + px[k][0], 1u); atomicAdd(th + 256 + px[k][1], 1u); atomicAdd(th + 512 + px[k][2], 1u);
             } else {
-                atomicAdd(&lh[wv][0][px[k][0]], 1u); atomicAdd(&lh[wv][1][px[k][1]], 1u); atomicAdd(&lh[wv][2][px[k][2]], 1u);
+                atomicAdd(&lh[0][px[k][0] * CB_COPIES + cp], 1u); atomicAdd(&lh[1][px[k][1] * CB_COPIES + cp], 1u);
+                atomicAdd(&lh[2][px[k][2] * CB_COPIES + cp], 1u);
             }
         }
     }
@@ -117,13 +121,16 @@ __global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src
             u32* th = fh + (size_t)cb_tile_of(P, p) * 768;
             atomicAdd(th + fs[3 * p], 1u); atomicAdd(th + 256 + fs[3 * p + 1], 1u); atomicAdd(th + 512 + fs[3 * p + 2], 1u);
         } else {
-            atomicAdd(&lh[wv][0][fs[3 * p]], 1u); atomicAdd(&lh[wv][1][fs[3 * p + 1]], 1u); atomicAdd(&lh[wv][2][fs[3 * p + 2]], 1u);
+            atomicAdd(&lh[0][fs[3 * p] * CB_COPIES + cp], 1u); atomicAdd(&lh[1][fs[3 * p + 1] * CB_COPIES + cp], 1u);
+            atomicAdd(&lh[2][fs[3 * p + 2] * CB_COPIES + cp], 1u);
         }
     }
     if (!TILED) {
         __syncthreads();
         for (int i = tid; i < 768; i += 256) {
-            const u32 v = (&lh[0][0][0])[i] + (&lh[1][0][0])[i] + (&lh[2][0][0])[i] + (&lh[3][0][0])[i];
+            u32 v = 0;
+#pragma unroll
+            for (int k = 0; k < CB_COPIES; k++) v += (&lh[0][0])[i * CB_COPIES + k];
             if (v) atomicAdd(fh + i, v);
         }
     }
@@ -252,28 +259,42 @@ __global__ __launch_bounds__(256) void k_cb_hsvhist(const uint8_t* __restrict__ 
 {
     __shared__ HsvTab ht;
     __shared__ uint8_t ll[768];
-    __shared__ u32 lh[4][2][256];
-    const int f = blockIdx.y, tid = threadIdx.x, wv = tid >> 6;
+    __shared__ u32 lh[2][256 * CB_COPIES];
+    const int f = blockIdx.y, tid = threadIdx.x, cp = tid & (CB_COPIES - 1);
     const int tiles = P.hb * P.vb;
     const size_t npx = (size_t)P.w * P.h;
     const uint8_t* fs = src + (size_t)f * npx * 3;
     const uint8_t* fl = lut + (size_t)f * tiles * 768;
     ht.sdiv[tid] = tab.sdiv[tid]; ht.hdiv[tid] = tab.hdiv[tid];
     for (int i = tid; i < 768; i += 256) ll[i] = fl[i];
-    for (int i = tid; i < 4 * 512; i += 256) (&lh[0][0][0])[i] = 0;
+    for (int i = tid; i < 512 * CB_COPIES; i += 256) (&lh[0][0])[i] = 0;
     __syncthreads();
-    for (size_t p = (size_t)blockIdx.x * 256 + tid; p < npx; p += (size_t)gridDim.x * 256) {
-        int b = fs[3 * p], g = fs[3 * p + 1], r = fs[3 * p + 2];
+    auto one = [&](size_t p, int b, int g, int r) {
         if (TILED) { const uint8_t* tl = fl + (size_t)cb_tile_of(P, p) * 768; b = tl[b]; g = tl[256 + g]; r = tl[512 + r]; }
         else { b = ll[b]; g = ll[256 + g]; r = ll[512 + r]; }
         int H, S, V;
         cb_bgr2hsv(ht, b, g, r, H, S, V);
-        atomicAdd(&lh[wv][0][S], 1u);
-        atomicAdd(&lh[wv][1][V], 1u);
+        atomicAdd(&lh[0][S * CB_COPIES + cp], 1u);
+        atomicAdd(&lh[1][V * CB_COPIES + cp], 1u);
+    };
+    const size_t ngroups = npx / 4;
+    const u32* s32 = reinterpret_cast<const u32*>(fs);
+    for (size_t gidx = (size_t)blockIdx.x * 256 + tid; gidx < ngroups; gidx += (size_t)gridDim.x * 256) {
+        const u32 a = s32[3 * gidx], bb = s32[3 * gidx + 1], c = s32[3 * gidx + 2];
+        one(4 * gidx, (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255));
+        one(4 * gidx + 1, (int)(a >> 24), (int)(bb & 255), (int)((bb >> 8) & 255));
+        one(4 * gidx + 2, (int)((bb >> 16) & 255), (int)(bb >> 24), (int)(c & 255));
+        one(4 * gidx + 3, (int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24));
+    }
+    if (blockIdx.x == 0 && tid < (int)(npx & 3)) {
+        const size_t p = (npx & ~(size_t)3) + tid;
+        one(p, fs[3 * p], fs[3 * p + 1], fs[3 * p + 2]);
     }
     __syncthreads();
     for (int i = tid; i < 512; i += 256) {
-        const u32 v = (&lh[0][0][0])[i] + (&lh[1][0][0])[i] + (&lh[2][0][0])[i] + (&lh[3][0][0])[i];
+        u32 v = 0;
+#pragma unroll
+        for (int k = 0; k < CB_COPIES; k++) v += (&lh[0][0])[i * CB_COPIES + k];
         if (v) atomicAdd(svhist + (size_t)f * 512 + i, v);
     }
 }
