@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the chain + contours side measurement")
     ap.add_argument("--max-labels", type=int, default=256)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: run the N-rank code path with every rank on cuda:0 and a gloo group (a one-GPU box cannot host "
+                         "an RCCL group); the printed value is then not a scaling number")
     return ap.parse_args()
 
 
@@ -109,8 +112,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libvp has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    _, _, _, dist = init_distributed("nccl")
+    _, _, _, dist = init_distributed("gloo" if args.rehearse_on_one_gpu else "nccl")
 
     import frames as F
     from vision import _vp
@@ -146,7 +151,7 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-    elapsed = timed_steps(lambda: ctx.chain_run(desc, bufs, B), sync, args.steps, dist, device="cuda")
+    elapsed = timed_steps(lambda: ctx.chain_run(desc, bufs, B), sync, args.steps, dist, device="cpu" if args.rehearse_on_one_gpu else "cuda")
 
     # ---- per-kernel attribution with HIP events on the launch stream (same K steps again) ----------
     ctx.profile_begin(args.steps * 16)
