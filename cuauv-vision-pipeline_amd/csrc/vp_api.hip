@@ -783,6 +783,8 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int 
 static int check_desc(vp_ctx* ctx, const vp_chain_desc* d, int n)
 {
     if (!d || n <= 0 || d->width <= 0 || d->height <= 0) return vp_fail(ctx, VP_ERR_INVALID, "chain: size");
+    // frames ride on gridDim.y; segment ids and pixel indices are 32-bit
+    if (n > 65535 || (unsigned long long)d->width * (unsigned long long)d->height > (1ull << 30)) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "chain: batch or frame too large");
     if (d->color_mode != VP_BGR2LAB && d->color_mode != VP_BGR2HSV && d->color_mode != VP_BGR2GRAY)
         return vp_fail(ctx, VP_ERR_INVALID, "chain: color_mode");
     if (d->n_morph < 0 || d->n_morph > VP_CHAIN_MAX_MORPH) return vp_fail(ctx, VP_ERR_INVALID, "chain: n_morph");

@@ -366,6 +366,170 @@ __global__ __launch_bounds__(256) void k_cb_apply(const uint8_t* __restrict__ sr
     }
 }
 
+// ---- HSI contrast stage (cpp:141-341, 678-775) -------------------------------------------------------------------------------
+// Works on the BGR image the earlier stages produced (in place).  The reference converts to float H, S, I planes, takes the
+// 0.2 % / 99.8 % order statistics of S and I by quickselect, clips, stretches and converts back.  S and I need no
+// trigonometry, so the order statistics come from four 8-bit radix passes over the image that recompute (S, I) per pixel
+// (3 B/px per pass, no float planes), driven entirely from the device (k_hsi_pick chooses the bucket of each pass); the
+// final pass recomputes H as well and writes the result.  float / double mixing follows the C++ expressions operand by
+// operand; acos / cos come from the device libm, hence the tolerance of 1 stated in the tests for this stage.
+#define CB_PI 3.14159265358979323846
+struct hsi_state { u32 prefix[4], mask[4], rank[4]; float val[4]; };   // 0 S-low, 1 S-high, 2 I-low, 3 I-high
+
+__device__ __forceinline__ float cb_clipf(float c, float mn, float mx)   // cpp:47-69 clip_channel_f, one element
+{
+    if (c < mn) return mn;
+    if (c > mx) return mx;
+    if (isnan(c)) return mn;
+    if (isinf(c)) return mx;
+    return c;
+}
+__device__ __forceinline__ void cb_rgb2si(int r, int g, int b, float& S, float& I)   // cpp:186-201 + the clips of cpp:253-255
+{
+    I = (float)((double)((float)r + (float)g + (float)b) / 3.);
+    const int mn = min(min(r, g), b);
+    S = I > 0 ? (float)(1. - (double)((float)mn / I)) : 0.f;
+    S = cb_clipf(S, 0.f, 1.f);
+    I = cb_clipf(I, 0.f, 255.f);
+}
+__device__ __forceinline__ float cb_rgb2h(int r, int g, int b)   // cpp:202-207
+{
+    const float rad = (float)r * r + (float)g * g + (float)b * b - (float)(r * g) - (float)(r * b) - (float)(g * b);
+    float H = (float)acos(((double)(float)r - (0.5 * g) - (0.5 * b)) / sqrt((double)rad));
+    if (b > g) H = (float)((CB_PI * 2) - (double)H);
+    return cb_clipf(H, 0.f, (float)(2. * CB_PI));
+}
+__device__ __forceinline__ int cb_uchar_clip(float f)   // cpp:155-164; (int) of NaN / huge values as x86 cvttss2si: INT_MIN
+{
+    int n = (f > -2147483904.f && f < 2147483648.f) ? (int)f : (int)0x80000000;
+    return n < 0 ? 0 : (n > 255 ? 255 : n);
+}
+__device__ __forceinline__ bool cb_feq(float a, float b) { return fabs((double)(a - b)) < 0.000001; }
+__device__ __forceinline__ void cb_hsi2rgb(float h, float s, float i, int& r, int& g, int& b)   // cpp:261-306
+{
+    const float lo = i - i * s;
+    if (cb_feq(h, 0.f)) { r = cb_uchar_clip(i + 2 * i * s); g = cb_uchar_clip(lo); b = cb_uchar_clip(lo); }
+    else if (0. < h && h < 2. * CB_PI / 3.) {
+        const double q = cos((double)h) / cos(CB_PI / 3. - h);
+        r = cb_uchar_clip((float)(i + i * s * q));
+        g = cb_uchar_clip((float)(i + i * s * (1 - q)));
+        b = cb_uchar_clip(lo);
+    } else if (cb_feq(h, (float)(2. * CB_PI / 3.))) { r = cb_uchar_clip(lo); g = cb_uchar_clip(i + 2 * i * s); b = cb_uchar_clip(lo); }
+    else if (2. * CB_PI / 3. < h && h < 4. * CB_PI / 3.) {
+        const double q = cos(h - 2. * CB_PI / 3.) / cos(CB_PI - h);
+        r = cb_uchar_clip(lo);
+        g = cb_uchar_clip((float)(i + i * s * q));
+        b = cb_uchar_clip((float)(i + i * s * (1 - q)));
+    } else if (cb_feq(h, (float)(4. * CB_PI / 3.))) { r = cb_uchar_clip(lo); g = cb_uchar_clip(lo); b = cb_uchar_clip(i + 2 * i * s); }
+    else {
+        const double q = cos(h - 4. * CB_PI / 3.) / cos(5. * CB_PI / 3. - h);
+        r = cb_uchar_clip((float)(i + i * s * (1 - q)));
+        g = cb_uchar_clip(lo);
+        b = cb_uchar_clip((float)(i + i * s * q));
+    }
+}
+
+__global__ void k_hsi_init(cb_params P, hsi_state* __restrict__ st)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= P.n) return;
+    const size_t npx = (size_t)P.w * P.h;
+    const u32 lowb = (u32)(int)(0.002f * (float)npx);          // cpp:142-143
+    u32 highb = (u32)(int)(0.998f * (float)npx);
+    if (highb >= npx) highb = (u32)npx - 1;
+    hsi_state s;
+    for (int q = 0; q < 4; q++) { s.prefix[q] = 0; s.mask[q] = 0; s.rank[q] = (q & 1) ? highb : lowb; s.val[q] = 0.f; }
+    st[f] = s;
+}
+
+// one radix pass: digit histograms of the S and I keys that still match each of the four prefixes.  hist: [n][4][256]
+__global__ __launch_bounds__(256) void k_hsi_hist(const uint8_t* __restrict__ img, cb_params P, const hsi_state* __restrict__ st, int shift,
+                                                  u32* __restrict__ hist)
+{
+    __shared__ u32 lh[4][256 * 8];
+    const int f = blockIdx.y, tid = threadIdx.x, cp = tid & 7;
+    const size_t npx = (size_t)P.w * P.h;
+    const uint8_t* fs = img + (size_t)f * npx * 3;
+    const hsi_state s = st[f];
+    for (int i = tid; i < 4 * 256 * 8; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    auto one = [&](int b, int g, int r) {
+        float S, I;
+        cb_rgb2si(r, g, b, S, I);
+        const u32 ks = __float_as_uint(S), ki = __float_as_uint(I);
+        if ((ks & s.mask[0]) == s.prefix[0]) atomicAdd(&lh[0][((ks >> shift) & 255u) * 8 + cp], 1u);
+        if ((ks & s.mask[1]) == s.prefix[1]) atomicAdd(&lh[1][((ks >> shift) & 255u) * 8 + cp], 1u);
+        if ((ki & s.mask[2]) == s.prefix[2]) atomicAdd(&lh[2][((ki >> shift) & 255u) * 8 + cp], 1u);
+        if ((ki & s.mask[3]) == s.prefix[3]) atomicAdd(&lh[3][((ki >> shift) & 255u) * 8 + cp], 1u);
+    };
+    const size_t ngroups = npx / 4;
+    const u32* s32 = reinterpret_cast<const u32*>(fs);
+    for (size_t gidx = (size_t)blockIdx.x * 256 + tid; gidx < ngroups; gidx += (size_t)gridDim.x * 256) {
+        const u32 a = s32[3 * gidx], bb = s32[3 * gidx + 1], c = s32[3 * gidx + 2];
+        one((int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255));
+        one((int)(a >> 24), (int)(bb & 255), (int)((bb >> 8) & 255));
+        one((int)((bb >> 16) & 255), (int)(bb >> 24), (int)(c & 255));
+        one((int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24));
+    }
+    if (blockIdx.x == 0 && tid < (int)(npx & 3)) {
+        const size_t p = (npx & ~(size_t)3) + tid;
+        one(fs[3 * p], fs[3 * p + 1], fs[3 * p + 2]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        u32 v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v += (&lh[0][0])[i * 8 + k];
+        if (v) atomicAdd(hist + (size_t)f * 1024 + i, v);
+    }
+}
+
+// one block per frame: walk each of the four histograms to the bucket holding the wanted rank, clear the histograms
+__global__ __launch_bounds__(256) void k_hsi_pick(hsi_state* __restrict__ st, u32* __restrict__ hist, int shift)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    u32* h = hist + (size_t)f * 1024;
+    if (tid < 4) {
+        hsi_state* s = st + f;
+        u32 rank = s->rank[tid];
+        int b = 0;
+        for (; b < 255; b++) {
+            const u32 c = h[tid * 256 + b];
+            if (rank < c) break;
+            rank -= c;
+        }
+        s->rank[tid] = rank;
+        s->prefix[tid] |= (u32)b << shift;
+        s->mask[tid] |= 0xffu << shift;
+        if (shift == 0) s->val[tid] = __uint_as_float(s->prefix[tid]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) h[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_hsi_apply(uint8_t* __restrict__ img, cb_params P, const hsi_state* __restrict__ st)
+{
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const size_t npx = (size_t)P.w * P.h;
+    uint8_t* fs = img + (size_t)f * npx * 3;
+    const float s_min = st[f].val[0], s_max = st[f].val[1], i_min = st[f].val[2], i_max = st[f].val[3];
+    const float s_mult = (float)(1. / (double)(s_max - s_min)), i_mult = (float)(255. / (double)(i_max - i_min));   // cpp:747-748
+    for (size_t p = (size_t)blockIdx.x * 256 + tid; p < npx; p += (size_t)gridDim.x * 256) {
+        int b = fs[3 * p], g = fs[3 * p + 1], r = fs[3 * p + 2];
+        float S, I;
+        cb_rgb2si(r, g, b, S, I);
+        const float H = cb_rgb2h(r, g, b);
+        S = cb_clipf(S, s_min, s_max);
+        I = cb_clipf(I, i_min, i_max);
+        S = (S - s_min) * s_mult;
+        I = (I - i_min) * i_mult;
+        S = cb_clipf(S, 0.f, 1.f);
+        I = cb_clipf(I, 0.f, 255.f);
+        cb_hsi2rgb(H, S, I, r, g, b);
+        fs[3 * p] = (uint8_t)b; fs[3 * p + 1] = (uint8_t)g; fs[3 * p + 2] = (uint8_t)r;
+    }
+}
+
 // HSV -> BGR as an operator (cv2.cvtColor(COLOR_HSV2BGR), 8-bit): packed rows
 __global__ __launch_bounds__(256) void k_hsv2bgr(const uint8_t* __restrict__ src, size_t npx, uint8_t* __restrict__ dst)
 {
@@ -385,13 +549,12 @@ int vpk_hsv2bgr(vp_ctx* ctx, const uint8_t* d_src, size_t npx, uint8_t* d_dst)
     return VP_OK;
 }
 
-size_t vp_balance_ws_bytes(int n, int tiles) { return vp_align((size_t)n * tiles * 768 * 4) + vp_align((size_t)n * 512 * 4) + vp_align((size_t)n * tiles * 768) +
-                                                      vp_align((size_t)n * 512) + vp_align(sizeof(cb_plan) * (size_t)n) + 4096; }
+size_t vp_balance_ws_bytes(int n, int tiles) { return vp_align((size_t)n * tiles * 768 * 4) + vp_align((size_t)n * 1024 * 4) + vp_align((size_t)n * tiles * 768) +
+                                                      vp_align((size_t)n * 512) + vp_align(sizeof(cb_plan) * (size_t)n) + vp_align(sizeof(hsi_state) * (size_t)n) + 4096; }
 
 // d_src / d_dst: (n, h, w, 3) packed; d_dst may equal d_src.  Frames must start 4-byte aligned (w*h*3 % 4 == 0 or n == 1).
 int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int flags, int hblocks, int vblocks)
 {
-    if (flags & VP_CB_HSI_CONTRAST) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: hsi_contrast_correct is not implemented");
     if (hblocks <= 0 || vblocks <= 0) return vp_fail(ctx, VP_ERR_INVALID, "colour balance: tiles");
     if ((flags & VP_CB_EQUALIZE_RGB) && (w % hblocks || h % vblocks))
         return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: tiles must divide the frame (the reference wraps rows otherwise)");
@@ -402,11 +565,12 @@ int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, 
     if (n > 1 && (npx * 3) % 4) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: batched frames must be 4-byte aligned");
     cb_params P = {w, h, n, flags, hblocks, vblocks, w / hblocks, h / vblocks};
     u32* hist = (u32*)vp_ws_take(ctx, (size_t)n * tiles * 768 * 4);
-    u32* svhist = (u32*)vp_ws_take(ctx, (size_t)n * 512 * 4);
+    u32* svhist = (u32*)vp_ws_take(ctx, (size_t)n * 1024 * 4);   // S/V histograms; reused as the four radix histograms of the HSI stage
     uint8_t* lut = (uint8_t*)vp_ws_take(ctx, (size_t)n * tiles * 768);
     uint8_t* svlut = (uint8_t*)vp_ws_take(ctx, (size_t)n * 512);
     cb_plan* plans = (cb_plan*)vp_ws_take(ctx, sizeof(cb_plan) * (size_t)n);
-    if (!hist || !svhist || !lut || !svlut || !plans) return vp_fail(ctx, VP_ERR_NOMEM, "colour balance workspace");
+    hsi_state* hst = (hsi_state*)vp_ws_take(ctx, sizeof(hsi_state) * (size_t)n);
+    if (!hist || !svhist || !lut || !svlut || !plans || !hst) return vp_fail(ctx, VP_ERR_NOMEM, "colour balance workspace");
     hipStream_t s = ctx->stream;
     const bool tiled = tiles > 1, hsv = (flags & VP_CB_HSV_CONTRAST) != 0;
     // enough blocks to fill the chip, few enough that the per-block table loads and histogram flushes stay small
@@ -429,6 +593,15 @@ int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, 
     } else {
         if (hsv) hipLaunchKernelGGL((k_cb_apply<false, true>), grid, dim3(256), 0, s, d_src, d_dst, P, ctx->tab, lut, svlut);
         else hipLaunchKernelGGL((k_cb_apply<false, false>), grid, dim3(256), 0, s, d_src, d_dst, P, ctx->tab, lut, svlut);
+    }
+    if (flags & VP_CB_HSI_CONTRAST) {
+        VP_HIP(ctx, hipMemsetAsync(svhist, 0, (size_t)n * 1024 * 4, s));
+        hipLaunchKernelGGL(k_hsi_init, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, hst);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(k_hsi_hist, grid, dim3(256), 0, s, d_dst, P, hst, shift, svhist);
+            hipLaunchKernelGGL(k_hsi_pick, dim3((unsigned)n), dim3(256), 0, s, hst, svhist, shift);
+        }
+        hipLaunchKernelGGL(k_hsi_apply, grid, dim3(256), 0, s, d_dst, P, hst);
     }
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;

@@ -6,9 +6,8 @@
  * (vp_color_balance_u8, include/vp.h) with one process-wide context created on first use.
  *
  * arr: (height, width, depth = 3) BGR uint8, modified in place.  Returns 0, or a negative VP_ERR_* code
- * (the reference always returns 0; it has no error path).  Not implemented: hsi_contrast_correct, and
- * horizontal_blocks / vertical_blocks that do not divide the frame — both return VP_ERR_UNSUPPORTED (-4) and
- * leave arr untouched.  Device selection: environment variable VP_DEVICE (default 0).
+ * (the reference always returns 0; it has no error path).  Not implemented: horizontal_blocks / vertical_blocks
+ * that do not divide the frame — returns VP_ERR_UNSUPPORTED (-4) and leaves arr untouched.  Device selection: environment variable VP_DEVICE (default 0).
  */
 #ifndef COLOR_BALANCE_C_H
 #define COLOR_BALANCE_C_H

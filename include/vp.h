@@ -91,8 +91,8 @@ int vp_cvt_bgr2lab_f32(vp_ctx* ctx, const float* src_host, int w, int h, float* 
 /* utils/color_correction/color_balance.hpp:9-14 `process_frame` (modules/color_balance.py:93-110 `balance`,
  * modules/preprocessor.py:87-88): colour-cast equalisation, optional RGB / HSV contrast stretch, 0.2 % extrema clipping.
  * flags = OR of VP_CB_*; the reference's default call is VP_CB_DEFAULT with 1x1 tiles.  Not implemented
- * (VP_ERR_UNSUPPORTED): VP_CB_HSI_CONTRAST, and tilings that do not divide the frame (the reference wraps into the next
- * row and processes pixels twice there).  src and dst are (h,w,3) BGR, tightly packed; dst may equal src. */
+ * (VP_ERR_UNSUPPORTED): tilings that do not divide the frame (the reference wraps into the next row and processes
+ * pixels twice there).  src and dst are (h,w,3) BGR, tightly packed; dst may equal src. */
 enum { VP_CB_EQUALIZE_RGB = 1, VP_CB_RGB_CONTRAST = 2, VP_CB_HSV_CONTRAST = 4, VP_CB_HSI_CONTRAST = 8, VP_CB_EXTREMA_CLIPPING = 16,
        VP_CB_ADAPTIVE_CAST = 32, VP_CB_DEFAULT = 1 | 4 | 16 };
 int vp_color_balance_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int flags, int horizontal_blocks, int vertical_blocks,
@@ -175,7 +175,7 @@ typedef struct vp_chain_buffers {  /* device pointers; any output may be NULL */
     int32_t* nlabels;              /* (n) */
 } vp_chain_buffers;
 
-/* Enqueues the whole chain for n frames on the context's stream and returns without
+/* Enqueues the whole chain for n frames (n <= 65535, width*height <= 2^30) on the context's stream and returns without
  * synchronising.  This is the hot path bench.py times (one call = one "step"). */
 int vp_chain_run(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* dev, int n_frames);
 /* Same with host buffers: H2D, chain, D2H, synchronised on return. */

@@ -25,6 +25,9 @@
 #include <string.h>
 
 #define ORC_API __attribute__((visibility("default")))
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 
 void orc_bgr2hsv_u8(const uint8_t* src, size_t sstride, int w, int h, uint8_t* dst, size_t dstride);
 
@@ -136,7 +139,91 @@ static double mean_u8(const uint8_t* c, size_t n)   /* cv::mean: exact integer s
     return (double)s / (double)n;
 }
 
-/* process_frame(arr, height, width, depth = 3, ...) — cpp:343-780.  hsi_contrast_correct is not restated (returns -4).
+/* ---- HSI stage (cpp:141-341, 678-775) ---------------------------------------------------------------------
+ * float/double mixing follows the C++ expressions operand by operand ((float)x op float -> float; anything touching a
+ * double literal or a <cmath> call -> double; stores to float arrays round to float).  `sqrt` is taken as the double
+ * function on the (exactly representable) float radicand.  glibc's acos/cos are correctly rounded in almost all cases;
+ * a device libm may differ in the last bit, which is why GPU parity for this stage is stated with a tolerance of 1. */
+static int feq(float a, float b) { return fabs(a - b) < 0.000001; }   /* cpp:9-11: float difference, double compare */
+static uint8_t uchar_clip(float f)   /* cpp:155-164; (int) of NaN / out-of-range floats as x86 cvttss2si: INT_MIN */
+{
+    int n = (f > -2147483904.f && f < 2147483648.f) ? (int)f : INT32_MIN;
+    if (n < 0) n = 0; else if (n > 255) n = 255;
+    return (uint8_t)n;
+}
+static void clip_channel_f(float* c, size_t n, float mn, float mx)   /* cpp:47-69 */
+{
+    for (size_t i = 0; i < n; i++) {
+        if (c[i] < mn) c[i] = mn;
+        else if (c[i] > mx) c[i] = mx;
+        else if (isnan(c[i])) c[i] = mn;
+        else if (isinf(c[i])) c[i] = mx;
+    }
+}
+static void rgb_to_hsi_px(uint8_t r, uint8_t g, uint8_t b, float* H, float* S, float* I)   /* cpp:166-215 */
+{
+    uint8_t mn = 255;
+    *I = (float)(((float)r + (float)g + (float)b) / 3.);
+    if (r < mn) mn = r;
+    if (g < mn) mn = g;
+    if (b < mn) mn = b;
+    if (*I > 0) *S = (float)(1. - ((float)mn / *I));
+    else *S = 0;
+    const float rad = (float)r * r + (float)g * g + (float)b * b - (float)(r * g) - (float)(r * b) - (float)(g * b);
+    *H = (float)acos(((float)r - (0.5 * g) - (0.5 * b)) / sqrt((double)rad));
+    if (b > g) *H = (float)((M_PI * 2) - *H);
+}
+static int cmp_f32(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return (x > y) - (x < y); }
+static void hsi_to_rgb_px(float h, float s, float i, uint8_t* r, uint8_t* g, uint8_t* b)   /* cpp:261-306 */
+{
+    if (feq(h, 0)) {
+        *r = uchar_clip(i + 2 * i * s); *g = uchar_clip(i - i * s); *b = uchar_clip(i - i * s);
+    } else if (0. < h && h < 2. * M_PI / 3.) {
+        *r = uchar_clip((float)(i + i * s * cos(h) / cos(M_PI / 3. - h)));
+        *g = uchar_clip((float)(i + i * s * (1 - cos(h) / cos(M_PI / 3. - h))));
+        *b = uchar_clip(i - i * s);
+    } else if (feq(h, (float)(2. * M_PI / 3.))) {
+        *r = uchar_clip(i - i * s); *g = uchar_clip(i + 2 * i * s); *b = uchar_clip(i - i * s);
+    } else if (2. * M_PI / 3. < h && h < 4. * M_PI / 3.) {
+        *r = uchar_clip(i - i * s);
+        *g = uchar_clip((float)(i + i * s * cos(h - 2. * M_PI / 3.) / cos(M_PI - h)));
+        *b = uchar_clip((float)(i + i * s * (1 - cos(h - 2. * M_PI / 3.) / cos(M_PI - h))));
+    } else if (feq(h, (float)(4. * M_PI / 3.))) {
+        *r = uchar_clip(i - i * s); *g = uchar_clip(i - i * s); *b = uchar_clip(i + 2 * i * s);
+    } else {
+        *r = uchar_clip((float)(i + i * s * (1 - cos(h - 4. * M_PI / 3.) / cos(5. * M_PI / 3. - h))));
+        *g = uchar_clip(i - i * s);
+        *b = uchar_clip((float)(i + i * s * cos(h - 4. * M_PI / 3.) / cos(5. * M_PI / 3. - h)));
+    }
+}
+/* cpp:678-775.  percentile_min_max_qselect (cpp:141-153) returns the low_bound-th and high_bound-th smallest values
+ * (0-based) - quickselect with random pivots is an exact order statistic - restated with a sort. */
+static void hsi_stage(uint8_t* rc, uint8_t* gc, uint8_t* bc, size_t n)
+{
+    float* H = (float*)malloc(n * 4);
+    float* S = (float*)malloc(n * 4);
+    float* I = (float*)malloc(n * 4);
+    float* tmp = (float*)malloc(n * 4);
+    for (size_t k = 0; k < n; k++) rgb_to_hsi_px(rc[k], gc[k], bc[k], &H[k], &S[k], &I[k]);
+    clip_channel_f(H, n, 0.f, (float)(2. * M_PI));
+    clip_channel_f(S, n, 0.f, 1.f);
+    clip_channel_f(I, n, 0.f, 255.f);
+    const int low_bound = (int)(0.002f * (float)n), high_bound = (int)(0.998f * (float)n);
+    memcpy(tmp, S, n * 4); qsort(tmp, n, 4, cmp_f32);
+    const float s_min = tmp[low_bound], s_max = tmp[high_bound < (int)n ? high_bound : (int)n - 1];
+    clip_channel_f(S, n, s_min, s_max);
+    memcpy(tmp, I, n * 4); qsort(tmp, n, 4, cmp_f32);
+    const float i_min = tmp[low_bound], i_max = tmp[high_bound < (int)n ? high_bound : (int)n - 1];
+    clip_channel_f(I, n, i_min, i_max);
+    const float s_mult = (float)(1. / (s_max - s_min)), i_mult = (float)(255. / (i_max - i_min));
+    for (size_t k = 0; k < n; k++) { S[k] = (S[k] - s_min) * s_mult; I[k] = (I[k] - i_min) * i_mult; }
+    clip_channel_f(S, n, 0.f, 1.f);
+    clip_channel_f(I, n, 0.f, 255.f);
+    for (size_t k = 0; k < n; k++) hsi_to_rgb_px(H[k], S[k], I[k], &rc[k], &gc[k], &bc[k]);
+    free(H); free(S); free(I); free(tmp);
+}
+
+/* process_frame(arr, height, width, depth = 3, ...) — cpp:343-780.
  * mean_mode 0: the running mean of cpp:452-467 literally (avg += (x - avg) / count, row-major inside the tile);
  * mean_mode 1: the same quantity as an exact sum / count (what a parallel implementation computes; differs from the
  * running mean by rounding noise of ~1e-13 relative).  hsv_variant: see orc_hsv2bgr_u8. */
@@ -145,7 +232,6 @@ ORC_API int orc_color_balance(uint8_t* arr, size_t height, size_t width, int equ
                               int adaptive_cast_correction, int horizontal_blocks, int vertical_blocks, int mean_mode,
                               int hsv_variant)
 {
-    if (hsi_contrast_correct) return -4;
     if (horizontal_blocks <= 0 || vertical_blocks <= 0 || !height || !width) return -1;
     const size_t n = height * width;
     uint8_t* bc = (uint8_t*)malloc(n);
@@ -260,6 +346,8 @@ ORC_API int orc_color_balance(uint8_t* arr, size_t height, size_t width, int equ
         for (size_t i = 0; i < n; i++) { bc[i] = bgr[3 * i]; gc[i] = bgr[3 * i + 1]; rc[i] = bgr[3 * i + 2]; }
         free(bgr); free(hsv); free(sc); free(vc);
     }
+
+    if (hsi_contrast_correct) hsi_stage(rc, gc, bc, n);   /* cpp:678-775 */
 
     for (size_t i = 0; i < n; i++) { arr[3 * i] = bc[i]; arr[3 * i + 1] = gc[i]; arr[3 * i + 2] = rc[i]; }   /* cv::merge cpp:777 */
     free(bc); free(gc); free(rc);

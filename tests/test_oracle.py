@@ -234,5 +234,8 @@ def test_color_balance_restatement(oracle):
     out = oracle.color_balance(f)
     hsv = oracle.bgr2hsv(out)
     assert hsv[:, :, 2].max() >= 250 and hsv[:, :, 2].min() <= 5
-    with pytest.raises(ValueError):
-        oracle.color_balance(f, hsi_contrast_correct=True)
+    # HSI stage alone: hue is kept (grey pixels stay grey), intensity spans the range afterwards
+    g = np.repeat(np.arange(0, 250, 1, dtype=np.uint8)[None, :, None], 40, 0).repeat(3, 2)      # a grey ramp
+    out = oracle.color_balance(g, equalize_rgb=False, hsv_contrast_correct=False, rgb_extrema_clipping=False, hsi_contrast_correct=True)
+    assert (out[:, :, 0] == out[:, :, 1]).all() and (out[:, :, 1] == out[:, :, 2]).all()
+    assert out.min() == 0 and out.max() >= 254 and (np.diff(out[0, :, 0].astype(int)) >= 0).all()
