@@ -257,6 +257,21 @@ def main():
         cpu = {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": f"{done} S1 1080p frames through oracle/vp_oracle.c orc_chain_u8 (scalar C, 1 thread, {dt:.1f} s); "
                          f"host has {os.cpu_count()} cores; cv2 absent so the reference's own cv2 path cannot be timed"}
+        # the same port, frame-parallel on this GPU's share of the host (ctypes releases the GIL): SURVEY 8d asks for both figures
+        from concurrent.futures import ThreadPoolExecutor
+        nthr = max(1, min(16, os.cpu_count() or 1))
+        per = max(2, int(args.cpu_seconds / 2 * cpu["value"]))
+
+        def _work(k):
+            for j in range(per):
+                orc.chain(distinct[(k + j) % len(distinct)], orc.MODE_LAB, (0, 150, 0), (255, 255, 255), [orc.OPEN, orc.CLOSE], 5, 5, 2, args.max_labels)
+            return per
+        t_start = time.perf_counter()
+        with ThreadPoolExecutor(nthr) as ex:
+            total = sum(ex.map(_work, range(nthr)))
+        dt = time.perf_counter() - t_start
+        extras["cpu_baseline_frame_parallel"] = {"value": round(total / dt, 2), "unit": "frames/s", "cores": nthr, "kind": "port",
+                                                 "sample": f"{total} frames, {nthr} threads x {per} frames each, {dt:.1f} s"}
 
     if rank == 0:
         out = {

@@ -226,6 +226,40 @@ def addWeighted(src1, alpha, src2, beta, gamma):
     return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
 
 
+def add(src1, src2):
+    """cv2.add with saturation; one operand may be a scalar (modules/preprocessor.py:90-103 adds a bias to a channel)."""
+    a, b = (src1, src2) if isinstance(src1, np.ndarray) else (src2, src1)
+    a = np.asarray(a)
+    if a.dtype != np.uint8:
+        raise error("add: only uint8 arrays are on the accelerated path")
+    if np.isscalar(b):
+        acc = a.astype(np.float64) + float(b)          # cv2 adds the scalar as a double, then saturate_cast (round half even)
+        return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    return np.clip(a.astype(np.int32) + np.asarray(b, np.int32), 0, 255).astype(np.uint8)
+
+
+def getRotationMatrix2D(center, angle, scale):
+    """imgproc/src/imgwarp.cpp getRotationMatrix2D: 2x3 float64 (modules/preprocessor.py:131-133)."""
+    ang = angle * np.pi / 180.0
+    a, b = scale * np.cos(ang), scale * np.sin(ang)
+    cx, cy = float(center[0]), float(center[1])
+    return np.array([[a, b, (1 - a) * cx - b * cy], [-b, a, b * cx + (1 - a) * cy]], np.float64)
+
+
+def _outside(name):
+    def _f(*_a, **_k):
+        raise error(f"cv2.{name} is outside the accelerated path of this build (modules/preprocessor.py uses it only when the "
+                    f"corresponding PPX_* option is switched on); install OpenCV to use it")
+    _f.__name__ = name
+    return _f
+
+
+GaussianBlur = _outside("GaussianBlur")
+warpAffine = _outside("warpAffine")
+resize = _outside("resize")
+BORDER_REPLICATE = 1
+
+
 def drawContours(image, contours, contourIdx, color, thickness=1):
     sel = contours if contourIdx < 0 else [contours[contourIdx]]
     _draw.draw_contours(image, [np.asarray(c) for c in sel], color, thickness)
