@@ -210,7 +210,7 @@ int vp_host_alloc(vp_ctx* ctx, size_t bytes, void** p)
 }
 int vp_host_free(vp_ctx* ctx, void* p)
 {
-    if (!ctx) return VP_ERR_INVALID;
+    if (!ctx) return hipHostFree(p) == hipSuccess ? VP_OK : VP_ERR_HIP;   // page-locked memory is not tied to a context
     VP_HIP(ctx, hipHostFree(p));
     return VP_OK;
 }

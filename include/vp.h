@@ -219,7 +219,7 @@ int vp_dev_alloc(vp_ctx* ctx, size_t bytes, void** dev_ptr);
 int vp_dev_free(vp_ctx* ctx, void* dev_ptr);
 /* Page-locked host memory: transfers to/from it run at PCIe speed (hipHostMalloc / hipHostFree). */
 int vp_host_alloc(vp_ctx* ctx, size_t bytes, void** host_ptr);
-int vp_host_free(vp_ctx* ctx, void* host_ptr);
+int vp_host_free(vp_ctx* ctx, void* host_ptr);   /* ctx may be NULL */
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
 int vp_memcpy_d2h(vp_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
 

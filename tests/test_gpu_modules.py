@@ -44,8 +44,11 @@ def test_facade_matches_oracle(vp, oracle, cv2mod):
     vis = cv2.cvtColor(mask, cv2.COLOR_GRAY2BGR)
     over = cv2.addWeighted(img, 0.7, vis, 0.3, 0)
     assert over.dtype == np.uint8 and over.shape == img.shape
-    with pytest.raises(AttributeError):
-        cv2.GaussianBlur
+    with pytest.raises(cv2.error):          # named, but outside the accelerated path: fails loudly instead of falling back
+        cv2.GaussianBlur(img, (5, 5), 0)
+    assert cv2.add(10, np.array([[250, 3]], np.uint8)).tolist() == [[255, 13]]
+    assert np.allclose(cv2.getRotationMatrix2D((10, 5), 90, 1), [[0, 1, 5], [-1, 0, 15]])
+    assert np.array_equal(cv2.cvtColor(cv2.cvtColor(img, cv2.COLOR_BGR2HSV), cv2.COLOR_HSV2BGR), oracle.hsv2bgr(oracle.bgr2hsv(img)))
 
 
 def test_rotated_rect_helpers(cv2mod):
