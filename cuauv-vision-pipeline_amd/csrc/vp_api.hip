@@ -581,7 +581,7 @@ int vp_color_distance_u8(vp_ctx* ctx, const uint8_t* const* planes, int w, int h
 
 // one erode or dilate (after cv2 normalisation) on a device image; result in d_out
 static int morph_basic_dev(vp_ctx* ctx, int dilate, const norm_se& se, const uint8_t* d_in, int w, int h, int cn, bool binary,
-                           uint8_t* d_out, uint8_t* d_tmp, u64* bits_a, u64* bits_b, int16_t* d_offs)
+                           uint8_t* d_out, uint8_t* d_tmp, u64* bits_a, u64* bits_b, int16_t* d_offs, uint8_t* d_tab = nullptr)
 {
     const size_t nbytes = (size_t)w * h * cn;
     if (se.iterations == 0 || se.kw * se.kh == 1) {
@@ -615,12 +615,31 @@ static int morph_basic_dev(vp_ctx* ctx, int dilate, const norm_se& se, const uin
         return VP_OK;
     }
     const int noffs = (int)(offs.size() / 2);
+    // span form when it saves reads: one (dy, x0, x1) triple per run of members in a row of the element
+    std::vector<int16_t> spans;
+    int max_len = 1;
+    for (int i = 0; i < se.kh; i++)
+        for (int j = 0; j < se.kw;) {
+            if (!se.k[(size_t)i * se.kw + j]) { j++; continue; }
+            int e = j;
+            while (e + 1 < se.kw && se.k[(size_t)i * se.kw + e + 1]) e++;
+            spans.push_back((int16_t)(i - se.ay)); spans.push_back((int16_t)(j - se.ax)); spans.push_back((int16_t)(e - se.ax));
+            max_len = std::max(max_len, e - j + 1);
+            j = e + 1;
+        }
+    const int nspans = (int)(spans.size() / 3);
+    const bool use_spans = d_tab && 2 * nspans < noffs && max_len <= 255 && nspans <= 2048 && (size_t)w * cn <= 16384;
+    if (use_spans) {
+        VP_HIP(ctx, hipMemcpyAsync(d_offs, spans.data(), spans.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+        VP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // spans is a local vector
+    }
     const uint8_t* cur = d_in;
     uint8_t* bufs[2] = {d_out, d_tmp};
     // arrange so that the last pass lands in d_out
     int which = (se.iterations % 2 == 1) ? 0 : 1;
     for (int it = 0; it < se.iterations; it++) {
-        VP_TRY(vpk_morph_generic(ctx, dilate, cur, w, h, cn, d_offs, noffs, bufs[which]));
+        if (use_spans) VP_TRY(vpk_morph_spans(ctx, dilate, cur, w, h, cn, d_offs, nspans, max_len, d_tab, bufs[which]));
+        else VP_TRY(vpk_morph_generic(ctx, dilate, cur, w, h, cn, d_offs, noffs, bufs[which]));
         cur = bufs[which];
         which ^= 1;
     }
@@ -638,8 +657,11 @@ int vp_morph_u8(vp_ctx* ctx, int op, const uint8_t* src, int w, int h, int cn, c
     const size_t nbytes = (size_t)w * h * cn;
     const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
     const size_t offbytes = ((size_t)se.kw * se.kh + se.kw + se.kh) * 4 + 64;
-    VP_TRY(vp_ws_reserve(ctx, 5 * vp_align(nbytes) + 2 * vp_align(bitbytes) + vp_align(offbytes) + 4096));
+    const size_t tabbytes = se.allones ? 0 : 7 * nbytes;   // running min/max tables of the span form
+    VP_TRY(vp_ws_reserve(ctx, 5 * vp_align(nbytes) + 2 * vp_align(bitbytes) + vp_align(offbytes) + vp_align(tabbytes) + 4096));
     TAKE(d_src, uint8_t*, nbytes);
+    uint8_t* d_tab = tabbytes ? (uint8_t*)vp_ws_take(ctx, tabbytes) : nullptr;
+    if (tabbytes && !d_tab) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
     TAKE(d_a, uint8_t*, nbytes);
     TAKE(d_b, uint8_t*, nbytes);
     TAKE(d_c, uint8_t*, nbytes);
@@ -667,14 +689,14 @@ int vp_morph_u8(vp_ctx* ctx, int op, const uint8_t* src, int w, int h, int cn, c
         if (!(se.iterations == 0 || se.kw * se.kh == 1)) stages_for_op(st, op, k);
         VP_TRY(run_bit_stages(ctx, st, bits_a, bits_b, w, h, 1, nullptr, d_a));
     } else if (op == VP_MORPH_ERODE || op == VP_MORPH_DILATE) {
-        VP_TRY(morph_basic_dev(ctx, op == VP_MORPH_DILATE, se, d_src, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs));
+        VP_TRY(morph_basic_dev(ctx, op == VP_MORPH_DILATE, se, d_src, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs, d_tab));
     } else if (op == VP_MORPH_OPEN || op == VP_MORPH_CLOSE) {
         const int first = op == VP_MORPH_CLOSE;
-        VP_TRY(morph_basic_dev(ctx, first, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs));
-        VP_TRY(morph_basic_dev(ctx, !first, se, d_b, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs));
+        VP_TRY(morph_basic_dev(ctx, first, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs, d_tab));
+        VP_TRY(morph_basic_dev(ctx, !first, se, d_b, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs, d_tab));
     } else {  // GRADIENT = dilate - erode
-        VP_TRY(morph_basic_dev(ctx, 1, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs));
-        VP_TRY(morph_basic_dev(ctx, 0, se, d_src, w, h, cn, binary, d_c, d_tmp, bits_a, bits_b, d_offs));
+        VP_TRY(morph_basic_dev(ctx, 1, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs, d_tab));
+        VP_TRY(morph_basic_dev(ctx, 0, se, d_src, w, h, cn, binary, d_c, d_tmp, bits_a, bits_b, d_offs, d_tab));
         VP_TRY(vpk_absdiff_sub_u8(ctx, d_b, d_c, nbytes, d_a));
     }
     VP_TRY(d2h(ctx, dst, result, nbytes));

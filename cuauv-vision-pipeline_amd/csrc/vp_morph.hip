@@ -414,6 +414,84 @@ int vpk_morph_generic(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int 
     return VP_OK;
 }
 
+// ---- span form of the same operator ------------------------------------------------------------------------------------------
+// A structuring element is a list of horizontal spans (dy, x0..x1), one per run of members in each of its rows (an ellipse
+// has one span per row).  With running min/max tables over windows of 1, 2, 4, ... 128 pixels of every row
+// (T_j[x] = op over [x, x + 2^j - 1], clipped at the row end), the op over any span is the op of two table entries, so a
+// pixel costs two reads per span instead of one per member: 202 instead of 7,845 for the 101 x 101 ellipse of
+// modules/preprocessor.py:120-129.  Out-of-image pixels never win (cv2's default border for morphology) because spans are
+// clipped to the row and rows outside the image are skipped.
+#define MS_MAX_LEVELS 7          // windows up to 255 pixels
+#define MS_MAX_ROWBYTES 16384    // one row in LDS, twice
+#define MS_MAX_SPANS 2048
+
+// one block per row: tab[j-1][y][p] for j = 1..levels
+__global__ __launch_bounds__(256) void k_morph_table(int dilate, const uint8_t* __restrict__ src, int rowbytes, int cn, int levels, size_t plane,
+                                                     uint8_t* __restrict__ tab)
+{
+    extern __shared__ uint8_t ms_lds[];
+    uint8_t* A = ms_lds;
+    uint8_t* B = ms_lds + rowbytes;
+    const int y = blockIdx.x;
+    const uint8_t* row = src + (size_t)y * rowbytes;
+    for (int p = threadIdx.x; p < rowbytes; p += 256) A[p] = row[p];
+    __syncthreads();
+    for (int j = 1; j <= levels; j++) {
+        const int s = (1 << (j - 1)) * cn;
+        uint8_t* out = tab + (size_t)(j - 1) * plane + (size_t)y * rowbytes;
+        for (int p = threadIdx.x; p < rowbytes; p += 256) {
+            const int a = A[p], b = p + s < rowbytes ? A[p + s] : a;
+            const uint8_t v = (uint8_t)(dilate ? max(a, b) : min(a, b));
+            B[p] = v;
+            out[p] = v;
+        }
+        __syncthreads();
+        uint8_t* t = A; A = B; B = t;
+    }
+}
+
+// spans: nspans triples (dy, x0, x1) relative to the anchor.  One thread per (x, channel) of row blockIdx.y.
+__global__ __launch_bounds__(256) void k_morph_spans(int dilate, const uint8_t* __restrict__ src, const uint8_t* __restrict__ tab, size_t plane, int w,
+                                                     int h, int cn, const int16_t* __restrict__ spans, int nspans, uint8_t* __restrict__ dst)
+{
+    __shared__ int16_t sp[3 * MS_MAX_SPANS];
+    for (int i = threadIdx.x; i < 3 * nspans; i += 256) sp[i] = spans[i];
+    __syncthreads();
+    const int xc = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (xc >= w * cn) return;
+    const int x = xc / cn, c = xc - x * cn;
+    const size_t rowbytes = (size_t)w * cn;
+    int best = dilate ? 0 : 255;
+    for (int k = 0; k < nspans; k++) {
+        const int yy = y + sp[3 * k];
+        if (yy < 0 || yy >= h) continue;
+        const int l = max(x + sp[3 * k + 1], 0), r = min(x + sp[3 * k + 2], w - 1);
+        if (l > r) continue;
+        const int j = 31 - __clz(r - l + 1);
+        const uint8_t* T = (j == 0 ? src : tab + (size_t)(j - 1) * plane) + (size_t)yy * rowbytes + c;
+        const int a = T[(size_t)l * cn], b = T[(size_t)(r - (1 << j) + 1) * cn];
+        best = dilate ? max(best, max(a, b)) : min(best, min(a, b));
+    }
+    dst[(size_t)y * rowbytes + xc] = (uint8_t)best;
+}
+
+int vpk_morph_spans(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int h, int cn, const int16_t* d_spans, int nspans, int max_len,
+                    uint8_t* d_tab, uint8_t* d_dst)
+{
+    const int rowbytes = w * cn;
+    int levels = 0;
+    while ((2 << levels) <= max_len) levels++;   // largest j with 2^j <= max_len
+    if (levels > MS_MAX_LEVELS || rowbytes > MS_MAX_ROWBYTES || nspans > MS_MAX_SPANS) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "span morphology limits");
+    const size_t plane = (size_t)rowbytes * h;
+    if (levels > 0)
+        hipLaunchKernelGGL(k_morph_table, dim3((unsigned)h), dim3(256), 2 * (size_t)rowbytes, ctx->stream, dilate, d_src, rowbytes, cn, levels, plane, d_tab);
+    dim3 grid((unsigned)((rowbytes + 255) / 256), (unsigned)h);
+    hipLaunchKernelGGL(k_morph_spans, grid, dim3(256), 0, ctx->stream, dilate, d_src, d_tab, plane, w, h, cn, d_spans, nspans, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
 __global__ __launch_bounds__(256) void k_sub_sat_u8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
                                                     uint8_t* __restrict__ dst)
 {

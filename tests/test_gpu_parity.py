@@ -150,6 +150,36 @@ def test_morph_grey_and_ellipse(vp, oracle, h, w):
     assert np.array_equal(T.erode(g, None), oracle.morph(oracle.ERODE, g, None))
 
 
+def test_morph_span_form_large_and_irregular_elements(vp, oracle):
+    """The span form of the generic operator (running min/max tables): the preprocessor's largest ellipse (side 2*50+1,
+    modules/preprocessor.py:120-129), elements wider than the image, irregular elements with several runs per row, off-centre
+    anchors, iterations, 1/3/4 channels, image widths around the table's power-of-two windows."""
+    from vision.utils import transform as T
+    from vision import _vp
+    rng = np.random.default_rng(7)
+    imgs = [rng.integers(0, 256, (97, 130), dtype=np.uint8), _rand_bgr(rng, 120, 161), rng.integers(0, 256, (33, 65, 4), dtype=np.uint8)]
+    for img in imgs:
+        for k in (T.elliptic_kernel(101), T.elliptic_kernel(51, 9), T.elliptic_kernel(5, 77), T.elliptic_kernel(255, 3)):
+            assert np.array_equal(T.erode(img, k), oracle.morph(oracle.ERODE, img, k))
+            assert np.array_equal(T.dilate(img, k), oracle.morph(oracle.DILATE, img, k))
+    img = imgs[1]
+    for t in range(6):
+        kh, kw = int(rng.integers(1, 12)), int(rng.integers(2, 40))
+        k = (rng.random((kh, kw)) < 0.7).astype(np.uint8)          # several runs per row
+        k[kh // 2, kw // 2] = 1
+        assert np.array_equal(T.erode(img, k), oracle.morph(oracle.ERODE, img, k)), (kh, kw)
+        assert np.array_equal(T.dilate(img, k, iterations=2), oracle.morph(oracle.DILATE, img, k, iterations=2)), (kh, kw)
+    cross = np.zeros((21, 21), np.uint8); cross[10, :] = 1; cross[:, 10] = 1
+    assert np.array_equal(T.morph_borders(img, cross), oracle.morph(oracle.GRADIENT, img, cross))
+    # off-centre anchor through the C ABI
+    k = T.elliptic_kernel(31, 15)
+    g = imgs[0]
+    out = np.empty_like(g)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_morph_u8(ctx.handle, _vp.MORPH_ERODE, _vp.ptr(g), g.shape[1], g.shape[0], 1, _vp.ptr(k), 31, 15, 3, 12, 1, _vp.ptr(out)), ctx.handle)
+    assert np.array_equal(out, oracle.morph(oracle.ERODE, g, k, anchor=(3, 12)))
+
+
 def _check_ccl(vp, oracle, m, numbering):
     from vision.utils import feature
     n, lab, st, ce = feature.connected_components(m, numbering=numbering, max_labels=m.size // 1 + 2)
