@@ -1059,6 +1059,65 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
     return vp_synchronize(ctx);
 }
 
+static int check_lb(vp_ctx* ctx, const void* src, const void* dst, int w, int h, int dw, int dh, int pad)
+{
+    if (!src || !dst || w <= 0 || h <= 0 || dw <= 0 || dh <= 0 || dh > 65535 || pad < 0 || pad > 255) return vp_fail(ctx, VP_ERR_INVALID, "letterbox arguments");
+    return VP_OK;
+}
+
+int vp_letterbox_u8_f32(vp_ctx* ctx, const uint8_t* src, int w, int h, int dw, int dh, int pad, float* dst, float* geom_out)
+{
+    VP_TRY(check_ctx(ctx));
+    VP_TRY(check_lb(ctx, src, dst, w, h, dw, dh, pad));
+    const size_t sbytes = (size_t)w * h * 3, dbytes = (size_t)dw * dh * 12;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(sbytes) + vp_align(dbytes) + 1024));
+    TAKE(d_src, uint8_t*, sbytes);
+    TAKE(d_dst, float*, dbytes);
+    VP_TRY(h2d(ctx, d_src, src, sbytes));
+    VP_TRY(vpk_letterbox(ctx, d_src, w, h, dw, dh, pad, d_dst, geom_out));
+    VP_TRY(d2h(ctx, dst, d_dst, dbytes));
+    return vp_synchronize(ctx);
+}
+
+int vp_letterbox_dev(vp_ctx* ctx, const uint8_t* src, int w, int h, int dw, int dh, int pad, float* dst, float* geom_out)
+{
+    VP_TRY(check_ctx(ctx));
+    VP_TRY(check_lb(ctx, src, dst, w, h, dw, dh, pad));
+    return vpk_letterbox(ctx, src, w, h, dw, dh, pad, dst, geom_out);
+}
+
+int vp_nms_f32(vp_ctx* ctx, const float* boxes, const float* scores, int n, float thr, int rotated, int max_keep, int32_t* keep_out,
+               int32_t* n_keep_out)
+{
+    VP_TRY(check_ctx(ctx));
+    if (n < 0 || max_keep < 0 || !n_keep_out || (n > 0 && (!boxes || !scores)) || (max_keep > 0 && !keep_out))
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_nms_f32 arguments");
+    *n_keep_out = 0;
+    if (n == 0 || max_keep == 0) return VP_OK;
+    const int bs = rotated ? 5 : 4;
+    VP_TRY(vp_ws_reserve(ctx, vp_align((size_t)n * bs * 4) + vp_align((size_t)n * 4) + vp_align((size_t)max_keep * 4) + vp_nms_ws_bytes(n) + 2048));
+    TAKE(d_boxes, float*, (size_t)n * bs * 4);
+    TAKE(d_scores, float*, (size_t)n * 4);
+    TAKE(d_keep, int*, (size_t)max_keep * 4);
+    TAKE(d_nk, int*, 4);
+    VP_TRY(h2d(ctx, d_boxes, boxes, (size_t)n * bs * 4));
+    VP_TRY(h2d(ctx, d_scores, scores, (size_t)n * 4));
+    VP_TRY(vpk_nms(ctx, d_boxes, d_scores, n, thr, rotated ? 1 : 0, max_keep, d_keep, d_nk));
+    VP_TRY(d2h(ctx, n_keep_out, d_nk, 4));
+    VP_TRY(vp_synchronize(ctx));
+    if (*n_keep_out > 0) { VP_TRY(d2h(ctx, keep_out, d_keep, (size_t)*n_keep_out * 4)); VP_TRY(vp_synchronize(ctx)); }
+    return VP_OK;
+}
+
+int vp_nms_dev(vp_ctx* ctx, const float* boxes, const float* scores, int n, float thr, int rotated, int max_keep, int32_t* keep_out,
+               int32_t* n_keep)
+{
+    VP_TRY(check_ctx(ctx));
+    if (n < 0 || max_keep <= 0 || !n_keep || !keep_out || (n > 0 && (!boxes || !scores))) return vp_fail(ctx, VP_ERR_INVALID, "vp_nms_dev arguments");
+    VP_TRY(vp_ws_reserve(ctx, vp_nms_ws_bytes(n > 0 ? n : 1) + 2048));
+    return vpk_nms(ctx, boxes, scores, n, thr, rotated ? 1 : 0, max_keep, keep_out, n_keep);
+}
+
 uint64_t vp_chain_algorithmic_bytes(const vp_chain_desc* desc, const vp_chain_buffers* bufs, int n)
 {
     if (!desc || !bufs || n <= 0) return 0;

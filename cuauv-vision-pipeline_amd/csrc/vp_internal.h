@@ -99,6 +99,11 @@ int vpk_hsv2bgr(vp_ctx* ctx, const uint8_t* d_src, size_t npx, uint8_t* d_dst);
 size_t vp_balance_ws_bytes(int n, int tiles);
 int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int flags, int hblocks, int vblocks);
 
+// ---- detector pre / post-processing (vp_yolo.hip) ------------------------------------------------
+int vpk_letterbox(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int dw, int dh, int pad, float* d_dst, float* geom_out);
+size_t vp_nms_ws_bytes(int n);
+int vpk_nms(vp_ctx* ctx, const float* d_boxes, const float* d_scores, int n, float thr, int rotated, int max_keep, int* d_keep, int* d_nkeep);
+
 // ---- morphology (vp_morph.hip) ---------------------------------------------------------------
 struct vp_bitstage { int dilate; int l, r, u, d; };  // window [-l, r] x [-u, d]
 #define VP_MAX_STAGES 32

@@ -214,6 +214,26 @@ int vp_chain_run_contours(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain
 int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_chain_buffers* host, const vp_contour_desc* cdesc,
                                const vp_contour_buffers* chost, int n_frames);
 
+/* ---- detector pre / post-processing (BASELINE config 5) ----------------------
+ * modules/yolo.py:112 `self.model.track(image)` hides these steps inside ultralytics (not in the reference tree, not
+ * installed): LetterBox (scale to fit, centre, pad, BGR->RGB, HWC->CHW, /255) before the network, non-maximum suppression
+ * after it.  Checked against plain PyTorch fp32 restatements; parity with the third-party package is unpinned.
+ *
+ * vp_letterbox_*: src (h,w,3) BGR uint8 -> dst (3,dst_h,dst_w) float32 RGB in [0,1]; the resize is cv2.resize INTER_LINEAR's
+ * 8-bit arithmetic; geom_out (3 floats, may be NULL) = {scale r, left pad, top pad} for mapping boxes back.
+ * vp_nms_*: boxes (n,4) x1,y1,x2,y2 (rotated: (n,5) x,y,w,h,angle[rad]), scores (n); keep_out receives up to max_keep original
+ * indices in descending score order (ties: lower index first).  rotated = 0: greedy, suppress IoU > thr.  rotated = 1:
+ * probabilistic IoU of the boxes' Gaussian models; a box is dropped when any higher-scored box overlaps it by >= thr.
+ * n <= 16384.  The _dev forms take device pointers (e.g. tensors of a PyTorch-ROCm model via data_ptr()), enqueue on the
+ * context's stream and return without synchronising. */
+int vp_letterbox_u8_f32(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int dst_w, int dst_h, int pad_value, float* dst_host,
+                        float* geom_out);
+int vp_letterbox_dev(vp_ctx* ctx, const uint8_t* src_dev, int w, int h, int dst_w, int dst_h, int pad_value, float* dst_dev, float* geom_out);
+int vp_nms_f32(vp_ctx* ctx, const float* boxes_host, const float* scores_host, int n, float thr, int rotated, int max_keep,
+               int32_t* keep_out_host, int32_t* n_keep_out);
+int vp_nms_dev(vp_ctx* ctx, const float* boxes_dev, const float* scores_dev, int n, float thr, int rotated, int max_keep,
+               int32_t* keep_out_dev, int32_t* n_keep_dev);
+
 /* ---- device memory helpers (so a host program needs no HIP binding of its own) --------- */
 int vp_dev_alloc(vp_ctx* ctx, size_t bytes, void** dev_ptr);
 int vp_dev_free(vp_ctx* ctx, void* dev_ptr);
