@@ -1065,6 +1065,20 @@ static int check_lb(vp_ctx* ctx, const void* src, const void* dst, int w, int h,
     return VP_OK;
 }
 
+int vp_resize_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int dw, int dh, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || dw <= 0 || dh <= 0 || dh > 65535 || cn < 1 || cn > 4) return vp_fail(ctx, VP_ERR_INVALID, "vp_resize_u8 arguments");
+    const size_t sbytes = (size_t)w * h * cn, dbytes = (size_t)dw * dh * cn;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(sbytes) + vp_align(dbytes) + 1024));
+    TAKE(d_src, uint8_t*, sbytes);
+    TAKE(d_dst, uint8_t*, dbytes);
+    VP_TRY(h2d(ctx, d_src, src, sbytes));
+    VP_TRY(vpk_resize_u8(ctx, d_src, w, h, cn, dw, dh, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, dbytes));
+    return vp_synchronize(ctx);
+}
+
 int vp_letterbox_u8_f32(vp_ctx* ctx, const uint8_t* src, int w, int h, int dw, int dh, int pad, float* dst, float* geom_out)
 {
     VP_TRY(check_ctx(ctx));

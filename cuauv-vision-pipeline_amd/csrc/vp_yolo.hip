@@ -49,6 +49,12 @@ __global__ __launch_bounds__(64) void k_letterbox(const uint8_t* __restrict__ sr
     if (P.nw == P.sw && P.nh == P.sh) {
         const uint8_t* p = src + ((size_t)cy * P.sw + cx) * 3;
         bgr[0] = p[0]; bgr[1] = p[1]; bgr[2] = p[2];
+    } else if (P.sw == 2 * P.nw && P.sh == 2 * P.nh) {
+        // cv2.resize turns INTER_LINEAR into the 2x2 box average at an exact halving (imgproc/src/resize.cpp)
+        const uint8_t* r0 = src + ((size_t)(2 * cy) * P.sw + 2 * cx) * 3;
+        const uint8_t* r1 = r0 + (size_t)P.sw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) bgr[c] = (r0[c] + r0[3 + c] + r1[c] + r1[3 + c] + 2) >> 2;
     } else {
         int sx, ax0, ax1, sy, ay0, ay1;
         lb_coef(cx, P.scale_x, P.sw, sx, ax0, ax1);
@@ -67,6 +73,46 @@ __global__ __launch_bounds__(64) void k_letterbox(const uint8_t* __restrict__ sr
     o[0] = (float)bgr[2] / 255.f;
     o[plane] = (float)bgr[1] / 255.f;
     o[2 * plane] = (float)bgr[0] / 255.f;
+}
+
+// cv2.resize(src, (dw, dh), interpolation=INTER_LINEAR) for 8-bit images with cn interleaved channels: thread = one destination byte
+__global__ __launch_bounds__(256) void k_resize_u8(const uint8_t* __restrict__ src, int sw, int sh, int cn, int dw, int dh, float scale_x, float scale_y,
+                                                   uint8_t* __restrict__ dst)
+{
+    const int xc = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xc >= dw * cn) return;
+    const int x = xc / cn, c = xc - x * cn;
+    int v;
+    if (sw == 2 * dw && sh == 2 * dh) {
+        const uint8_t* r0 = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+        const uint8_t* r1 = r0 + (size_t)sw * cn;
+        v = (r0[0] + r0[cn] + r1[0] + r1[cn] + 2) >> 2;
+    } else {
+        int sx, ax0, ax1, sy, ay0, ay1;
+        lb_coef(x, scale_x, sw, sx, ax0, ax1);
+        lb_coef(y, scale_y, sh, sy, ay0, ay1);
+        const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
+        const uint8_t* r0 = src + (size_t)sy * sw * cn + c;
+        const uint8_t* r1 = src + (size_t)sy1 * sw * cn + c;
+        const int S0 = r0[sx * cn] * ax0 + r0[sx1 * cn] * ax1;
+        const int S1 = r1[sx * cn] * ax0 + r1[sx1 * cn] * ax1;
+        v = (((ay0 * (S0 >> 4)) >> 16) + ((ay1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+    }
+    dst[((size_t)y * dw + x) * cn + c] = (uint8_t)v;
+}
+
+int vpk_resize_u8(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int cn, int dw, int dh, uint8_t* d_dst)
+{
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    if (sw == dw && sh == dh) {
+        VP_HIP(ctx, hipMemcpyAsync(d_dst, d_src, (size_t)sw * sh * cn, hipMemcpyDeviceToDevice, ctx->stream));
+        return VP_OK;
+    }
+    hipLaunchKernelGGL(k_resize_u8, dim3((unsigned)((dw * cn + 255) / 256), (unsigned)dh), dim3(256), 0, ctx->stream, d_src, sw, sh, cn, dw, dh,
+                       (float)((double)sw / dw), (float)((double)sh / dh), d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
 }
 
 // LetterBox geometry (scale-up allowed, centred): r = min(dh/sh, dw/sw); content = round(size * r); the odd padding pixel goes

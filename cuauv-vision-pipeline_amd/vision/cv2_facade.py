@@ -256,8 +256,26 @@ def _outside(name):
 
 GaussianBlur = _outside("GaussianBlur")
 warpAffine = _outside("warpAffine")
-resize = _outside("resize")
 BORDER_REPLICATE = 1
+INTER_LINEAR = 1
+
+
+def resize(src, dsize, interpolation=INTER_LINEAR):
+    """cv2.resize(src, (width, height)) with the default bilinear interpolation, uint8 images (modules/preprocessor.py:136-144)."""
+    from vision import _vp
+    if interpolation != INTER_LINEAR:
+        raise error("resize: only INTER_LINEAR is on the accelerated path")
+    src = np.ascontiguousarray(src)
+    if src.dtype != np.uint8 or src.ndim not in (2, 3) or src.size == 0:
+        raise error("resize: expected a non-empty uint8 image")
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dw, dh = int(dsize[0]), int(dsize[1])
+    if dw <= 0 or dh <= 0 or cn > 4:
+        raise error("resize: bad size")
+    out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_resize_u8(ctx.handle, _vp.ptr(src), src.shape[1], src.shape[0], cn, dw, dh, _vp.ptr(out)), ctx.handle)
+    return out
 
 
 def drawContours(image, contours, contourIdx, color, thickness=1):

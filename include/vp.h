@@ -226,6 +226,10 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
  * probabilistic IoU of the boxes' Gaussian models; a box is dropped when any higher-scored box overlaps it by >= thr.
  * n <= 16384.  The _dev forms take device pointers (e.g. tensors of a PyTorch-ROCm model via data_ptr()), enqueue on the
  * context's stream and return without synchronising. */
+/* cv2.resize(src, (dst_w, dst_h)) with the default INTER_LINEAR on 8-bit images, cn = 1..4 interleaved channels
+ * (modules/preprocessor.py:136-144): OpenCV's generic fixed-point path, including the 2x2 box average it substitutes at an
+ * exact halving.  (IPP-enabled OpenCV builds may round differently.) */
+int vp_resize_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int cn, int dst_w, int dst_h, uint8_t* dst_host);
 int vp_letterbox_u8_f32(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int dst_w, int dst_h, int pad_value, float* dst_host,
                         float* geom_out);
 int vp_letterbox_dev(vp_ctx* ctx, const uint8_t* src_dev, int w, int h, int dst_w, int dst_h, int pad_value, float* dst_dev, float* geom_out);

@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 def _resize_linear_u8(src, nw, nh):
     """cv2.resize(src, (nw, nh), interpolation=INTER_LINEAR) for uint8, OpenCV's 11-bit fixed-point generic path."""
     h, w = src.shape[:2]
+    if w == 2 * nw and h == 2 * nh:          # OpenCV substitutes the 2x2 box average at an exact halving
+        s = src.astype(np.int64)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
 
     def coef(n, ssize, scale):
         d = np.arange(n)
@@ -48,7 +51,7 @@ def _letterbox_ref(img, H, W, pad=114):
 
 
 @pytest.mark.parametrize("shape,new", [((1080, 1920), (640, 640)), ((360, 640), (640, 640)), ((480, 480), (640, 640)), ((97, 333), (320, 256)),
-                                       ((640, 640), (640, 640)), ((700, 300), (64, 96))])
+                                       ((640, 640), (640, 640)), ((700, 300), (64, 96)), ((720, 1280), (640, 640))])
 def test_letterbox(vp, shape, new):
     from vision.yolo import letterbox
     img = F.s1_buoy(1, shape[1], shape[0])
@@ -167,3 +170,20 @@ def test_detection_records_and_corner_order(vp):
     assert tl == (10, 5) and tr == (110, 8) and br == (108, 60) and bl == (12, 58)
     b = scale_boxes(np.array([[100, 140, 300, 340]], np.float32), (0.5, 0, 140))
     assert np.allclose(b, [[200, 0, 600, 400]])
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_linear_u8(vp, cn):
+    """cv2.resize (facade) == the fixed-point restatement, and within one count of float bilinear interpolation."""
+    from vision import cv2_facade as cv2
+    rng = np.random.default_rng(cn)
+    for (h, w), (dh, dw) in [((90, 160), (45, 80)), ((90, 160), (512, 512)), ((33, 65), (7, 200)), ((64, 64), (64, 64)), ((100, 50), (99, 51))]:
+        img = rng.integers(0, 256, (h, w, cn), dtype=np.uint8)
+        src = img[:, :, 0] if cn == 1 else img
+        got = cv2.resize(src, (dw, dh))
+        exp = _resize_linear_u8(img, dw, dh)
+        assert got.shape == ((dh, dw) if cn == 1 else (dh, dw, cn))
+        assert np.array_equal(got.reshape(dh, dw, cn), exp)
+        t = torch.from_numpy(img.transpose(2, 0, 1).astype(np.float32))[None]
+        ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0].numpy().transpose(1, 2, 0)
+        assert np.abs(got.reshape(dh, dw, cn).astype(np.float32) - ref).max() <= 1.01
