@@ -16,5 +16,11 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 $root
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 cd $root
 python3 tools/pmc_traffic.py $(find $out/pf -name '*counter_collection.csv' | head -1) $(find $out/pw -name '*counter_collection.csv' | head -1) $out/${tag}_traffic.json > /dev/null
-rm -rf $out/ks $out/pf $out/pw
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kb -o kb -- python3 $root/tools/exp_balance.py > $out/${tag}_balance.txt 2>&1
+cp $(find $out/kb -name '*kernel_stats.csv' | head -1) $out/${tag}_balance_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kc -o kc -- python3 $root/tools/exp_contours.py > $out/${tag}_contours.txt 2>&1
+cp $(find $out/kc -name '*kernel_stats.csv' | head -1) $out/${tag}_contours_kernel_stats.csv
+cd $root
+rm -rf $out/ks $out/pf $out/pw $out/kb $out/kc
 cat $out/${tag}_bench.json
