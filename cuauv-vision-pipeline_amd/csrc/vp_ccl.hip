@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, 
 }
 
 // One block per (frame, strip of CL_ROWS rows).
-// dynamic LDS: lbits[nw] u64 | wbase[nw + 2] u32 | lparent[CAP] | lgid[CAP] | lmin[CAP]
+// dynamic LDS: lbits[nw] u64 | wbase[nw + 2] u32 | lparent[cap] | lgid[cap] | lmin[cap] (cap <= nw + 2: lmin reuses wbase)
 __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
                                                    u32* __restrict__ flags, int strips, int cap)
 {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
     const u64* fb = bits + (size_t)frame * G.h * ww;
     CL_FOR_WORDS(r, j, i) lbits[i] = ccl_word(G, fb, (y0 + r) * ww + j, j);
     __syncthreads();
-    ccl_local_strip(G, lbits, wbase, lparent, lparent + cap, lparent + 2 * cap, wsum, &total_s, y0, nrows, strip, strips, fb,
+    ccl_local_strip(G, lbits, wbase, lparent, lparent + cap, cap <= nwmax + 2 ? wbase : lparent + 2 * cap, wsum, &total_s, y0, nrows, strip, strips, fb,
                     parent + (size_t)frame * G.nids, flags + (size_t)frame * G.nw32, (u32)cap);
 }
 
@@ -332,49 +332,73 @@ __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits,
             T.minx[i] = INT_MAX; T.miny[i] = INT_MAX; T.maxx[i] = INT_MIN; T.maxy[i] = INT_MIN;
         }
         __syncthreads();
-        if (w) {
-            const int y = idx / G.ww, j = idx - y * G.ww;
-            const u32* p = parent + (size_t)f * G.nids;
-            const u32* fl = flags + (size_t)f * G.nw32;
-            const u32* pf = prefix + (size_t)f * G.nw32;
-            u32* sl = seglabel + (size_t)f * G.nids;
-            u64 rem = w;
-            bool first = true;
-            while (rem) {
-                const int s = __ffsll((long long)rem) - 1;
-                const int e = run_end(rem, s);
-                rem &= ~bit_range(s, e);
-                const u32 id = seg_id(G, y, 64 * j + s);
-                u32 r = id;
-                for (u32 q = p[r]; q != r; q = p[r]) r = q;   // read-only walk: strip root, then across strips
-                const u32 label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
-                sl[id] = label;
-                if (first) { wordlabel[(size_t)f * G.h * G.ww + idx] = label; first = false; }
-                if (label >= (u32)max_labels) continue;
-                const u32 len = (u32)(e - s + 1);
-                const int xs = 64 * j + s, xe = 64 * j + e;
-                const u64 sx = (u64)len * (u64)(xs + xe) / 2ull, sy = (u64)len * (u64)y;
-                u32 slot = (label * 2654435761u) >> 26;   // 6 bits
-                bool placed = false;
-                for (int probe = 0; probe < 8 && !placed; probe++, slot = (slot + 1) & (ST_SLOTS - 1)) {
-                    const u32 cur = atomicCAS(&T.label[slot], 0u, label);
-                    if (cur == 0u || cur == label) {
-                        atomicAdd(&T.area[slot], len);
-                        atomicAdd((unsigned long long*)&T.sx[slot], (unsigned long long)sx);
-                        atomicAdd((unsigned long long*)&T.sy[slot], (unsigned long long)sy);
-                        atomicMin(&T.minx[slot], xs);
-                        atomicMax(&T.maxx[slot], xe);
-                        atomicMin(&T.miny[slot], y);
-                        atomicMax(&T.maxy[slot], y);
-                        placed = true;
-                    }
-                }
-                if (!placed) {   // crowded block (noise): straight to global memory
-                    contrib c;
-                    c.area = len; c.sx = sx; c.sy = sy; c.minx = xs; c.maxx = xe; c.miny = c.maxy = y;
-                    acc_commit(a + label, c);
+        // label of a segment + its contribution; the first segment of every word goes through a wave-level shortcut: when all
+        // the first segments of a wave carry the same label (the inside of a blob, a full mask) their records are combined with
+        // shuffles and added once, instead of 64 lanes queueing on the same LDS slot
+        const int y = idx / G.ww, j = idx - y * G.ww;
+        const u32* p = parent + (size_t)f * G.nids;
+        const u32* fl = flags + (size_t)f * G.nw32;
+        const u32* pf = prefix + (size_t)f * G.nw32;
+        u32* sl = seglabel + (size_t)f * G.nids;
+        auto table_add = [&](u32 label, const contrib& c) {
+            u32 slot = (label * 2654435761u) >> 26;   // 6 bits
+            for (int probe = 0; probe < 8; probe++, slot = (slot + 1) & (ST_SLOTS - 1)) {
+                const u32 cur = atomicCAS(&T.label[slot], 0u, label);
+                if (cur == 0u || cur == label) {
+                    atomicAdd(&T.area[slot], c.area);
+                    atomicAdd((unsigned long long*)&T.sx[slot], (unsigned long long)c.sx);
+                    atomicAdd((unsigned long long*)&T.sy[slot], (unsigned long long)c.sy);
+                    atomicMin(&T.minx[slot], c.minx);
+                    atomicMax(&T.maxx[slot], c.maxx);
+                    atomicMin(&T.miny[slot], c.miny);
+                    atomicMax(&T.maxy[slot], c.maxy);
+                    return;
                 }
             }
+            acc_commit(a + label, c);   // crowded block (noise): straight to global memory
+        };
+        auto segment = [&](int s, int e, contrib& c) -> u32 {
+            const u32 id = seg_id(G, y, 64 * j + s);
+            u32 r = id;
+            for (u32 q = p[r]; q != r; q = p[r]) r = q;   // read-only walk: strip root, then across strips
+            const u32 label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
+            sl[id] = label;
+            const u32 len = (u32)(e - s + 1);
+            const int xs = 64 * j + s, xe = 64 * j + e;
+            c.area = len; c.sx = (u64)len * (u64)(xs + xe) / 2ull; c.sy = (u64)len * (u64)y;
+            c.minx = xs; c.maxx = xe; c.miny = c.maxy = y;
+            return label;
+        };
+        u64 rem = w;
+        contrib c0;
+        contrib_zero(c0);
+        u32 lab0 = 0;
+        if (w) {
+            const int s = __ffsll((long long)rem) - 1;
+            const int e = run_end(rem, s);
+            rem &= ~bit_range(s, e);
+            lab0 = segment(s, e, c0);
+            wordlabel[(size_t)f * G.h * G.ww + idx] = lab0;
+            if (lab0 >= (u32)max_labels) { lab0 = 0; contrib_zero(c0); }
+        }
+        const unsigned long long act = __ballot(lab0 != 0u);
+        if (act) {
+            const int lead = __ffsll((long long)act) - 1;
+            const u32 ref = __shfl(lab0, lead);
+            if (__popcll(act) >= 8 && __all(lab0 == 0u || lab0 == ref)) {
+                wave_combine(c0);
+                if ((int)(threadIdx.x & 63) == lead) table_add(ref, c0);
+            } else if (lab0) {
+                table_add(lab0, c0);
+            }
+        }
+        while (rem) {
+            const int s = __ffsll((long long)rem) - 1;
+            const int e = run_end(rem, s);
+            rem &= ~bit_range(s, e);
+            contrib c;
+            const u32 label = segment(s, e, c);
+            if (label < (u32)max_labels) table_add(label, c);
         }
         __syncthreads();
         if (threadIdx.x < ST_SLOTS && T.label[threadIdx.x]) {
@@ -522,11 +546,14 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
     hipStream_t s = ctx->stream;
     const int strips = (h + CL_ROWS - 1) / CL_ROWS;
     const size_t nwmax = (size_t)CL_ROWS * G.ww;
-    // the background of a mask is mostly full words: every word of every row is a segment, so the inverted pass needs room
-    // for all of them plus the fragments around the foreground
-    size_t cap = G.invert ? (size_t)nwmax + 1024 : CL_CAP;
-    size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + 3 * cap * 4;
-    if (lds_local > 64 * 1024 && G.invert) { cap = CL_CAP; lds_local = nwmax * 8 + (nwmax + 2) * 4 + 3 * cap * 4; }
+    // Foreground: room for one segment per word of the strip (a full mask) + 2, the size of the wbase array whose LDS lmin then
+    // reuses; denser strips (speckle) take the global fallback.  Background pass of the contour code: every empty word is a
+    // segment and every foreground edge adds one, so it gets its own lmin array and 1024 more entries.
+    static const char* cap_env = getenv("VP_CL_CAP");
+    size_t cap = G.invert ? nwmax + 1024 : nwmax + 2;
+    if (cap_env && (size_t)atoi(cap_env) >= 64 && (size_t)atoi(cap_env) < cap) cap = (size_t)atoi(cap_env);
+    size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + (cap <= nwmax + 2 ? 2 : 3) * cap * 4;
+    if (lds_local > 64 * 1024 && G.invert) { cap = nwmax + 2; lds_local = nwmax * 8 + (nwmax + 2) * 4 + 2 * cap * 4; }
     if (lds_local <= 64 * 1024) {
         { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips, (int)cap); }
         if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags); }

@@ -149,7 +149,7 @@ __device__ __forceinline__ void lds_unite(u32* p, u32 a, u32 b)
 // parent[id] = smallest id of the segment's strip-local component (init + link in one pass); clears the strip's slice
 // of the root bitmap and marks the strip-local representatives.  wbase needs nrows*ww + 2 words, lparent / lgid / lmin
 // `cap` words each, wsum 4 words and total_s 1 word of LDS.  fb = the frame's bit image in global memory (only the
-// dense-strip fallback reads it, for rows of this strip).
+// dense-strip fallback reads it, for rows of this strip).  lmin may alias wbase when cap <= nrows*ww + 2.
 __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lbits, u32* wbase, u32* lparent, u32* lgid, u32* lmin,
                                                 u32* wsum, u32* total_s, int y0, int nrows, int strip, int strips,
                                                 const u64* __restrict__ fb, u32* __restrict__ gp, u32* __restrict__ gf, u32 cap = CL_CAP)
@@ -209,7 +209,6 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
                 st &= st - 1;
                 lparent[run] = run;
                 lgid[run] = seg_id(G, y0 + r, 64 * j + s);
-                lmin[run] = 0xffffffffu;
                 run++;
             }
         }
@@ -246,6 +245,9 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
             me++;
         }
     }
+    __syncthreads();
+    // lmin may share its LDS with wbase, which the unions above were the last to read
+    for (u32 ci = tid; ci < S; ci += 256) lmin[ci] = 0xffffffffu;
     __syncthreads();
     for (u32 ci = tid; ci < S; ci += 256) atomicMin(lmin + lds_find(lparent, ci), lgid[ci]);
     __syncthreads();
