@@ -12,9 +12,10 @@
 // So: two union-find passes (foreground 8-conn, background 4-conn, both with first-pixel ids = VP_CCL_PIXEL), a
 // bitmap of start pixels + popcount prefix for the order, and segment-parallel border following (below).
 //
-// Known divergence (documented in DESIGN.md): OpenCV's RETR_EXTERNAL decides "inside a hole" from the sign of the
-// last mark left of the start pixel, which differs from the topological rule when a one-pixel-thick wall pixel was
-// negatively marked by its outer trace; tests/test_gpu_contours.py counts such cases on random masks.
+// RETR_EXTERNAL: OpenCV decides "inside a hole" from the sign of the last border mark left of a start pixel.  A mark is negative
+// exactly when the tracer examined the pixel's east neighbour as background, i.e. when the east crack belongs to the traced
+// border - and every crack belongs to exactly one border (see below) - so the mark rule and the topological rule used here
+// select the same borders (no difference on 460 noise / thin-wall masks: tests/test_gpu_contours.py, tools/exp_external_rule.py).
 
 struct ct_frame_out {      // per frame, device
     int32_t n_contours;
