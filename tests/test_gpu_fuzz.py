@@ -60,7 +60,7 @@ def test_random_chain(vp, oracle, seed):
         assert np.array_equal(out["labels"][f], olab), (seed, "labels")
         k = min(on, max_labels)
         assert np.array_equal(out["stats"][f][:k], ost[:k]) and np.array_equal(out["centroids"][f][:k].view(np.uint64), oce[:k].view(np.uint64))
-        if cmode == 1:                                             # RETR_LIST is exact on any mask (see test_gpu_contours)
+        if True:                                                   # both retrieval modes are exact on any mask (see test_gpu_contours)
             exp, eh = oracle.find_contours(cl if src == "cleaned" else th, cmode, cmethod, with_holes=True)
             got, gh = out["contours"][f]
             assert len(got) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got, exp)), (seed, "contours")
