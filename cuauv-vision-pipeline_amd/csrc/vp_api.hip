@@ -899,6 +899,7 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
                                      cb->offsets + f0 * mc, cb->points + 2 * (size_t)f0 * (size_t)cd->max_points, cd->max_contours,
                                      cd->max_points, cb->info + 2 * (size_t)f0));
         }
+        if (cb->features) VP_TRY(vpk_contour_features(ctx, cb->info, cb->counts, cb->offsets, cb->points, n, cd->max_contours, cd->max_points, cb->features));
     }
     return VP_OK;
 }
@@ -1019,7 +1020,7 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
     const size_t mc = (size_t)cdesc->max_contours, mp = (size_t)cdesc->max_points;
     VP_TRY(vp_ws_reserve(ctx, chain_ws_bytes(desc, n) + vp_align(npx * 3) + 2 * vp_align(npx) + vp_align(npx * 4) + vp_align(n * ml * 20) +
                                   vp_align(n * ml * 16) + vp_align((size_t)n * 4) + vp_align((size_t)n * 8) + 2 * vp_align(n * mc * 4) +
-                                  vp_align(n * mc) + vp_align(n * mp * 8) + 16384 +
+                                  vp_align(n * mc) + vp_align(n * mp * 8) + vp_align(n * mc * 64) + 16384 +
                                   vp_contours_ws_bytes(desc->width, desc->height, std::min(n, ct_group_for(desc->width, desc->height, cdesc->max_contours)), cdesc->max_contours)));
     vp_chain_buffers d;
     memset(&d, 0, sizeof d);
@@ -1040,7 +1041,8 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
     c.offsets = (int32_t*)vp_ws_take(ctx, n * mc * 4);
     c.is_hole = (uint8_t*)vp_ws_take(ctx, n * mc);
     c.points = (int32_t*)vp_ws_take(ctx, n * mp * 8);
-    if (!c.info || !c.counts || !c.offsets || !c.is_hole || !c.points) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
+    c.features = chost->features ? (double*)vp_ws_take(ctx, n * mc * 64) : nullptr;
+    if (!c.info || !c.counts || !c.offsets || !c.is_hole || !c.points || (chost->features && !c.features)) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
     VP_TRY(h2d(ctx, d_bgr, host->bgr, npx * 3));
     VP_TRY(chain_core(ctx, desc, &d, n, cdesc, &c));
     if (host->threshed) VP_TRY(d2h(ctx, host->threshed, d.threshed, npx));
@@ -1056,6 +1058,7 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
     VP_TRY(d2h(ctx, chost->offsets, c.offsets, n * mc * 4));
     VP_TRY(d2h(ctx, chost->is_hole, c.is_hole, n * mc));
     VP_TRY(d2h(ctx, chost->points, c.points, n * mp * 8));
+    if (chost->features) VP_TRY(d2h(ctx, chost->features, c.features, n * mc * 64));
     return vp_synchronize(ctx);
 }
 

@@ -549,6 +549,64 @@ __global__ __launch_bounds__(256) void k_ct_offsets(ccl_geom G, const ct_aux* __
 #undef dx8
 #undef dy8
 
+// per contour: polygon moments by Green's formula (imgproc/src/moments.cpp contourMoments: a00 = sum(x[i-1]*y[i] - x[i]*y[i-1]),
+// a10 = sum(dxy * (x[i-1] + x[i])), a01 likewise; m00 = a00/2, m10 = a10/6, m01 = a01/6, all with the sign of a00), cv2.contourArea
+// and the bounding box.  The sums are integers, accumulated in int64, so the order of the additions does not matter and the
+// doubles are the ones a sequential CPU loop produces.  grid (max_contours, n), 64 threads: one wave per contour
+__global__ __launch_bounds__(64) void k_ct_features(const ct_frame_out* __restrict__ info, const int32_t* __restrict__ counts,
+                                                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ points, int max_contours,
+                                                    long long max_points, double* __restrict__ features)
+{
+    const int f = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    double* o = features + ((size_t)f * max_contours + r) * 8;
+    const int K = min(info[f].n_contours, max_contours);
+    const int cnt = r < K ? counts[(size_t)f * max_contours + r] : 0;
+    const long long off = r < K ? offsets[(size_t)f * max_contours + r] : 0;
+    if (cnt <= 0 || off + cnt > max_points) {
+        if (lane < 8) o[lane] = 0.0;
+        return;
+    }
+    const int32_t* p = points + 2 * ((size_t)f * max_points + off);
+    long long a00 = 0, a10 = 0, a01 = 0;
+    int minx = INT_MAX, miny = INT_MAX, maxx = INT_MIN, maxy = INT_MIN;
+    for (int i = lane; i < cnt; i += 64) {
+        const int ip = i == 0 ? cnt - 1 : i - 1;
+        const long long x = p[2 * i], y = p[2 * i + 1], xp = p[2 * ip], yp = p[2 * ip + 1];
+        const long long dxy = xp * y - x * yp;
+        a00 += dxy;
+        a10 += dxy * (xp + x);
+        a01 += dxy * (yp + y);
+        minx = min(minx, (int)x); maxx = max(maxx, (int)x);
+        miny = min(miny, (int)y); maxy = max(maxy, (int)y);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a00 += __shfl_xor(a00, d); a10 += __shfl_xor(a10, d); a01 += __shfl_xor(a01, d);
+        minx = min(minx, __shfl_xor(minx, d)); maxx = max(maxx, __shfl_xor(maxx, d));
+        miny = min(miny, __shfl_xor(miny, d)); maxy = max(maxy, __shfl_xor(maxy, d));
+    }
+    if (lane == 0) {
+        const double d00 = (double)a00, d10 = (double)a10, d01 = (double)a01;
+        double m00 = 0, m10 = 0, m01 = 0;
+        if (fabs(d00) > 1.1920929e-07) {
+            const double s2 = d00 > 0 ? 0.5 : -0.5, s6 = d00 > 0 ? 1.0 / 6 : -1.0 / 6;
+            m00 = d00 * s2; m10 = d10 * s6; m01 = d01 * s6;
+        }
+        o[0] = m00; o[1] = m10; o[2] = m01; o[3] = fabs(d00 * 0.5);
+        o[4] = (double)minx; o[5] = (double)miny; o[6] = (double)(maxx - minx + 1); o[7] = (double)(maxy - miny + 1);
+    }
+}
+
+int vpk_contour_features(vp_ctx* ctx, const int32_t* d_info, const int32_t* d_counts, const int32_t* d_offsets, const int32_t* d_points, int n,
+                         int max_contours, long long max_points, double* d_features)
+{
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    hipLaunchKernelGGL(k_ct_features, dim3((unsigned)max_contours, (unsigned)n), dim3(64), 0, ctx->stream, reinterpret_cast<const ct_frame_out*>(d_info),
+                       d_counts, d_offsets, d_points, max_contours, max_points, d_features);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
 size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
 {
     const size_t nids = vp_ccl_nids(w, h);

@@ -140,6 +140,8 @@ size_t vp_ccl_nids(int w, int h);   // multiple of 32
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels);
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out);
 size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours);
+int vpk_contour_features(vp_ctx* ctx, const int32_t* d_info, const int32_t* d_counts, const int32_t* d_offsets, const int32_t* d_points, int n,
+                         int max_contours, long long max_points, double* d_features);
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info);
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,

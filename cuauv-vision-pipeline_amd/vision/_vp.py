@@ -50,7 +50,7 @@ class ContourDesc(C.Structure):
 
 class ContourBuffers(C.Structure):
     _fields_ = [("info", C.c_void_p), ("counts", C.c_void_p), ("offsets", C.c_void_p), ("is_hole", C.c_void_p),
-                ("points", C.c_void_p)]
+                ("points", C.c_void_p), ("features", C.c_void_p)]
 
 
 _lib = None
@@ -266,7 +266,7 @@ def contour_arrays(alloc, n, cdesc):
     """(dict of numpy arrays, ContourBuffers) for n frames; alloc(shape, dtype) -> array (plain or pinned)."""
     mc, mp = int(cdesc.max_contours), int(cdesc.max_points)
     arrs = {"info": alloc((n, 2), np.int32), "counts": alloc((n, mc), np.int32), "offsets": alloc((n, mc), np.int32),
-            "is_hole": alloc((n, mc), np.uint8), "points": alloc((n, mp, 2), np.int32)}
+            "is_hole": alloc((n, mc), np.uint8), "points": alloc((n, mp, 2), np.int32), "features": alloc((n, mc, 8), np.float64)}
     b = ContourBuffers()
     for k, a in arrs.items():
         setattr(b, k, a.ctypes.data)
@@ -286,4 +286,15 @@ def contour_lists(arrs, cdesc):
         cnt, off, pts = arrs["counts"][f], arrs["offsets"][f], arrs["points"][f]
         cs = tuple(pts[off[i]:off[i] + cnt[i]].reshape(-1, 1, 2).copy() for i in range(k - 1, -1, -1))
         out.append((cs, arrs["is_hole"][f, :k][::-1].copy()))
+    return out
+
+
+def contour_features(arrs, cdesc):
+    """Per frame: (k, 8) float64 rows {m00, m10, m01, area, x, y, width, height} in the order of contour_lists (cv2's), or None
+    where the frame exceeded the capacities."""
+    out = []
+    mc, mp = int(cdesc.max_contours), int(cdesc.max_points)
+    for f in range(arrs["info"].shape[0]):
+        k, npts = int(arrs["info"][f, 0]), int(arrs["info"][f, 1])
+        out.append(None if (k > mc or npts > mp) else arrs["features"][f, :k][::-1].copy())
     return out

@@ -52,6 +52,7 @@ def run_chain(frames, color_mode, lo, hi, morph=(), ccl=1, numbering=_vp.CCL_BLO
         cdesc.max_contours = max(cdesc.max_contours, 2 * need_c)
         cdesc.max_points = max(cdesc.max_points, 2 * need_p)
     out["contours"] = _vp.contour_lists(arrs, cdesc)
+    out["contour_features"] = _vp.contour_features(arrs, cdesc)
     return out
 
 
@@ -90,4 +91,5 @@ class ChainRunner:
         else:
             self.ctx.chain_run_contours_host(self.desc, self.bufs, self.cdesc, self.cbufs, self.n)
             self.out["contours"] = _vp.contour_lists(self.carrs, self.cdesc)   # None where a frame exceeded the capacities
+            self.out["contour_features"] = _vp.contour_features(self.carrs, self.cdesc)
         return self.out

@@ -203,6 +203,9 @@ typedef struct vp_contour_buffers {  /* device pointers (vp_chain_run_contours) 
     int32_t* offsets;      /* (n,max_contours) first point of the contour within the frame's point list */
     uint8_t* is_hole;      /* (n,max_contours) */
     int32_t* points;       /* (n,max_points,2) (x,y) */
+    double* features;      /* optional (may be NULL): (n,max_contours,8) per contour {m00, m10, m01 as cv2.moments gives them
+                              for the contour (utils/feature.py:240-252), area = cv2.contourArea (:255-265), bounding box x, y,
+                              width, height as cv2.boundingRect} - computed on the device, exact (the sums are integers) */
 } vp_contour_buffers;
 
 /* Contours beyond max_contours are counted in info[.][0] but not traced; a contour whose points

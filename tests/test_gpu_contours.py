@@ -219,6 +219,13 @@ def test_chain_with_contours_batch(vp, oracle, source, mode, monkeypatch):
         got, gh = out["contours"][f]
         assert _same(got, exp), f
         assert np.array_equal(gh, eh)
+        feat = out["contour_features"][f]                      # computed on the device; exact (integer sums)
+        assert feat.shape == (len(exp), 8)
+        for c, row in zip(exp, feat):
+            mo = oracle.contour_moments(c)
+            assert (row[0], row[1], row[2], row[3]) == (mo["m00"], mo["m10"], mo["m01"], mo["area"]), (f, row, mo)
+            pts = c.reshape(-1, 2)
+            assert row[4:].tolist() == [pts[:, 0].min(), pts[:, 1].min(), np.ptp(pts[:, 0]) + 1, np.ptp(pts[:, 1]) + 1]
     # without CCL and without mask outputs the contours are the same
     out2 = chain.run_chain(frames, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), morph, ccl=0, want=(),
                            contours=dict(source=source, mode=mode, method=2, max_contours=256, max_points=1 << 14))
