@@ -237,6 +237,7 @@ ORC_API int orc_color_balance(uint8_t* arr, size_t height, size_t width, int equ
     uint8_t* bc = (uint8_t*)malloc(n);
     uint8_t* gc = (uint8_t*)malloc(n);
     uint8_t* rc = (uint8_t*)malloc(n);
+    if (!bc || !gc || !rc) { free(bc); free(gc); free(rc); return -3; }
     for (size_t i = 0; i < n; i++) { bc[i] = arr[3 * i]; gc[i] = arr[3 * i + 1]; rc[i] = arr[3 * i + 2]; }   /* cv::split cpp:372 */
 
     double r_min, r_max, g_min, g_max, b_min, b_max;
