@@ -234,9 +234,9 @@ ORC_API int orc_color_balance(uint8_t* arr, size_t height, size_t width, int equ
 {
     if (horizontal_blocks <= 0 || vertical_blocks <= 0 || !height || !width) return -1;
     const size_t n = height * width;
-    uint8_t* bc = (uint8_t*)malloc(n);
-    uint8_t* gc = (uint8_t*)malloc(n);
-    uint8_t* rc = (uint8_t*)malloc(n);
+    uint8_t* bc = (uint8_t*)calloc(n, 1);
+    uint8_t* gc = (uint8_t*)calloc(n, 1);
+    uint8_t* rc = (uint8_t*)calloc(n, 1);
     if (!bc || !gc || !rc) { free(bc); free(gc); free(rc); return -3; }
     for (size_t i = 0; i < n; i++) { bc[i] = arr[3 * i]; gc[i] = arr[3 * i + 1]; rc[i] = arr[3 * i + 2]; }   /* cv::split cpp:372 */
 
