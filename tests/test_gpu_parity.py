@@ -455,6 +455,28 @@ def test_c_abi_argument_checks(vp):
     assert b"bgr" in L.vp_last_error(ctx.handle)
     assert L.vp_chain_run(None, C.byref(desc), C.byref(bufs), 1) == -1
     assert L.vp_set_option(ctx.handle, 77, 1) == -1
+    # entry points added after the first pass: colour balance, contours in the chain, detector pre / post steps, resize
+    assert L.vp_color_balance_u8(ctx.handle, None, 4, 4, vp.CB_DEFAULT, 1, 1, vp.ptr(img)) == -1
+    assert L.vp_color_balance_u8(ctx.handle, vp.ptr(img), 4, 4, vp.CB_DEFAULT, 0, 1, vp.ptr(img)) == -1
+    assert L.vp_color_balance_u8(ctx.handle, vp.ptr(img), 4, 4, vp.CB_DEFAULT, 3, 1, vp.ptr(img)) == -4      # tiles do not divide the frame
+    assert L.vp_color_balance_dev(ctx.handle, None, None, 4, 4, 1, vp.CB_DEFAULT, 1, 1) == -1
+    cd = vp.make_contour_desc("cleaned", 0, 2, 8, 64)
+    cb = vp.ContourBuffers()
+    bufs.bgr = img.ctypes.data
+    assert L.vp_chain_run_contours_host(ctx.handle, C.byref(desc), C.byref(bufs), C.byref(cd), C.byref(cb), 1) == -1   # no contour buffers
+    cd.mode = 5
+    assert L.vp_chain_run_contours_host(ctx.handle, C.byref(desc), C.byref(bufs), C.byref(cd), C.byref(cb), 1) == -1
+    f32 = np.zeros((3, 8, 8), np.float32)
+    assert L.vp_letterbox_u8_f32(ctx.handle, vp.ptr(img), 4, 4, 0, 8, 114, vp.ptr(f32), None) == -1
+    assert L.vp_letterbox_u8_f32(ctx.handle, vp.ptr(img), 4, 4, 8, 8, 300, vp.ptr(f32), None) == -1
+    assert L.vp_resize_u8(ctx.handle, vp.ptr(img), 4, 4, 5, 8, 8, vp.ptr(img)) == -1
+    boxes = np.zeros((4, 4), np.float32)
+    keep = np.zeros(4, np.int32)
+    assert L.vp_nms_f32(ctx.handle, vp.ptr(boxes), vp.ptr(boxes), -1, C.c_float(0.5), 0, 4, vp.ptr(keep), C.byref(n)) == -1
+    assert L.vp_nms_f32(ctx.handle, None, None, 4, C.c_float(0.5), 0, 4, vp.ptr(keep), C.byref(n)) == -1
+    big = np.zeros((20000, 4), np.float32)
+    assert L.vp_nms_f32(ctx.handle, vp.ptr(big), vp.ptr(big), 20000, C.c_float(0.5), 0, 4, vp.ptr(keep), C.byref(n)) == -4   # > 16384 candidates
+    assert L.vp_nms_f32(ctx.handle, vp.ptr(boxes), vp.ptr(boxes), 0, C.c_float(0.5), 0, 4, vp.ptr(keep), C.byref(n)) == 0 and n.value == 0
     with pytest.raises(TypeError):
         from vision.utils import color
         color.bgr_to_lab(np.zeros((4, 4, 3), np.float64))
