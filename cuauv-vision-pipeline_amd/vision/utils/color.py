@@ -192,3 +192,27 @@ def thresh_color_distance(split: List[np.ndarray], color, distance: float, auto_
     else:
         distance = distance**2
     return range_threshold(d2, 0, distance), sq
+
+
+def _outside_path(name):
+    def _f(*_a, **_k):
+        raise NotImplementedError(f"{name}: outside the accelerated path of this build")
+    _f.__name__ = name
+    return _f
+
+
+# the rest of the reference's utils/color.py (:156-392): names kept so that `from vision.utils.color import ...` lines of existing modules
+# import; calling them fails loudly instead of falling back to a CPU implementation
+max_threshold = _outside_path("max_threshold")
+above_threshold = _outside_path("above_threshold")
+below_threshold = _outside_path("below_threshold")
+otsu_threshold = _outside_path("otsu_threshold")
+adaptive_threshold_mean = _outside_path("adaptive_threshold_mean")
+adaptive_threshold_mean_inv = _outside_path("adaptive_threshold_mean_inv")
+adaptive_threshold_gaussian = _outside_path("adaptive_threshold_gaussian")
+adaptive_threshold_gaussian_inv = _outside_path("adaptive_threshold_gaussian_inv")
+kmeans = _outside_path("kmeans")
+mask_from_labels = _outside_path("mask_from_labels")
+mask_from_labels_target_color = _outside_path("mask_from_labels_target_color")
+white_balance_bgr = _outside_path("white_balance_bgr")
+white_balance_bgr_blur = _outside_path("white_balance_bgr_blur")

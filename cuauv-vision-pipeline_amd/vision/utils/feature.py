@@ -85,6 +85,43 @@ def contour_area(contour: np.ndarray) -> float:
     return abs(a00 * 0.5)
 
 
+def contour_perimeter(contour: np.ndarray, closed: bool = True) -> float:
+    """utils/feature.py:266-278 (cv2.arcLength): host arithmetic on the few points of one contour."""
+    from vision import cv2_facade
+    return cv2_facade.arcLength(contour, closed)
+
+
+def contour_approx(contour: np.ndarray, epsilon: float = None, closed: bool = True) -> np.ndarray:
+    """utils/feature.py:281-296 (cv2.approxPolyDP; epsilon defaults to a tenth of the perimeter)."""
+    from vision import cv2_facade
+    if epsilon is None:
+        epsilon = 0.1 * contour_perimeter(contour, closed)
+    return cv2_facade.approxPolyDP(contour, epsilon, closed)
+
+
+def min_enclosing_rect(contour: np.ndarray):
+    """utils/feature.py:299-310 (cv2.minAreaRect): ((cx, cy), (w, h), angle in degrees), OpenCV >= 4.5.1 angle convention."""
+    from vision import cv2_facade
+    return cv2_facade.minAreaRect(contour)
+
+
+def _outside_path(name):
+    def _f(*_a, **_k):
+        raise NotImplementedError(f"{name}: outside the accelerated path of this build")
+    _f.__name__ = name
+    return _f
+
+
+min_enclosing_circle = _outside_path("min_enclosing_circle")
+min_enclosing_ellipse = _outside_path("min_enclosing_ellipse")
+canny = _outside_path("canny")
+simple_canny = _outside_path("simple_canny")
+find_corners = _outside_path("find_corners")
+find_circles = _outside_path("find_circles")
+find_lines = _outside_path("find_lines")
+find_line_segments = _outside_path("find_line_segments")
+
+
 def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = _vp.CHAIN_APPROX_SIMPLE, with_holes: bool = False):
     """cv2.findContours(mat, mode, method)[0] on the GPU (libvp vp_find_contours_u8): tuple of (N,1,2) int32 arrays of
     (x, y) points, newest contour first like cv2."""

@@ -81,3 +81,22 @@ def morph_close_holes(mat: np.ndarray, kernel: np.ndarray, iterations: int = 1) 
 def morph_borders(mat: np.ndarray, kernel: np.ndarray, iterations: int = 1) -> np.ndarray:
     """utils/transform.py:149-164 (cv2.morphologyEx MORPH_GRADIENT)."""
     return _morph(_vp.MORPH_GRADIENT, mat, kernel, iterations)
+
+
+def resize(mat: np.ndarray, width: int, height: int) -> np.ndarray:
+    """utils/transform.py:167-179 (cv2.resize, default bilinear interpolation) on the GPU (libvp vp_resize_u8)."""
+    from vision import cv2_facade
+    return cv2_facade.resize(mat, (width, height))
+
+
+def _outside_path(name):
+    def _f(*_a, **_k):
+        raise NotImplementedError(f"{name}: outside the accelerated path of this build")
+    _f.__name__ = name
+    return _f
+
+
+simple_gaussian_blur = _outside_path("simple_gaussian_blur")
+rotate = _outside_path("rotate")
+translate = _outside_path("translate")
+decode_normal = _outside_path("decode_normal")

@@ -74,6 +74,13 @@ def test_polygon_helpers():
     assert feature.contour_area(sq) == 16.0
     assert feature.contour_centroid(sq) == (4, 4)
     assert feature.contour_centroid(np.array([[[3, 3]]], np.int32)) == (0, 0)  # degenerate: m00 clamped (utils/feature.py:251)
+    assert feature.contour_perimeter(sq) == 16.0 and feature.contour_perimeter(sq, closed=False) == 12.0
+    big = np.array([[[0, 0]], [[0, 50]], [[1, 100]], [[100, 100]], [[100, 0]]], np.int32)
+    assert feature.contour_approx(big, epsilon=2.0).reshape(-1, 2).tolist() == [[0, 0], [1, 100], [100, 100], [100, 0]]
+    (cx, cy), (w, h), ang = feature.min_enclosing_rect(sq)
+    assert (cx, cy) == (4.0, 4.0) and sorted((w, h)) == [4.0, 4.0] and ang == 90.0
+    with pytest.raises(NotImplementedError):
+        feature.find_circles(sq)
 
 
 def test_color_balance_library_exports_reference_entry():
