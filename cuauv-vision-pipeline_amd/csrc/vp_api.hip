@@ -1068,6 +1068,31 @@ static int check_lb(vp_ctx* ctx, const void* src, const void* dst, int w, int h,
     return VP_OK;
 }
 
+int vp_gaussian_blur_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int kw, int kh, double sigma1, double sigma2, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || h > 65535 || cn < 1 || cn > 4 || kw <= 0 || kh <= 0 || !(kw & 1) || !(kh & 1) || kw > 511 || kh > 511)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_gaussian_blur_u8 arguments");
+    if (sigma1 < 0) sigma1 = 0;
+    if (sigma2 <= 0) sigma2 = sigma1;
+    const size_t nbytes = (size_t)w * h * cn;
+    uint16_t taps[1024];
+    vp_gaussian_taps(kw, sigma1, taps);
+    vp_gaussian_taps(kh, sigma2, taps + kw);
+    VP_TRY(vp_ws_reserve(ctx, 2 * vp_align(nbytes) + vp_align(nbytes * 2) + 4096));
+    TAKE(d_src, uint8_t*, nbytes);
+    TAKE(d_dst, uint8_t*, nbytes);
+    TAKE(d_tmp, uint16_t*, nbytes * 2);
+    TAKE(d_taps, uint16_t*, 2048);
+    VP_TRY(h2d(ctx, d_src, src, nbytes));
+    VP_TRY(h2d(ctx, d_taps, taps, (size_t)(kw + kh) * 2));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // taps is a local array
+    if (kw == 1 && kh == 1) { VP_TRY(d2h(ctx, dst, d_src, nbytes)); return vp_synchronize(ctx); }
+    VP_TRY(vpk_gaussian_blur(ctx, d_src, w, h, cn, d_taps, kw, kh, d_tmp, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, nbytes));
+    return vp_synchronize(ctx);
+}
+
 int vp_resize_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int dw, int dh, uint8_t* dst)
 {
     VP_TRY(check_ctx(ctx));

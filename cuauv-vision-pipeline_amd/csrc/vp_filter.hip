@@ -1,0 +1,115 @@
+// cv2.GaussianBlur on 8-bit images (modules/preprocessor.py:110-114 `PPX_gaussian_blur`, utils/transform.py `simple_gaussian_blur`).
+//
+// OpenCV >= 4.0 filters CV_8U images on a bit-exact fixed-point path (imgproc/src/smooth.dispatch.cpp, GaussianBlurFixedPoint):
+// taps in 8.8 fixed point that sum to exactly 256 (error diffusion towards the centre tap), a horizontal pass whose 8.8 sums are
+// exact, a vertical pass whose 16.16 sums are rounded half up to 8 bits, BORDER_REFLECT_101.  The taps are made on the host
+// (vp_gaussian_taps, double precision); the two passes below are integer arithmetic, so the result does not depend on the order
+// of the additions.
+#include "vp_internal.h"
+#include <cmath>
+
+#define GB_MAX_TAPS 511
+#define GB_TILE 1024     // output bytes per block in the horizontal pass
+
+__device__ __forceinline__ int gb_reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// grid (ceil(w*cn / GB_TILE), h), 256 threads.  A block stages its piece of the row (+ halo, already reflected) in LDS.
+__global__ __launch_bounds__(256) void k_gauss_h(const uint8_t* __restrict__ src, int w, int cn, const uint16_t* __restrict__ taps, int kw,
+                                                 uint16_t* __restrict__ tmp)
+{
+    extern __shared__ uint8_t gb_lds[];
+    __shared__ uint16_t tp[GB_MAX_TAPS + 1];
+    const int y = blockIdx.y, rowbytes = w * cn, r = kw / 2;
+    const int b0 = blockIdx.x * GB_TILE;                    // first output byte of this block
+    const int nb = min(GB_TILE, rowbytes - b0);
+    const int x0 = b0 / cn;                                 // first pixel touched
+    const int x1 = (b0 + nb - 1) / cn;                      // last pixel touched
+    const int npx = x1 - x0 + 1 + 2 * r;                    // staged pixels
+    const uint8_t* row = src + (size_t)y * rowbytes;
+    for (int i = threadIdx.x; i < kw; i += 256) tp[i] = taps[i];
+    for (int i = threadIdx.x; i < npx * cn; i += 256) {
+        const int px = i / cn, c = i - px * cn;
+        gb_lds[i] = row[(size_t)gb_reflect101(x0 - r + px, w) * cn + c];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nb; o += 256) {
+        const int b = b0 + o, x = b / cn, c = b - x * cn;
+        const uint8_t* p = gb_lds + (size_t)(x - x0) * cn + c;   // tap 0 sits at pixel x - r = staged pixel (x - x0)
+        u32 s = 0;
+        for (int k = 0; k < kw; k++) s += (u32)tp[k] * p[(size_t)k * cn];
+        tmp[(size_t)y * rowbytes + b] = (uint16_t)s;
+    }
+}
+
+// grid (ceil(w*cn / 256), h), 256 threads: thread = one output byte
+__global__ __launch_bounds__(256) void k_gauss_v(const uint16_t* __restrict__ tmp, int rowbytes, int h, const uint16_t* __restrict__ taps, int kh,
+                                                 uint8_t* __restrict__ dst)
+{
+    __shared__ uint16_t tp[GB_MAX_TAPS + 1];
+    for (int i = threadIdx.x; i < kh; i += 256) tp[i] = taps[i];
+    __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, r = kh / 2;
+    if (b >= rowbytes) return;
+    u32 s = 0;
+    if (y - r >= 0 && y + r < h) {
+        const uint16_t* p = tmp + (size_t)(y - r) * rowbytes + b;
+        for (int k = 0; k < kh; k++) s += (u32)tp[k] * p[(size_t)k * rowbytes];
+    } else {
+        for (int k = 0; k < kh; k++) s += (u32)tp[k] * tmp[(size_t)gb_reflect101(y + k - r, h) * rowbytes + b];
+    }
+    const u32 v = (s + (1u << 15)) >> 16;
+    dst[(size_t)y * rowbytes + b] = (uint8_t)(v > 255u ? 255u : v);
+}
+
+// getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (8 fraction bits): n odd, 1 <= n <= GB_MAX_TAPS
+void vp_gaussian_taps(int n, double sigma, uint16_t* out)
+{
+    static const double t3[] = {0.25, 0.5, 0.25}, t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625},
+                        t7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125},
+                        t9[] = {4 / 256., 13 / 256., 30 / 256., 51 / 256., 60 / 256., 51 / 256., 30 / 256., 13 / 256., 4 / 256.};
+    if (n == 1) { out[0] = 256; return; }
+    double k[GB_MAX_TAPS + 1];
+    const double* tab = nullptr;
+    if (sigma <= 0) tab = n == 3 ? t3 : n == 5 ? t5 : n == 7 ? t7 : n == 9 ? t9 : nullptr;
+    if (tab) {
+        for (int i = 0; i < n; i++) k[i] = tab[i];
+    } else {
+        const double sx = sigma > 0 ? sigma : (double)n * 0.15 + 0.35;
+        const double scale2x = -0.125 / (sx * sx);
+        const int n2 = (n - 1) / 2;
+        double sum = 0;
+        for (int i = 0, x = 1 - n; i < n2; i++, x += 2) { k[i] = std::exp((double)(x * x) * scale2x); sum += k[i]; }
+        sum = sum * 2 + 1;
+        const double mul1 = 1.0 / sum;
+        for (int i = 0; i < n2; i++) { k[i] *= mul1; k[n - 1 - i] = k[i]; }
+        k[n2] = mul1;
+    }
+    const int n2 = n / 2;
+    double err = 0;
+    long long sum = 0;
+    for (int i = 0; i < n2; i++) {
+        const double adj = k[i] * 256.0 + err;
+        const long long v0 = std::llrint(adj);
+        err = adj - (double)v0;
+        out[i] = out[n - 1 - i] = (uint16_t)v0;
+        sum += 2 * v0;
+    }
+    out[n2] = (uint16_t)(256 - sum);
+}
+
+// d_taps: kw + kh uint16 (x taps then y taps); d_tmp: w*h*cn uint16
+int vpk_gaussian_blur(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int cn, const uint16_t* d_taps, int kw, int kh, uint16_t* d_tmp, uint8_t* d_dst)
+{
+    const int rowbytes = w * cn;
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    const size_t lds = (size_t)(GB_TILE / cn + 2 + 2 * (kw / 2)) * cn + 16;
+    hipLaunchKernelGGL(k_gauss_h, dim3((unsigned)((rowbytes + GB_TILE - 1) / GB_TILE), (unsigned)h), dim3(256), lds, ctx->stream, d_src, w, cn, d_taps, kw, d_tmp);
+    hipLaunchKernelGGL(k_gauss_v, dim3((unsigned)((rowbytes + 255) / 256), (unsigned)h), dim3(256), 0, ctx->stream, d_tmp, rowbytes, h, d_taps + kw, kh, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

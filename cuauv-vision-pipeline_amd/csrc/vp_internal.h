@@ -105,6 +105,10 @@ int vpk_resize_u8(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int cn, int
 size_t vp_nms_ws_bytes(int n);
 int vpk_nms(vp_ctx* ctx, const float* d_boxes, const float* d_scores, int n, float thr, int rotated, int max_keep, int* d_keep, int* d_nkeep);
 
+// ---- filters (vp_filter.hip) -----------------------------------------------------------------------
+void vp_gaussian_taps(int n, double sigma, uint16_t* out);   // n odd, <= 511
+int vpk_gaussian_blur(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int cn, const uint16_t* d_taps, int kw, int kh, uint16_t* d_tmp, uint8_t* d_dst);
+
 // ---- morphology (vp_morph.hip) ---------------------------------------------------------------
 struct vp_bitstage { int dilate; int l, r, u, d; };  // window [-l, r] x [-u, d]
 #define VP_MAX_STAGES 32

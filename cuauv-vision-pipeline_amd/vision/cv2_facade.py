@@ -254,7 +254,23 @@ def _outside(name):
     return _f
 
 
-GaussianBlur = _outside("GaussianBlur")
+def GaussianBlur(src, ksize, sigmaX, sigmaY=0):
+    """cv2.GaussianBlur on uint8 images (modules/preprocessor.py:110-114): OpenCV's bit-exact fixed-point path on the GPU."""
+    from vision import _vp
+    src = np.ascontiguousarray(src)
+    if src.dtype != np.uint8 or src.ndim not in (2, 3) or src.size == 0:
+        raise error("GaussianBlur: only non-empty uint8 images are on the accelerated path")
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    kw, kh = int(ksize[0]), int(ksize[1])
+    if kw <= 0 or kh <= 0 or kw % 2 == 0 or kh % 2 == 0 or kw > 511 or kh > 511 or cn > 4:
+        raise error("GaussianBlur: kernel sizes must be odd, 1..511")
+    out = np.empty_like(src)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_gaussian_blur_u8(ctx.handle, _vp.ptr(src), src.shape[1], src.shape[0], cn, kw, kh, float(sigmaX), float(sigmaY),
+                                            _vp.ptr(out)), ctx.handle)
+    return out
+
+
 warpAffine = _outside("warpAffine")
 BORDER_REPLICATE = 1
 INTER_LINEAR = 1

@@ -96,7 +96,14 @@ def _outside_path(name):
     return _f
 
 
-simple_gaussian_blur = _outside_path("simple_gaussian_blur")
+
+
+def simple_gaussian_blur(mat: np.ndarray, kernel_size: int, std_dev: float) -> np.ndarray:
+    """utils/transform.py:3-25 (cv2.GaussianBlur with a square kernel); ValueError for an even kernel size as in the reference."""
+    if kernel_size % 2 == 0:
+        raise ValueError("kernel_size must be an odd integer")
+    from vision import cv2_facade
+    return cv2_facade.GaussianBlur(mat, (kernel_size, kernel_size), std_dev)
 rotate = _outside_path("rotate")
 translate = _outside_path("translate")
 decode_normal = _outside_path("decode_normal")

@@ -229,6 +229,12 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
  * probabilistic IoU of the boxes' Gaussian models; a box is dropped when any higher-scored box overlaps it by >= thr.
  * n <= 16384.  The _dev forms take device pointers (e.g. tensors of a PyTorch-ROCm model via data_ptr()), enqueue on the
  * context's stream and return without synchronising. */
+/* cv2.GaussianBlur(src, (kw, kh), sigma1, sigma2) on 8-bit images, cn = 1..4 (modules/preprocessor.py:110-114,
+ * utils/transform.py simple_gaussian_blur): OpenCV's bit-exact fixed-point path (8.8 taps summing to 256, 16.16 vertical sums
+ * rounded half up, BORDER_REFLECT_101).  kw, kh odd, 1..511; sigma <= 0 means "from the kernel size", sigma2 <= 0 means sigma1.
+ * dst may equal src. */
+int vp_gaussian_blur_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int cn, int kw, int kh, double sigma1, double sigma2,
+                        uint8_t* dst_host);
 /* cv2.resize(src, (dst_w, dst_h)) with the default INTER_LINEAR on 8-bit images, cn = 1..4 interleaved channels
  * (modules/preprocessor.py:136-144): OpenCV's generic fixed-point path, including the 2x2 box average it substitutes at an
  * exact halving.  (IPP-enabled OpenCV builds may round differently.) */

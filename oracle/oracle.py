@@ -104,6 +104,26 @@ def color_balance(bgr, equalize_rgb=True, rgb_contrast_correct=False, hsv_contra
     return out
 
 
+def gaussian_kernel_fixed(n, sigma=0.0):
+    out = np.zeros(n, np.uint16)
+    assert lib().orc_gaussian_kernel_fixed(int(n), C.c_double(sigma), _p(out, C.c_void_p)) == 0
+    return out
+
+
+def gaussian_blur(img, ksize, sigma1=0.0, sigma2=0.0):
+    """cv2.GaussianBlur(img, (kw, kh), sigma1, sigma2) on uint8 images (bit-exact fixed-point path)."""
+    img = _c(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    out = np.empty_like(img)
+    L = lib()
+    L.orc_gaussian_blur_u8.restype = C.c_int
+    rc = L.orc_gaussian_blur_u8(_p(img, _u8p), w, h, cn, int(ksize[0]), int(ksize[1]), C.c_double(sigma1), C.c_double(sigma2), _p(out, _u8p))
+    if rc != 0:
+        raise ValueError(f"orc_gaussian_blur_u8: {rc}")
+    return out
+
+
 def bgr2gray(bgr):
     bgr = _c(bgr)
     h, w, _ = bgr.shape

@@ -354,3 +354,84 @@ ORC_API int orc_color_balance(uint8_t* arr, size_t height, size_t width, int equ
     free(bc); free(gc); free(rc);
     return 0;
 }
+
+/* ---- cv2.GaussianBlur on 8-bit images (modules/preprocessor.py:110-114, utils/transform.py simple_gaussian_blur) ----------
+ * OpenCV >= 4.0 takes the bit-exact fixed-point path for CV_8U (imgproc/src/smooth.dispatch.cpp): the double kernel of
+ * getGaussianKernelBitExact (fixed tables for sigma <= 0 and n in {1,3,5,7,9}, otherwise exp(-x^2 / (2 sigma^2)) with
+ * sigma = 0.15 n + 0.35 when not given, normalised), converted to 8.8 fixed point with error diffusion towards the centre
+ * (getGaussianKernelFixedPoint_ED: the taps sum to exactly 256), a horizontal pass producing exact 8.8 sums, a vertical pass
+ * producing 16.16 sums rounded half up to 8 bits; border BORDER_REFLECT_101.  (OpenCV evaluates exp() in its own softfloat; a
+ * libm last-bit difference could only matter if tap * 256 fell within 1e-13 of a half.) */
+static void gauss_kernel_fixed(int n, double sigma, uint16_t* out)
+{
+    double k[512];
+    static const double t3[] = {0.25, 0.5, 0.25}, t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625},
+                        t7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125},
+                        t9[] = {4 / 256., 13 / 256., 30 / 256., 51 / 256., 60 / 256., 51 / 256., 30 / 256., 13 / 256., 4 / 256.};
+    const double* tab = NULL;
+    if (sigma <= 0) tab = n == 3 ? t3 : n == 5 ? t5 : n == 7 ? t7 : n == 9 ? t9 : NULL;
+    if (n == 1) { out[0] = 256; return; }
+    if (tab) for (int i = 0; i < n; i++) k[i] = tab[i];
+    else {
+        const double sx = sigma > 0 ? sigma : (double)n * 0.15 + 0.35;
+        const double scale2x = -0.125 / (sx * sx);
+        const int n2 = (n - 1) / 2;
+        double sum = 0;
+        for (int i = 0, x = 1 - n; i < n2; i++, x += 2) { k[i] = exp((double)(x * x) * scale2x); sum += k[i]; }
+        sum = sum * 2 + 1;
+        const double mul1 = 1.0 / sum;
+        for (int i = 0; i < n2; i++) { k[i] *= mul1; k[n - 1 - i] = k[i]; }
+        k[n2] = mul1;
+    }
+    const int n2 = n / 2;
+    double err = 0;
+    long long sum = 0;
+    for (int i = 0; i < n2; i++) {
+        const double adj = k[i] * 256.0 + err;
+        const long long v0 = llrint(adj);   /* cvRound: half to even */
+        err = adj - (double)v0;
+        out[i] = out[n - 1 - i] = (uint16_t)v0;
+        sum += 2 * v0;
+    }
+    out[n2] = (uint16_t)(256 - sum);
+}
+static int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+ORC_API int orc_gaussian_kernel_fixed(int n, double sigma, uint16_t* out)
+{
+    if (n <= 0 || n > 511 || !(n & 1)) return -1;
+    gauss_kernel_fixed(n, sigma, out);
+    return 0;
+}
+ORC_API int orc_gaussian_blur_u8(const uint8_t* src, int w, int h, int cn, int kw, int kh, double sigma1, double sigma2, uint8_t* dst)
+{
+    if (w <= 0 || h <= 0 || cn < 1 || cn > 4 || kw <= 0 || kh <= 0 || !(kw & 1) || !(kh & 1) || kw > 511 || kh > 511) return -1;
+    if (sigma1 < 0) sigma1 = 0;
+    if (sigma2 <= 0) sigma2 = sigma1;
+    uint16_t kx[512], ky[512];
+    gauss_kernel_fixed(kw, sigma1, kx);
+    gauss_kernel_fixed(kh, sigma2, ky);
+    uint16_t* tmp = (uint16_t*)malloc((size_t)w * h * cn * 2);
+    if (!tmp) return -3;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < cn; c++) {
+                uint32_t s = 0;
+                for (int k = 0; k < kw; k++) s += (uint32_t)kx[k] * src[((size_t)y * w + reflect101(x + k - kw / 2, w)) * cn + c];
+                tmp[((size_t)y * w + x) * cn + c] = (uint16_t)s;
+            }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < cn; c++) {
+                uint32_t s = 0;
+                for (int k = 0; k < kh; k++) s += (uint32_t)ky[k] * tmp[((size_t)reflect101(y + k - kh / 2, h) * w + x) * cn + c];
+                const uint32_t v = (s + (1u << 15)) >> 16;
+                dst[((size_t)y * w + x) * cn + c] = (uint8_t)(v > 255 ? 255 : v);
+            }
+    free(tmp);
+    return 0;
+}

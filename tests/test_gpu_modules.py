@@ -45,7 +45,8 @@ def test_facade_matches_oracle(vp, oracle, cv2mod):
     over = cv2.addWeighted(img, 0.7, vis, 0.3, 0)
     assert over.dtype == np.uint8 and over.shape == img.shape
     with pytest.raises(cv2.error):          # named, but outside the accelerated path: fails loudly instead of falling back
-        cv2.GaussianBlur(img, (5, 5), 0)
+        cv2.warpAffine(img, np.eye(2, 3), (4, 4))
+    assert np.array_equal(cv2.GaussianBlur(img, (5, 5), 0), oracle.gaussian_blur(img, (5, 5)))
     assert cv2.add(10, np.array([[250, 3]], np.uint8)).tolist() == [[255, 13]]
     assert np.allclose(cv2.getRotationMatrix2D((10, 5), 90, 1), [[0, 1, 5], [-1, 0, 15]])
     assert np.array_equal(cv2.cvtColor(cv2.cvtColor(img, cv2.COLOR_BGR2HSV), cv2.COLOR_HSV2BGR), oracle.hsv2bgr(oracle.bgr2hsv(img)))

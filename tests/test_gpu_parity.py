@@ -501,3 +501,33 @@ def test_chain_runner_pinned_staging(vp, oracle):
             assert np.array_equal(out["labels"][i], lab) and np.array_equal(out["stats"][i][:n], st)
             assert np.array_equal(out["centroids"][i][:n].view(np.uint64), ce.view(np.uint64))
     assert "threshed" not in out
+
+
+def test_gaussian_blur_u8(vp, oracle):
+    """cv2.GaussianBlur on 8-bit images (modules/preprocessor.py:110-114): the fixed-point taps (host) and the two integer passes
+    (GPU) against the oracle; kernel sizes from the preprocessor's range, explicit sigmas, rectangular kernels, kernels wider than
+    the image (the reflection wraps more than once), 1 / 3 / 4 channels, single-row and single-column images."""
+    from vision import cv2_facade as cv2
+    from vision.utils import transform as T
+    rng = np.random.default_rng(9)
+    for n in (1, 3, 5, 7, 9, 11, 31, 101, 201):
+        taps = oracle.gaussian_kernel_fixed(n)
+        assert int(taps.sum()) == 256 and np.array_equal(taps, taps[::-1])
+    imgs = [rng.integers(0, 256, (67, 130), dtype=np.uint8), _rand_bgr(rng, 90, 161), rng.integers(0, 256, (33, 65, 4), dtype=np.uint8),
+            rng.integers(0, 256, (1, 40, 3), dtype=np.uint8), rng.integers(0, 256, (40, 1), dtype=np.uint8), rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)]
+    for img in imgs:
+        for (kw, kh), s1, s2 in [((3, 3), 0, 0), ((5, 5), 0, 0), ((7, 7), 0, 0), ((9, 9), 0, 0), ((11, 11), 0, 0), ((31, 31), 0, 0), ((5, 5), 1.3, 0),
+                                 ((21, 3), 4.0, 0.7), ((1, 9), 0, 0), ((101, 101), 0, 0), ((201, 201), 0, 0)]:
+            got = cv2.GaussianBlur(img, (kw, kh), s1, s2)
+            exp = oracle.gaussian_blur(img, (kw, kh), s1, s2)
+            assert got.shape == img.shape and np.array_equal(got, exp), (img.shape, kw, kh, s1, s2)
+    assert np.array_equal(T.simple_gaussian_blur(imgs[1], 7, 2.0), oracle.gaussian_blur(imgs[1], (7, 7), 2.0))
+    with pytest.raises(ValueError):
+        T.simple_gaussian_blur(imgs[1], 4, 1.0)
+    # independent witness: a float Gaussian with mirrored borders agrees to the quantisation of the 8.8 taps
+    import scipy.ndimage as ndi
+    g = imgs[0]
+    ref = ndi.gaussian_filter(g.astype(np.float64), 0.15 * 31 + 0.35, mode="mirror", truncate=15 / (0.15 * 31 + 0.35))
+    assert np.abs(cv2.GaussianBlur(g, (31, 31), 0).astype(np.float64) - ref).max() <= 2.0
+    f = F.s1_buoy(0)
+    assert np.array_equal(cv2.GaussianBlur(f, (11, 11), 0), oracle.gaussian_blur(f, (11, 11)))

@@ -239,3 +239,30 @@ def test_color_balance_restatement(oracle):
     out = oracle.color_balance(g, equalize_rgb=False, hsv_contrast_correct=False, rgb_extrema_clipping=False, hsi_contrast_correct=True)
     assert (out[:, :, 0] == out[:, :, 1]).all() and (out[:, :, 1] == out[:, :, 2]).all()
     assert out.min() == 0 and out.max() >= 254 and (np.diff(out[0, :, 0].astype(int)) >= 0).all()
+
+
+def test_gaussian_blur_restatement(oracle):
+    """cv2.GaussianBlur, 8-bit fixed-point path: the published small kernels (1-2-1, 1-4-6-4-1, ...) in 8.8 fixed point, taps that
+    always sum to 256, a constant image stays constant, an impulse reproduces the outer product of the taps, and the 3x3 case is
+    the binomial average with half-up rounding and mirrored (101) borders."""
+    assert oracle.gaussian_kernel_fixed(3).tolist() == [64, 128, 64]
+    assert oracle.gaussian_kernel_fixed(5).tolist() == [16, 64, 96, 64, 16]
+    assert oracle.gaussian_kernel_fixed(7).tolist() == [8, 28, 56, 72, 56, 28, 8]
+    assert oracle.gaussian_kernel_fixed(9).tolist() == [4, 13, 30, 51, 60, 51, 30, 13, 4]
+    for n in range(1, 202, 2):
+        for sigma in (0.0, 0.5, 3.7):
+            t = oracle.gaussian_kernel_fixed(n, sigma)
+            assert int(t.sum()) == 256 and np.array_equal(t, t[::-1]) and t[n // 2] == t.max()
+    flat = np.full((9, 12, 3), 77, np.uint8)
+    assert np.array_equal(oracle.gaussian_blur(flat, (11, 7)), flat)
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 255
+    t = oracle.gaussian_kernel_fixed(5).astype(np.int64)
+    exp = (np.outer(t, t) * 255 + 32768) >> 16
+    assert np.array_equal(oracle.gaussian_blur(imp, (5, 5))[8:13, 8:13], exp)
+    rng = np.random.default_rng(4)
+    g = rng.integers(0, 256, (6, 8), dtype=np.uint8).astype(np.int64)
+    p = np.pad(g, 1, mode="reflect")                       # reflect = BORDER_REFLECT_101
+    k = np.array([1, 2, 1])
+    s = sum(k[i] * k[j] * p[i:i + 6, j:j + 8] for i in range(3) for j in range(3))
+    assert np.array_equal(oracle.gaussian_blur(g.astype(np.uint8), (3, 3)), ((s * 4096 + 32768) >> 16).astype(np.uint8))
