@@ -25,10 +25,22 @@ _f64p = C.POINTER(C.c_double)
 
 
 def build(force=False):
+    """Builds liboracle.so when it is missing or older than its sources.  Several processes may ask at once (the two-rank test):
+    the build runs under a file lock into a temporary name and is renamed into place, so nobody ever loads a half-written file."""
+    import fcntl
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("vp_oracle.c", "vp_oracle_balance.c", "Makefile")]
-    if force or not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+
+    def stale():
+        return not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
+    if not (force or stale()):
+        return so
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or stale():
+            tmp = os.path.join(_HERE, f"liboracle.{os.getpid()}.tmp.so")
+            subprocess.check_call(["make", "-C", _HERE, "-B", f"TARGET={os.path.basename(tmp)}", os.path.basename(tmp)], stdout=subprocess.DEVNULL)
+            os.replace(tmp, so)
     return so
 
 
