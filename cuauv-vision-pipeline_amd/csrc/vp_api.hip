@@ -1068,6 +1068,24 @@ static int check_lb(vp_ctx* ctx, const void* src, const void* dst, int w, int h,
     return VP_OK;
 }
 
+int vp_threshold_u8(vp_ctx* ctx, const uint8_t* src, size_t n, double thresh, double maxval, int type, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || n == 0 || type < VP_THRESH_BINARY || type > VP_THRESH_TOZERO_INV || thresh != thresh || maxval != maxval)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_threshold_u8 arguments");
+    const double ft = floor(thresh);
+    const int ithresh = ft < -1 ? -1 : (ft > 256 ? 256 : (int)ft);
+    const double rm = nearbyint(maxval);
+    const int imaxval = rm < 0 ? 0 : (rm > 255 ? 255 : (int)rm);
+    VP_TRY(vp_ws_reserve(ctx, 2 * vp_align(n) + 1024));
+    TAKE(d_src, uint8_t*, n);
+    TAKE(d_dst, uint8_t*, n);
+    VP_TRY(h2d(ctx, d_src, src, n));
+    VP_TRY(vpk_threshold_u8(ctx, d_src, n, ithresh, imaxval, type, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, n));
+    return vp_synchronize(ctx);
+}
+
 int vp_gaussian_blur_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int kw, int kh, double sigma1, double sigma2, uint8_t* dst)
 {
     VP_TRY(check_ctx(ctx));

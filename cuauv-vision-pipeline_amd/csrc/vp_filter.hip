@@ -113,3 +113,33 @@ int vpk_gaussian_blur(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int cn, c
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
+
+// cv2.threshold on 8-bit data (utils/color.py:124-199 binary_threshold / binary_threshold_inv / max_threshold / above_threshold /
+// below_threshold): imgproc/src/thresh.cpp compares against ithresh = floor(thresh); imaxval = saturate(round(maxval)).
+// type: 0 BINARY, 1 BINARY_INV, 2 TRUNC, 3 TOZERO, 4 TOZERO_INV
+__global__ __launch_bounds__(256) void k_threshold_u8(const uint8_t* __restrict__ src, size_t n, int ithresh, int imaxval, int type, uint8_t* __restrict__ dst)
+{
+    const int tr = ithresh < 0 ? 0 : (ithresh > 255 ? 255 : ithresh);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = src[i];
+        const bool above = v > ithresh;
+        int o;
+        switch (type) {
+        case 0: o = above ? imaxval : 0; break;
+        case 1: o = above ? 0 : imaxval; break;
+        case 2: o = above ? tr : v; break;
+        case 3: o = above ? v : 0; break;
+        default: o = above ? 0 : v; break;
+        }
+        dst[i] = (uint8_t)o;
+    }
+}
+
+int vpk_threshold_u8(vp_ctx* ctx, const uint8_t* d_src, size_t n, int ithresh, int imaxval, int type, uint8_t* d_dst)
+{
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 16));
+    hipLaunchKernelGGL(k_threshold_u8, dim3(blocks), dim3(256), 0, ctx->stream, d_src, n, ithresh, imaxval, type, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

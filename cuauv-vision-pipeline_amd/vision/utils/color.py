@@ -203,9 +203,34 @@ def _outside_path(name):
 
 # the rest of the reference's utils/color.py (:156-392): names kept so that `from vision.utils.color import ...` lines of existing modules
 # import; calling them fails loudly instead of falling back to a CPU implementation
-max_threshold = _outside_path("max_threshold")
-above_threshold = _outside_path("above_threshold")
-below_threshold = _outside_path("below_threshold")
+
+
+def _threshold(mat: np.ndarray, thresh: float, maxval: float, kind: int) -> np.ndarray:
+    """cv2.threshold(mat, thresh, maxval, kind)[1] on uint8 images (libvp vp_threshold_u8)."""
+    mat = as_mat(mat)
+    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8 or mat.size == 0:
+        raise TypeError("expected a non-empty uint8 numpy image")
+    mat = np.ascontiguousarray(mat)
+    out = np.empty_like(mat)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_threshold_u8(ctx.handle, _vp.ptr(mat), mat.size, float(thresh), float(maxval), int(kind), _vp.ptr(out)), ctx.handle)
+    return out
+
+
+def max_threshold(mat: np.ndarray, threshold: float) -> np.ndarray:
+    """utils/color.py:156-169 (THRESH_TRUNC): values above the threshold become the threshold."""
+    return _threshold(mat, threshold, 0, 2)
+
+
+def above_threshold(mat: np.ndarray, threshold: float) -> np.ndarray:
+    """utils/color.py:172-185 (THRESH_TOZERO): values above the threshold are kept, the rest become zero."""
+    return _threshold(mat, threshold, 0, 3)
+
+
+def below_threshold(mat: np.ndarray, threshold: float) -> np.ndarray:
+    """utils/color.py:188-199 (THRESH_TOZERO_INV): values above the threshold become zero, the rest are kept."""
+    return _threshold(mat, threshold, 0, 4)
+
 otsu_threshold = _outside_path("otsu_threshold")
 adaptive_threshold_mean = _outside_path("adaptive_threshold_mean")
 adaptive_threshold_mean_inv = _outside_path("adaptive_threshold_mean_inv")

@@ -229,6 +229,11 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
  * probabilistic IoU of the boxes' Gaussian models; a box is dropped when any higher-scored box overlaps it by >= thr.
  * n <= 16384.  The _dev forms take device pointers (e.g. tensors of a PyTorch-ROCm model via data_ptr()), enqueue on the
  * context's stream and return without synchronising. */
+/* cv2.threshold(src, thresh, maxval, type)[1] on 8-bit data of any channel count (utils/color.py:124-199: binary_threshold,
+ * binary_threshold_inv, max_threshold, above_threshold, below_threshold): the comparison is against floor(thresh), maxval is
+ * rounded and saturated.  n_bytes = h * w * channels of a tightly packed image; dst may equal src. */
+enum { VP_THRESH_BINARY = 0, VP_THRESH_BINARY_INV = 1, VP_THRESH_TRUNC = 2, VP_THRESH_TOZERO = 3, VP_THRESH_TOZERO_INV = 4 };
+int vp_threshold_u8(vp_ctx* ctx, const uint8_t* src_host, size_t n_bytes, double thresh, double maxval, int type, uint8_t* dst_host);
 /* cv2.GaussianBlur(src, (kw, kh), sigma1, sigma2) on 8-bit images, cn = 1..4 (modules/preprocessor.py:110-114,
  * utils/transform.py simple_gaussian_blur): OpenCV's bit-exact fixed-point path (8.8 taps summing to 256, 16.16 vertical sums
  * rounded half up, BORDER_REFLECT_101).  kw, kh odd, 1..511; sigma <= 0 means "from the kernel size", sigma2 <= 0 means sigma1.

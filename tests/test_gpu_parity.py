@@ -531,3 +531,20 @@ def test_gaussian_blur_u8(vp, oracle):
     assert np.abs(cv2.GaussianBlur(g, (31, 31), 0).astype(np.float64) - ref).max() <= 2.0
     f = F.s1_buoy(0)
     assert np.array_equal(cv2.GaussianBlur(f, (11, 11), 0), oracle.gaussian_blur(f, (11, 11)))
+
+
+def test_threshold_family(vp):
+    """cv2.threshold variants of utils/color.py:124-199 on 8-bit data.  The definition is elementary (compare with floor(thresh)),
+    so the expectation is written out in numpy: fractional, negative and > 255 thresholds, single- and 3-channel images."""
+    from vision.utils import color
+    rng = np.random.default_rng(2)
+    for img in (rng.integers(0, 256, (37, 53), dtype=np.uint8), rng.integers(0, 256, (20, 31, 3), dtype=np.uint8)):
+        for t in (-3, 0, 0.5, 99, 99.9, 127, 254, 255, 300):
+            it = int(np.floor(t))
+            above = img.astype(np.int32) > it
+            assert np.array_equal(color.max_threshold(img, t), np.where(above, np.clip(it, 0, 255), img).astype(np.uint8)), t
+            assert np.array_equal(color.above_threshold(img, t), np.where(above, img, 0).astype(np.uint8)), t
+            assert np.array_equal(color.below_threshold(img, t), np.where(above, 0, img).astype(np.uint8)), t
+    g = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    assert np.array_equal(color.binary_threshold(g, 100), np.where(g > 100, 255, 0).astype(np.uint8))
+    assert np.array_equal(color.binary_threshold_inv(g, 100), np.where(g > 100, 0, 255).astype(np.uint8))
