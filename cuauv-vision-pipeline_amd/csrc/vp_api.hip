@@ -1086,6 +1086,44 @@ int vp_threshold_u8(vp_ctx* ctx, const uint8_t* src, size_t n, double thresh, do
     return vp_synchronize(ctx);
 }
 
+int vp_otsu_threshold_u8(vp_ctx* ctx, const uint8_t* src, size_t n, double maxval, int type, double* thresh_out, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || n == 0 || n > 0xffffffffull || type < VP_THRESH_BINARY || type > VP_THRESH_TOZERO_INV || maxval != maxval)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_otsu_threshold_u8 arguments");
+    VP_TRY(vp_ws_reserve(ctx, 2 * vp_align(n) + 2048));
+    TAKE(d_src, uint8_t*, n);
+    TAKE(d_dst, uint8_t*, n);
+    TAKE(d_hist, u32*, 1024);
+    VP_TRY(h2d(ctx, d_src, src, n));
+    VP_TRY(vpk_hist_u8(ctx, d_src, n, d_hist));
+    u32 h[256];
+    VP_TRY(d2h(ctx, h, d_hist, 1024));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // imgproc/src/thresh.cpp getThreshVal_Otsu_8u, statement by statement
+    const double scale = 1. / (double)n;
+    double mu = 0;
+    for (int i = 0; i < 256; i++) mu += i * (double)h[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        const double p_i = h[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1. - q1;
+        if (std::min(q1, q2) < 1.1920929e-07 || std::max(q1, q2) > 1. - 1.1920929e-07) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    if (thresh_out) *thresh_out = max_val;
+    const double rm = nearbyint(maxval);
+    VP_TRY(vpk_threshold_u8(ctx, d_src, n, (int)max_val, rm < 0 ? 0 : (rm > 255 ? 255 : (int)rm), type, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, n));
+    return vp_synchronize(ctx);
+}
+
 int vp_gaussian_blur_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int kw, int kh, double sigma1, double sigma2, uint8_t* dst)
 {
     VP_TRY(check_ctx(ctx));

@@ -143,3 +143,28 @@ int vpk_threshold_u8(vp_ctx* ctx, const uint8_t* d_src, size_t n, int ithresh, i
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
+
+// 256-bin histogram of a byte plane (Otsu's threshold, imgproc/src/thresh.cpp getThreshVal_Otsu_8u, needs nothing else)
+__global__ __launch_bounds__(256) void k_hist_u8(const uint8_t* __restrict__ src, size_t n, u32* __restrict__ hist)
+{
+    __shared__ u32 lh[256 * 16];   // 16 interleaved copies against same-bin atomics
+    const int cp = threadIdx.x & 15;
+    for (int i = threadIdx.x; i < 256 * 16; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) atomicAdd(&lh[src[i] * 16 + cp], 1u);
+    __syncthreads();
+    u32 v = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) v += lh[threadIdx.x * 16 + k];
+    if (v) atomicAdd(hist + threadIdx.x, v);
+}
+
+int vpk_hist_u8(vp_ctx* ctx, const uint8_t* d_src, size_t n, u32* d_hist)
+{
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    VP_HIP(ctx, hipMemsetAsync(d_hist, 0, 1024, ctx->stream));
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8));
+    hipLaunchKernelGGL(k_hist_u8, dim3(blocks), dim3(256), 0, ctx->stream, d_src, n, d_hist);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

@@ -231,7 +231,18 @@ def below_threshold(mat: np.ndarray, threshold: float) -> np.ndarray:
     """utils/color.py:188-199 (THRESH_TOZERO_INV): values above the threshold become zero, the rest are kept."""
     return _threshold(mat, threshold, 0, 4)
 
-otsu_threshold = _outside_path("otsu_threshold")
+
+
+def otsu_threshold(mat: np.ndarray):
+    """utils/color.py:204-217 (cv2.threshold(mat, 0, 255, THRESH_OTSU)): (threshold chosen by Otsu's method, thresholded image)."""
+    mat = _u8_image(mat, 1)
+    mat = np.ascontiguousarray(mat)
+    out = np.empty_like(mat)
+    t = _vp.C.c_double(0)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_otsu_threshold_u8(ctx.handle, _vp.ptr(mat), mat.size, 255.0, 0, _vp.C.byref(t), _vp.ptr(out)), ctx.handle)
+    return t.value, out
+
 adaptive_threshold_mean = _outside_path("adaptive_threshold_mean")
 adaptive_threshold_mean_inv = _outside_path("adaptive_threshold_mean_inv")
 adaptive_threshold_gaussian = _outside_path("adaptive_threshold_gaussian")

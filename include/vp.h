@@ -234,6 +234,10 @@ int vp_chain_run_contours_host(vp_ctx* ctx, const vp_chain_desc* desc, const vp_
  * rounded and saturated.  n_bytes = h * w * channels of a tightly packed image; dst may equal src. */
 enum { VP_THRESH_BINARY = 0, VP_THRESH_BINARY_INV = 1, VP_THRESH_TRUNC = 2, VP_THRESH_TOZERO = 3, VP_THRESH_TOZERO_INV = 4 };
 int vp_threshold_u8(vp_ctx* ctx, const uint8_t* src_host, size_t n_bytes, double thresh, double maxval, int type, uint8_t* dst_host);
+/* cv2.threshold(src, 0, maxval, type | THRESH_OTSU) on a single-channel 8-bit image (utils/color.py:204-217 otsu_threshold):
+ * threshold chosen by getThreshVal_Otsu_8u from the histogram (device) with the reference's double-precision scan (host),
+ * returned in *thresh_out, then applied as above. */
+int vp_otsu_threshold_u8(vp_ctx* ctx, const uint8_t* src_host, size_t n_bytes, double maxval, int type, double* thresh_out, uint8_t* dst_host);
 /* cv2.GaussianBlur(src, (kw, kh), sigma1, sigma2) on 8-bit images, cn = 1..4 (modules/preprocessor.py:110-114,
  * utils/transform.py simple_gaussian_blur): OpenCV's bit-exact fixed-point path (8.8 taps summing to 256, 16.16 vertical sums
  * rounded half up, BORDER_REFLECT_101).  kw, kh odd, 1..511; sigma <= 0 means "from the kernel size", sigma2 <= 0 means sigma1.

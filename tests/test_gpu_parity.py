@@ -548,3 +548,42 @@ def test_threshold_family(vp):
     g = rng.integers(0, 256, (37, 53), dtype=np.uint8)
     assert np.array_equal(color.binary_threshold(g, 100), np.where(g > 100, 255, 0).astype(np.uint8))
     assert np.array_equal(color.binary_threshold_inv(g, 100), np.where(g > 100, 0, 255).astype(np.uint8))
+
+
+def test_otsu_threshold(vp):
+    """cv2.threshold(..., THRESH_OTSU) (utils/color.py:204-217): the histogram comes from the GPU, the scan is OpenCV's
+    getThreshVal_Otsu_8u; the expectation restates that scan in numpy float64 and, independently, maximises the between-class
+    variance by brute force."""
+    from vision.utils import color
+    rng = np.random.default_rng(5)
+    for img in (np.clip(np.concatenate([rng.normal(60, 12, 4000), rng.normal(180, 20, 6000)]), 0, 255).astype(np.uint8).reshape(100, 100),
+                rng.integers(0, 256, (77, 91), dtype=np.uint8), np.full((8, 8), 7, np.uint8), np.repeat(np.array([[10, 200]], np.uint8), 6, 0)):
+        t, out = color.otsu_threshold(img)
+        h = np.bincount(img.ravel(), minlength=256).astype(np.float64)
+        scale = 1.0 / img.size
+        mu = float((np.arange(256) * h).sum()) * scale
+        mu1 = q1 = 0.0
+        best, arg = 0.0, 0.0
+        for i in range(256):
+            p = h[i] * scale
+            mu1 *= q1
+            q1 += p
+            q2 = 1.0 - q1
+            if min(q1, q2) < 1.1920929e-07 or max(q1, q2) > 1.0 - 1.1920929e-07:
+                continue
+            mu1 = (mu1 + i * p) / q1
+            mu2 = (mu - q1 * mu1) / q2
+            s = q1 * q2 * (mu1 - mu2) ** 2
+            if s > best:
+                best, arg = s, float(i)
+        assert t == arg
+        assert np.array_equal(out, np.where(img > t, 255, 0).astype(np.uint8))
+        if h[h > 0].size > 1:   # brute force: the chosen threshold maximises the between-class variance
+            var = []
+            for k in range(256):
+                w0 = h[:k + 1].sum(); w1 = h[k + 1:].sum()
+                if w0 == 0 or w1 == 0:
+                    var.append(0.0); continue
+                m0 = (np.arange(k + 1) * h[:k + 1]).sum() / w0; m1 = (np.arange(k + 1, 256) * h[k + 1:]).sum() / w1
+                var.append(w0 * w1 * (m0 - m1) ** 2)
+            assert var[int(t)] >= max(var) * (1 - 1e-12)
