@@ -76,3 +76,59 @@ def draw_contours(mat: np.ndarray, contours: List[np.ndarray], color: Tuple[int,
     """utils/draw.py:283-301 (cv2.drawContours(mat, contours, -1, color, thickness)); modifies `mat` in place."""
     for c in contours:
         draw_polylines(mat, c, True, color, thickness)
+
+
+def draw_line(mat: np.ndarray, pt1: Tuple[int, int], pt2: Tuple[int, int], color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
+    """utils/draw.py:101-121 (cv2.line): in place."""
+    _line(mat, pt1, pt2, color, max(int(thickness), 1))
+
+
+def draw_rect(mat: np.ndarray, pt1: Tuple[int, int], pt2: Tuple[int, int], color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
+    """utils/draw.py:147-168 (cv2.rectangle): in place; negative thickness fills."""
+    (x0, y0), (x1, y1) = (int(pt1[0]), int(pt1[1])), (int(pt2[0]), int(pt2[1]))
+    if thickness < 0:
+        h, w = mat.shape[:2]
+        xa, xb = max(min(x0, x1), 0), min(max(x0, x1), w - 1)
+        ya, yb = max(min(y0, y1), 0), min(max(y0, y1), h - 1)
+        if xa <= xb and ya <= yb:
+            mat[ya:yb + 1, xa:xb + 1] = color
+        return
+    for a, b in (((x0, y0), (x1, y0)), ((x1, y0), (x1, y1)), ((x1, y1), (x0, y1)), ((x0, y1), (x0, y0))):
+        _line(mat, a, b, color, max(int(thickness), 1))
+
+
+def draw_circle(mat: np.ndarray, center: Tuple[int, int], radius: int, color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
+    """utils/draw.py:51-72 (cv2.circle): in place; negative thickness fills.  Midpoint rasterisation."""
+    cx, cy, r = int(center[0]), int(center[1]), int(radius)
+    h, w = mat.shape[:2]
+    if r < 0:
+        return
+    if thickness < 0:
+        for dy in range(-r, r + 1):
+            y = cy + dy
+            if 0 <= y < h:
+                dx = int(np.floor(np.sqrt(r * r - dy * dy)))
+                xa, xb = max(cx - dx, 0), min(cx + dx, w - 1)
+                if xa <= xb:
+                    mat[y, xa:xb + 1] = color
+        return
+    t = max(int(thickness), 1)
+    r0, r1 = (t - 1) // 2, t // 2
+    x, y, d = r, 0, 1 - r
+    while x >= y:
+        for px, py in ((x, y), (y, x), (-y, x), (-x, y), (-x, -y), (-y, -x), (y, -x), (x, -y)):
+            _stamp(mat, cx + px, cy + py, color, r0, r1)
+        y += 1
+        if d < 0:
+            d += 2 * y + 1
+        else:
+            x -= 1
+            d += 2 * (y - x) + 1
+
+
+def draw_text(mat: np.ndarray, s: str, origin: Tuple[int, int], scale: float, color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
+    """utils/draw.py:218-242 (cv2.putText with the Hershey simplex font).  Glyph rendering is not reproduced: the stand-in marks the
+    text's baseline with a line of the width the label would take (about 20 * scale pixels per character), so overlays stay
+    legible as "something was labelled here" and handlers that annotate their debug images run unchanged."""
+    x, y = int(origin[0]), int(origin[1])
+    _line(mat, (x, y), (x + int(round(20 * float(scale) * len(str(s)))), y), color, max(int(thickness), 1))

@@ -106,4 +106,11 @@ def simple_gaussian_blur(mat: np.ndarray, kernel_size: int, std_dev: float) -> n
     return cv2_facade.GaussianBlur(mat, (kernel_size, kernel_size), std_dev)
 rotate = _outside_path("rotate")
 translate = _outside_path("translate")
-decode_normal = _outside_path("decode_normal")
+
+
+def decode_normal(mat: np.ndarray) -> np.ndarray:
+    """utils/transform.py:218-233 (modules/normal.py:26): [0, 255] normal map back to float32 vectors in [-1, 1]; plain numpy in the
+    reference as well, same operations in the same order."""
+    img = np.asarray(mat).astype(np.float32)
+    img = (img / 255.0) * 2.0 - 1.0
+    return img

@@ -272,3 +272,22 @@ def test_video_capture_source(tmp_path):
         src._quit_flag.set()
         t.join(5)
         src.close()
+
+
+def test_overlay_helpers_and_decode_normal():
+    """The drawing helpers the handlers import (handlers/bins.py, gate.py: draw_rect / draw_circle / draw_text) and
+    utils/transform.py decode_normal (modules/normal.py:26): in-place host stand-ins, not part of the accelerated path."""
+    from vision.utils import draw, transform
+    m = np.zeros((40, 60, 3), np.uint8)
+    draw.draw_rect(m, (5, 5), (20, 15), (0, 255, 0), 1)
+    assert m[5, 5:21, 1].min() == 255 and m[15, 5:21, 1].min() == 255 and m[5:16, 5, 1].min() == 255 and m[10, 10].sum() == 0
+    draw.draw_rect(m, (30, 5), (35, 8), (7, 7, 7), -1)
+    assert (m[5:9, 30:36] == 7).all()
+    draw.draw_circle(m, (40, 25), 8, (255, 0, 0), 1)
+    assert m[25, 48, 0] == 255 and m[25, 32, 0] == 255 and m[17, 40, 0] == 255 and m[25, 40].sum() == 0
+    before = m.copy()
+    draw.draw_text(m, "label", (2, 38), 0.5, (0, 0, 255))
+    assert (m != before).any()
+    draw.draw_circle(m, (1000, 1000), 5)                     # fully outside: no exception
+    n = transform.decode_normal(np.array([[[0, 255, 128]]], np.uint8))
+    assert n.dtype == np.float32 and n[0, 0, 0] == -1.0 and n[0, 0, 1] == 1.0 and abs(n[0, 0, 2] - (128 / 255 * 2 - 1)) < 1e-6
