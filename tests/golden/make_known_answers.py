@@ -26,6 +26,15 @@ known = {
     # by definition (Appendix A8): two single pixels, A at (row 1, col 0), B at (row 0, col 10):
     # 2x2-block raster order labels A=1, B=2; pixel raster order labels B=1, A=2
     "ccl_numbering": {"size": [4, 16], "A": [1, 0], "B": [0, 10], "block2x2": {"A": 1, "B": 2}, "pixel": {"A": 2, "B": 1}},
+    # (H,S,V) -> (B,G,R), COLOR_HSV2BGR uint8: the inverses of the A2 pairs plus two secondaries
+    "hsv2bgr": [[[0, 255, 255], [0, 0, 255]], [[60, 255, 255], [0, 255, 0]], [[120, 255, 255], [255, 0, 0]], [[0, 0, 255], [255, 255, 255]],
+                [[0, 0, 0], [0, 0, 0]], [[15, 76, 200], [140, 170, 200]], [[30, 255, 255], [0, 255, 255]], [[90, 255, 128], [128, 128, 0]]],
+    # cv2.getGaussianKernel's small fixed kernels scaled by 256 (the 8.8 taps of the bit-exact 8-bit GaussianBlur)
+    "gaussian_taps": {"3": [64, 128, 64], "5": [16, 64, 96, 64, 16], "7": [8, 28, 56, 72, 56, 28, 8], "9": [4, 13, 30, 51, 60, 51, 30, 13, 4]},
+    # cv2.findContours on a filled 5x4 rectangle at (3,2): top-left, bottom-left, bottom-right, top-right (CHAIN_APPROX_SIMPLE)
+    "contour_rect": {"size": [8, 10], "rect": [2, 3, 6, 8], "points": [[3, 2], [3, 5], [7, 5], [7, 2]]},
+    # cv2.threshold(THRESH_OTSU) on a two-valued image returns the lower value
+    "otsu_two_values": {"values": [10, 200], "threshold": 10},
 }
 
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "known_answers.json"), "w") as f:

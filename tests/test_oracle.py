@@ -188,6 +188,20 @@ def test_chain_equals_composition(oracle):
     assert n >= 2
 
 
+def test_known_answers_second_batch(oracle):
+    """tests/golden/known_answers.json entries added with the colour balance / blur / contour work."""
+    for hsv, bgr in G["hsv2bgr"]:
+        assert oracle.hsv2bgr(np.array([[hsv]], np.uint8))[0, 0].tolist() == bgr
+    for n, taps in G["gaussian_taps"].items():
+        assert oracle.gaussian_kernel_fixed(int(n)).tolist() == taps
+    c = G["contour_rect"]
+    m = np.zeros(c["size"], np.uint8)
+    y0, x0, y1, x1 = c["rect"]
+    m[y0:y1, x0:x1] = 255
+    (cont,) = oracle.find_contours(m, 0, 2)
+    assert cont.reshape(-1, 2).tolist() == c["points"]
+
+
 def test_hsv2bgr_known_answers_and_variants(oracle):
     """cv2.cvtColor(COLOR_HSV2BGR), 8-bit: primaries / greys (the inverses of SURVEY A2's known answers), agreement of the two
     arithmetic forms of OpenCV's float kernel except on a small counted set, round trip through BGR2HSV within the
