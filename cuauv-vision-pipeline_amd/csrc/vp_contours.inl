@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void k_ct_outside(const u64* __restrict__ bits
         const int st = run_start(w, s);   // `rem` may have been cut: the segment id comes from the real start
         u32 r = seg_id(G, y, 64 * j + st);
         for (u32 q = p[r]; q != r; q = p[r]) r = q;
-        atomicOr(o + (r >> 5), 1u << (r & 31));
+        // nearly every frame-touching segment belongs to the one big outside region: test before setting, or a couple of thousand
+        // atomics per frame queue up on a single word (28 us of a single-frame call were exactly that)
+        if (!((ld_rlx(o + (r >> 5)) >> (r & 31)) & 1u)) atomicOr(o + (r >> 5), 1u << (r & 31));
     }
 }
 
