@@ -1,6 +1,6 @@
 // C ABI of libvp.so (see include/vp.h): context, workspace, per-operator host entry points and the
 // batched device-resident chain.  No CPU arithmetic path exists here: every operator stages its
-// operands into HBM and launches the HIP kernels of vp_color / vp_morph / vp_ccl.
+// operands into HBM and launches the HIP kernels of vp_color / vp_morph / vp_ccl (+ contours) / vp_balance / vp_filter / vp_yolo.
 #include "vp_internal.h"
 #include <cstdio>
 #include <cstdlib>

@@ -24,11 +24,12 @@
 //   k_ccl_stats    label = rank(root)+1 per segment -> seglabel[id], wordlabel[word]; per-block LDS aggregation,
 //                  then one set of global atomics per (block, label)
 //   k_ccl_final    accumulators -> stats (i32 x5) + centroids (f64 x2)
-//
-// Measured and dropped (git history has them): one 1024-thread block per frame running boundary -> rank -> stats -> final
-// with block barriers (111 us vs 65 us for the separate launches, 64 x 1080p: per-thread serial chains); writing the
-// stats rows from the last block of k_ccl_stats (a counter atomic + fence per block: 35x slower); 2-4 internal streams.
 //   k_ccl_write    bits + wordlabel (+ seglabel for words holding several segments) -> int32 label image
+//
+// Measured and dropped (git history has them; DESIGN.md section 5 lists the numbers): one 1024-thread block per frame running
+// boundary -> rank -> stats -> final with block barriers; writing the stats rows from the last block of k_ccl_stats; 2-4 internal
+// streams; 64-row strips; a per-strip rank fed by root counters; path compression after the boundary unions; replicated
+// accumulators; label write of one half of the batch under the bookkeeping of the other.
 #include "vp_internal.h"
 #include "vp_ccl_dev.h"
 #include <limits.h>
