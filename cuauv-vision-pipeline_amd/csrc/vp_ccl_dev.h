@@ -199,17 +199,46 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
         return;
     }
     {
+        // Segments get their local index here, and the segments of one row that continue across word boundaries get their run's
+        // first segment as parent straight away: a scan over the 32 words a half-wave holds (a word of all ones passes the
+        // incoming leader on, any other word starts a new one), not 30 neighbour unions that would leave a chain 30 links deep
+        // for every later find to walk (measured: the union phase was 24 of the 31 us a block took).
         u32 run = wsum[wv] + inc - cnt;
-        CL_FOR_WORDS(r, j, i) {
-            const u64 w = lbits[i];
-            wbase[i] = run;
-            u64 st = w & ~(w << 1);
-            while (st) {
-                const int s = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                lparent[run] = run;
-                lgid[run] = seg_id(G, y0 + r, 64 * j + s);
-                run++;
+        const int l32 = tid & 31;
+        const u32 NONE = 0xffffffffu;
+        for (int r = tid >> 5; r < nrows; r += 8) {
+            u32 carry = NONE;   // leader of the run that leaves the previous chunk of this row through bit 63
+            for (int j0 = 0; j0 < ww; j0 += 32) {
+                const int j = j0 + l32, i = r * ww + j;
+                const bool valid = j < ww;
+                const u64 w = valid ? lbits[i] : 0ull;
+                const u32 first = run;
+                if (valid) wbase[i] = run;
+                u64 st = w & ~(w << 1);
+                while (st) {
+                    const int s = __ffsll((long long)st) - 1;
+                    st &= st - 1;
+                    lparent[run] = run;
+                    lgid[run] = seg_id(G, y0 + r, 64 * j + s);
+                    run++;
+                }
+                // f_j(x) = (pass && x != NONE) ? x : val  -  leader of the run that leaves word j through bit 63, given the one entering
+                bool pass = w == ~0ull;
+                u32 val = (w >> 63) ? run - 1u : NONE;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const u32 pv = __shfl_up(val, d, 32);
+                    const int pp = __shfl_up((int)pass, d, 32);
+                    if (l32 >= d && pass) {          // (earlier pp, pv) then (pass = true, val)
+                        if (pp) val = pv;            // both pass: the earlier default stands in
+                        else { val = pv != NONE ? pv : val; pass = false; }
+                    }
+                }
+                const u32 lout = (pass && carry != NONE) ? carry : val;
+                u32 lin = __shfl_up(lout, 1, 32);
+                if (l32 == 0) lin = carry;
+                if (valid && (w & 1ull) && lin != NONE) lparent[first] = lin;   // continues the run: lin < first
+                carry = __shfl(lout, 31, 32);
             }
         }
     }
@@ -218,7 +247,6 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
         const u64 w = lbits[i];
         if (!w) continue;
         const u32 base = wbase[i];
-        if ((w & 1ull) && j > 0 && (lbits[i - 1] >> 63)) lds_unite(lparent, base, wbase[i - 1] + nstarts(lbits[i - 1]) - 1u);
         if (r == 0) continue;
         const u64 um = lbits[i - ww];
         const u64 ul = (j > 0 && !G.conn4) ? lbits[i - ww - 1] : 0ull;
@@ -226,6 +254,8 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
         if (!(um | (ul >> 63) | (ur & 1ull))) continue;
         const u32 ubase = wbase[i - ww];
         const u64 ustarts = um & ~(um << 1);
+        // both this row's run and the run above come in from the left: the word to the left asks for the same union
+        const bool left_has_it = (w & 1ull) && (um & 1ull) && j > 0 && (lbits[i - 1] >> 63) && (lbits[i - ww - 1] >> 63);
         u64 rem = w;
         u32 me = base;
         while (rem) {
@@ -234,6 +264,7 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
             const u64 Sg = bit_range(s, e);
             rem &= ~Sg;
             u64 c = um & (G.conn4 ? Sg : (Sg | (Sg << 1) | (Sg >> 1)));
+            if (s == 0 && left_has_it) c &= ~bit_range(0, run_end(um, 0));
             while (c) {
                 const int b = __ffsll((long long)c) - 1;
                 const int st = run_start(um, b), en = run_end(um, b);
