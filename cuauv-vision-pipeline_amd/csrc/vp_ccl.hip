@@ -114,9 +114,9 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
     __shared__ u32 total_s;
     const int ww = G.ww;
     const int frame = blockIdx.x / strips, strip = blockIdx.x - frame * strips;
-    const int y0 = strip * CL_ROWS;
-    const int nrows = min(CL_ROWS, G.h - y0);
-    const int nwmax = CL_ROWS * ww;
+    const int y0 = strip * G.rows;
+    const int nrows = min(G.rows, G.h - y0);
+    const int nwmax = G.rows * ww;
     u64* lbits = cl_lds;
     u32* wbase = reinterpret_cast<u32*>(cl_lds + nwmax);
     u32* lparent = wbase + (nwmax + 2);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
 // vertical unions across strip boundaries: grid (strips - 1, n), block = 64 threads over the words of the row
 __global__ __launch_bounds__(64) void k_ccl_boundary(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent, u32* __restrict__ flags)
 {
-    const int y = (blockIdx.x + 1) * CL_ROWS;
+    const int y = (blockIdx.x + 1) * G.rows;
     const u64* fb = bits + (size_t)blockIdx.y * G.h * G.ww;
     u32* p = parent + (size_t)blockIdx.y * G.nids;
     u32* f = flags + (size_t)blockIdx.y * G.nw32;
@@ -536,6 +536,11 @@ static void ccl_make_geom(ccl_geom& G, int w, int h, int numbering, int invert, 
     G.nids = (u32)vp_ccl_nids(w, h);
     G.nw32 = G.nids / 32;
     G.invert = invert; G.conn4 = conn4;
+    // Strip height of the strip-local pass.  A block's time grows faster than its strip (64 rows: 75 us, 32: 53 us at 1080p), and
+    // wide rows make strips heavy: at 4K (60 words per row) 16-row strips take k_ccl_local from 116 to 44 us for +4 us of
+    // boundary unions; at 1080p the two cancel.  16 rows need ceil(w/2) even (bitmap slices must not share a word).
+    G.rows = (G.ww > 32 && (G.wb % 2) == 0) ? 16 : 32;
+    if (const char* e = getenv("VP_CL_ROWS")) { const int r = atoi(e); if ((r == 8 || r == 16 || r == 32) && ((u32)r * (u32)G.wb) % 32u == 0) G.rows = r; }
 }
 
 // union-find phase only: parent[] (every segment points at a smaller id of its component, roots at themselves)
@@ -545,8 +550,8 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
     const int h = G.h;
     const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
     hipStream_t s = ctx->stream;
-    const int strips = (h + CL_ROWS - 1) / CL_ROWS;
-    const size_t nwmax = (size_t)CL_ROWS * G.ww;
+    const int strips = (h + G.rows - 1) / G.rows;
+    const size_t nwmax = (size_t)G.rows * G.ww;
     // Foreground: room for one segment per word of the strip (a full mask) + 2, the size of the wbase array whose LDS lmin then
     // reuses; denser strips (speckle) take the global fallback.  Background pass of the contour code: every empty word is a
     // segment and every foreground edge adds one, so it gets its own lmin array and 1024 more entries.

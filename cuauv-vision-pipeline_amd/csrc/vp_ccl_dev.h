@@ -7,6 +7,7 @@ struct ccl_geom {
     int w, h, ww, wb, numbering;
     u32 nids;   // multiple of 128
     u32 nw32;   // nids / 32
+    int rows;   // rows per strip of the strip-local pass: 32, or 16 for wide frames (see ccl_make_geom)
     int invert; // label the zero pixels instead (background regions, for hole borders)
     int conn4;  // 4-connectivity (background of an 8-connected foreground)
 };
@@ -112,7 +113,7 @@ __device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, con
 }
 
 // ---- strip-local union-find in LDS ------------------------------------------------------------------
-#define CL_ROWS 32
+#define CL_ROWS 32    // largest strip height; G.rows is the one in use
 #define CL_CAP 512    // default segments per strip handled in LDS (foreground); denser strips fall back to global memory
 
 __device__ __forceinline__ u32 lds_find(volatile u32* p, u32 x)
@@ -156,13 +157,14 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
 {
     const int ww = G.ww;
     const int tid = threadIdx.x;
-    // this strip's slice of the root bitmap (ids of 32 rows = a multiple of 32 ids, so slices never share a word)
+    // this strip's slice of the root bitmap (ids of G.rows rows = a multiple of 32 ids, so slices never share a word:
+    // 32 rows always are, 16 rows when ceil(w/2) is even - ccl_make_geom only picks 16 then)
     {
         const u32 rows_ids = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;   // ids per row pair / per row
         const u32 lo = (G.numbering == VP_CCL_BLOCK2X2) ? (u32)(y0 >> 1) * rows_ids : (u32)y0 * rows_ids;
         const u32 w0 = lo >> 5;
-        const u32 w1 = (strip == strips - 1) ? G.nw32 : ((G.numbering == VP_CCL_BLOCK2X2) ? ((u32)((y0 + CL_ROWS) >> 1) * rows_ids) >> 5
-                                                                                         : ((u32)(y0 + CL_ROWS) * rows_ids) >> 5);
+        const u32 w1 = (strip == strips - 1) ? G.nw32 : ((G.numbering == VP_CCL_BLOCK2X2) ? ((u32)((y0 + G.rows) >> 1) * rows_ids) >> 5
+                                                                                         : ((u32)(y0 + G.rows) * rows_ids) >> 5);
         for (u32 i = w0 + tid; i < w1; i += 256) gf[i] = 0u;
     }
     u32 cnt = 0;
