@@ -587,3 +587,15 @@ def test_otsu_threshold(vp):
                 m0 = (np.arange(k + 1) * h[:k + 1]).sum() / w0; m1 = (np.arange(k + 1, 256) * h[k + 1:]).sum() / w1
                 var.append(w0 * w1 * (m0 - m1) ** 2)
             assert var[int(t)] >= max(var) * (1 - 1e-12)
+
+
+@pytest.mark.parametrize("h,w", [(40, 2050), (50, 2112), (70, 4100), (33, 3838)])
+def test_ccl_wide_frames_both_strip_heights(vp, oracle, h, w):
+    """Frames wider than 2048 px use 16-row strips for the strip-local union-find when ceil(w/2) is even and 32-row strips
+    otherwise (the root-bitmap slices must not share a word): both cases, both numberings, blobs crossing many strips."""
+    rng = np.random.default_rng(w)
+    m = F.random_mask(rng, h, w, 0.55)
+    m[:, w // 3: w // 3 + 70] = 255                      # a tall blob through every strip
+    m[h // 2, :] = 255                                    # and a line through every word of a row
+    for numbering in (2, 1):
+        _check_ccl(vp, oracle, m, numbering)
