@@ -358,29 +358,51 @@ __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits,
             }
             acc_commit(a + label, c);   // crowded block (noise): straight to global memory
         };
-        auto segment = [&](int s, int e, contrib& c) -> u32 {
+        const bool multi = nstarts(w) > 1u;   // the label-write kernel reads seglabel only for words holding several segments
+        auto lookup = [&](int s) -> u32 {     // label of the segment starting at bit s: four dependent, uncoalesced reads
             const u32 id = seg_id(G, y, 64 * j + s);
             u32 r = id;
             for (u32 q = p[r]; q != r; q = p[r]) r = q;   // read-only walk: strip root, then across strips
             const u32 label = pf[r >> 5] + (u32)__popc(fl[r >> 5] & ((1u << (r & 31)) - 1u)) + 1u;
-            sl[id] = label;
+            if (multi) sl[id] = label;
+            return label;
+        };
+        auto record = [&](int s, int e, contrib& c) {
             const u32 len = (u32)(e - s + 1);
             const int xs = 64 * j + s, xe = 64 * j + e;
             c.area = len; c.sx = (u64)len * (u64)(xs + xe) / 2ull; c.sy = (u64)len * (u64)y;
             c.minx = xs; c.maxx = xe; c.miny = c.maxy = y;
-            return label;
         };
         u64 rem = w;
         contrib c0;
         contrib_zero(c0);
         u32 lab0 = 0;
-        if (w) {
-            const int s = __ffsll((long long)rem) - 1;
-            const int e = run_end(rem, s);
-            rem &= ~bit_range(s, e);
-            lab0 = segment(s, e, c0);
-            wordlabel[(size_t)f * G.h * G.ww + idx] = lab0;
-            if (lab0 >= (u32)max_labels) { lab0 = 0; contrib_zero(c0); }
+        {
+            // A first segment that continues the only segment of the word to its left (same row, same wave) has that segment's
+            // label: only the first word of such a chain looks its label up, the others take it through a wave scan.  Inside
+            // blobs that removes most of the uncoalesced reads this kernel waits for.
+            const int lane = threadIdx.x & 63;
+            const u64 wprev = __shfl_up(w, 1);
+            bool take = (w & 1ull) && lane > 0 && j > 0 && (wprev >> 63) && nstarts(wprev) == 1u;
+            int s0 = 0, e0 = 0;
+            u32 lab = 0;
+            if (w) {
+                s0 = __ffsll((long long)rem) - 1;
+                e0 = run_end(rem, s0);
+                rem &= ~bit_range(s0, e0);
+                if (!take) lab = lookup(s0);
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 pv = __shfl_up(lab, d);
+                const int pt = __shfl_up((int)take, d);
+                if (lane >= d && take) { lab = pv; take = pt != 0; }
+            }
+            if (w) {
+                if (multi) sl[seg_id(G, y, 64 * j + s0)] = lab;
+                wordlabel[(size_t)f * G.h * G.ww + idx] = lab;
+                if (lab < (u32)max_labels) { lab0 = lab; record(s0, e0, c0); }
+            }
         }
         const unsigned long long act = __ballot(lab0 != 0u);
         if (act) {
@@ -398,8 +420,8 @@ __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits,
             const int e = run_end(rem, s);
             rem &= ~bit_range(s, e);
             contrib c;
-            const u32 label = segment(s, e, c);
-            if (label < (u32)max_labels) table_add(label, c);
+            const u32 label = lookup(s);
+            if (label < (u32)max_labels) { record(s, e, c); table_add(label, c); }
         }
         __syncthreads();
         if (threadIdx.x < ST_SLOTS && T.label[threadIdx.x]) {
