@@ -1163,6 +1163,25 @@ int vp_resize_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int dw, 
     return vp_synchronize(ctx);
 }
 
+int vp_warp_affine_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, const double* m23, int flags, int border_mode,
+                      const uint8_t* border_value, uint8_t* dst, int dw, int dh)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || !m23 || w <= 0 || h <= 0 || dw <= 0 || dh <= 0 || dh > 65535 || cn < 1 || cn > 4 || (flags & ~VP_WARP_INVERSE_MAP) ||
+        (border_mode != VP_BORDER_CONSTANT && border_mode != VP_BORDER_REPLICATE))
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_warp_affine_u8 arguments");
+    for (int i = 0; i < 6; i++)
+        if (!std::isfinite(m23[i])) return vp_fail(ctx, VP_ERR_INVALID, "vp_warp_affine_u8: matrix is not finite");
+    const size_t sbytes = (size_t)w * h * cn, dbytes = (size_t)dw * dh * cn;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(sbytes) + vp_align(dbytes) + 1024));
+    TAKE(d_src, uint8_t*, sbytes);
+    TAKE(d_dst, uint8_t*, dbytes);
+    VP_TRY(h2d(ctx, d_src, src, sbytes));
+    VP_TRY(vpk_warp_affine_u8(ctx, d_src, w, h, cn, m23, (flags & VP_WARP_INVERSE_MAP) != 0, border_mode, border_value, d_dst, dw, dh));
+    VP_TRY(d2h(ctx, dst, d_dst, dbytes));
+    return vp_synchronize(ctx);
+}
+
 int vp_letterbox_u8_f32(vp_ctx* ctx, const uint8_t* src, int w, int h, int dw, int dh, int pad, float* dst, float* geom_out)
 {
     VP_TRY(check_ctx(ctx));

@@ -102,6 +102,8 @@ int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, 
 // ---- detector pre / post-processing (vp_yolo.hip) ------------------------------------------------
 int vpk_letterbox(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int dw, int dh, int pad, float* d_dst, float* geom_out);
 int vpk_resize_u8(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int cn, int dw, int dh, uint8_t* d_dst);
+int vpk_warp_affine_u8(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int cn, const double* M23, int inverse_map, int border,
+                       const uint8_t* cval, uint8_t* d_dst, int dw, int dh);
 size_t vp_nms_ws_bytes(int n);
 int vpk_nms(vp_ctx* ctx, const float* d_boxes, const float* d_scores, int n, float thr, int rotated, int max_keep, int* d_keep, int* d_nkeep);
 

@@ -115,6 +115,81 @@ int vpk_resize_u8(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int cn, int
     return VP_OK;
 }
 
+// cv2.warpAffine(src, M, (dw, dh), INTER_LINEAR, borderMode) on 8-bit images, OpenCV's classical fixed-point path: source coordinates in
+// 22.10 fixed point from round-half-even products (no fused multiply-add: the reference arithmetic is plain IEEE double), 5 fractional
+// bits kept, 15-bit bilinear weights, (sum + 2^14) >> 15.  M maps destination to source here (the host inverts).  thread = one pixel.
+struct wa_params { double m[6]; int sw, sh, cn, dw, dh, border; uint8_t cval[4]; };
+__device__ __forceinline__ int wa_round(double v)
+{
+    if (!(v > -2147483648.0)) return INT_MIN;
+    if (v >= 2147483647.0) return INT_MAX;
+    return (int)rint(v);
+}
+__global__ __launch_bounds__(256) void k_warp_affine_u8(const uint8_t* __restrict__ src, wa_params P, uint8_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= P.dw) return;
+    const u32 ad = (u32)wa_round(__dmul_rn(__dmul_rn(P.m[0], (double)x), 1024.0));
+    const u32 bd = (u32)wa_round(__dmul_rn(__dmul_rn(P.m[3], (double)x), 1024.0));
+    const u32 X0 = (u32)wa_round(__dmul_rn(__dadd_rn(__dmul_rn(P.m[1], (double)y), P.m[2]), 1024.0)) + 16u;
+    const u32 Y0 = (u32)wa_round(__dmul_rn(__dadd_rn(__dmul_rn(P.m[4], (double)y), P.m[5]), 1024.0)) + 16u;
+    const int X = (int)(X0 + ad) >> 5, Y = (int)(Y0 + bd) >> 5;
+    const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
+    const int fx = X & 31, fy = Y & 31;
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    const int cn = P.cn, sw = P.sw, sh = P.sh;
+    uint8_t* d = dst + ((size_t)y * P.dw + x) * cn;
+    if (P.border == 0 && (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) {
+        for (int c = 0; c < cn; c++) d[c] = P.cval[c];
+        return;
+    }
+    int x0, x1, y0, y1;
+    if (P.border == 1) {
+        x0 = min(max(sx, 0), sw - 1); x1 = min(max(sx + 1, 0), sw - 1);
+        y0 = min(max(sy, 0), sh - 1); y1 = min(max(sy + 1, 0), sh - 1);
+    } else {
+        x0 = (sx >= 0 && sx < sw) ? sx : -1; x1 = (sx + 1 >= 0 && sx + 1 < sw) ? sx + 1 : -1;
+        y0 = (sy >= 0 && sy < sh) ? sy : -1; y1 = (sy + 1 >= 0 && sy + 1 < sh) ? sy + 1 : -1;
+    }
+    const bool i00 = x0 >= 0 && y0 >= 0, i01 = x1 >= 0 && y0 >= 0, i10 = x0 >= 0 && y1 >= 0, i11 = x1 >= 0 && y1 >= 0;
+    const uint8_t* p00 = src + ((size_t)max(y0, 0) * sw + max(x0, 0)) * cn;
+    const uint8_t* p01 = src + ((size_t)max(y0, 0) * sw + max(x1, 0)) * cn;
+    const uint8_t* p10 = src + ((size_t)max(y1, 0) * sw + max(x0, 0)) * cn;
+    const uint8_t* p11 = src + ((size_t)max(y1, 0) * sw + max(x1, 0)) * cn;
+    for (int c = 0; c < cn; c++) {
+        const int cv = P.cval[c];
+        const int v00 = i00 ? p00[c] : cv, v01 = i01 ? p01[c] : cv, v10 = i10 ? p10[c] : cv, v11 = i11 ? p11[c] : cv;
+        const int v = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+        d[c] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+int vpk_warp_affine_u8(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int cn, const double* M23, int inverse_map, int border,
+                       const uint8_t* cval, uint8_t* d_dst, int dw, int dh)
+{
+#pragma clang fp contract(off)   // the inversion is plain IEEE double in the reference arithmetic
+    wa_params P;
+    double M[6];
+    for (int i = 0; i < 6; i++) M[i] = M23[i];
+    if (!inverse_map) {
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11; M[1] *= -D;
+        M[3] *= -D; M[4] = A22;
+        const double b1 = -M[0] * M[2] - M[1] * M[5];
+        const double b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1; M[5] = b2;
+    }
+    for (int i = 0; i < 6; i++) P.m[i] = M[i];
+    P.sw = sw; P.sh = sh; P.cn = cn; P.dw = dw; P.dh = dh; P.border = border;
+    for (int c = 0; c < 4; c++) P.cval[c] = cval ? cval[c] : 0;
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    hipLaunchKernelGGL(k_warp_affine_u8, dim3((unsigned)((dw + 255) / 256), (unsigned)dh), dim3(256), 0, ctx->stream, d_src, P, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
 // LetterBox geometry (scale-up allowed, centred): r = min(dh/sh, dw/sw); content = round(size * r); the odd padding pixel goes
 // right / bottom (round(d - 0.1), round(d + 0.1)).  geom_out: {r, left, top}
 int vpk_letterbox(vp_ctx* ctx, const uint8_t* d_src, int sw, int sh, int dw, int dh, int pad, float* d_dst, float* geom_out)

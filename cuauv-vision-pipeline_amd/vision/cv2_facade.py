@@ -242,16 +242,8 @@ def getRotationMatrix2D(center, angle, scale):
     """imgproc/src/imgwarp.cpp getRotationMatrix2D: 2x3 float64 (modules/preprocessor.py:131-133)."""
     ang = angle * np.pi / 180.0
     a, b = scale * np.cos(ang), scale * np.sin(ang)
-    cx, cy = float(center[0]), float(center[1])
+    cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))   # the centre is a Point2f
     return np.array([[a, b, (1 - a) * cx - b * cy], [-b, a, b * cx + (1 - a) * cy]], np.float64)
-
-
-def _outside(name):
-    def _f(*_a, **_k):
-        raise error(f"cv2.{name} is outside the accelerated path of this build (modules/preprocessor.py uses it only when the "
-                    f"corresponding PPX_* option is switched on); install OpenCV to use it")
-    _f.__name__ = name
-    return _f
 
 
 def GaussianBlur(src, ksize, sigmaX, sigmaY=0):
@@ -271,9 +263,36 @@ def GaussianBlur(src, ksize, sigmaX, sigmaY=0):
     return out
 
 
-warpAffine = _outside("warpAffine")
+BORDER_CONSTANT = 0
 BORDER_REPLICATE = 1
 INTER_LINEAR = 1
+WARP_INVERSE_MAP = 16
+
+
+def warpAffine(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0):
+    """cv2.warpAffine with bilinear interpolation on uint8 images (modules/preprocessor.py:130-135,145-149): OpenCV's classical
+    fixed-point path on the GPU (libvp vp_warp_affine_u8)."""
+    from vision import _vp
+    if (flags & ~WARP_INVERSE_MAP) != INTER_LINEAR:
+        raise error("warpAffine: only INTER_LINEAR is on the accelerated path")
+    if borderMode not in (BORDER_CONSTANT, BORDER_REPLICATE):
+        raise error("warpAffine: only BORDER_CONSTANT and BORDER_REPLICATE are on the accelerated path")
+    src = np.ascontiguousarray(src)
+    if src.dtype != np.uint8 or src.ndim not in (2, 3) or src.size == 0:
+        raise error("warpAffine: expected a non-empty uint8 image")
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    m = np.ascontiguousarray(np.asarray(M, dtype=np.float64))
+    dw, dh = int(dsize[0]), int(dsize[1])
+    if m.shape != (2, 3) or dw <= 0 or dh <= 0 or cn > 4:
+        raise error("warpAffine: M must be 2x3 and the size positive")
+    bv = np.zeros(4, np.uint8)
+    vals = np.atleast_1d(np.asarray(borderValue, dtype=np.float64))[:4]
+    bv[:len(vals)] = np.clip(np.rint(vals), 0, 255).astype(np.uint8)
+    out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_warp_affine_u8(ctx.handle, _vp.ptr(src), src.shape[1], src.shape[0], cn, _vp.ptr(m), int(flags & WARP_INVERSE_MAP),
+                                          int(borderMode), _vp.ptr(bv), _vp.ptr(out), dw, dh), ctx.handle)
+    return out
 
 
 def resize(src, dsize, interpolation=INTER_LINEAR):

@@ -89,14 +89,6 @@ def resize(mat: np.ndarray, width: int, height: int) -> np.ndarray:
     return cv2_facade.resize(mat, (width, height))
 
 
-def _outside_path(name):
-    def _f(*_a, **_k):
-        raise NotImplementedError(f"{name}: outside the accelerated path of this build")
-    _f.__name__ = name
-    return _f
-
-
-
 
 def simple_gaussian_blur(mat: np.ndarray, kernel_size: int, std_dev: float) -> np.ndarray:
     """utils/transform.py:3-25 (cv2.GaussianBlur with a square kernel); ValueError for an even kernel size as in the reference."""
@@ -104,8 +96,20 @@ def simple_gaussian_blur(mat: np.ndarray, kernel_size: int, std_dev: float) -> n
         raise ValueError("kernel_size must be an odd integer")
     from vision import cv2_facade
     return cv2_facade.GaussianBlur(mat, (kernel_size, kernel_size), std_dev)
-rotate = _outside_path("rotate")
-translate = _outside_path("translate")
+
+
+def rotate(mat: np.ndarray, degrees: float) -> np.ndarray:
+    """utils/transform.py:180-196: rotation about the image centre, positive = counterclockwise, borders replicated."""
+    from vision import cv2_facade
+    rot_mat = cv2_facade.getRotationMatrix2D((mat.shape[1] / 2, mat.shape[0] / 2), degrees, 1)
+    return cv2_facade.warpAffine(mat, rot_mat, (mat.shape[1], mat.shape[0]), borderMode=cv2_facade.BORDER_REPLICATE)
+
+
+def translate(mat: np.ndarray, x: int, y: int) -> np.ndarray:
+    """utils/transform.py:199-215: shift by (x, y); uncovered pixels become 0.  The matrix goes through float32 as in the reference."""
+    from vision import cv2_facade
+    trans_mat = np.float32([[1, 0, x], [0, 1, y]])
+    return cv2_facade.warpAffine(mat, trans_mat, (mat.shape[1], mat.shape[0]))
 
 
 def decode_normal(mat: np.ndarray) -> np.ndarray:

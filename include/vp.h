@@ -248,6 +248,15 @@ int vp_gaussian_blur_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int 
  * (modules/preprocessor.py:136-144): OpenCV's generic fixed-point path, including the 2x2 box average it substitutes at an
  * exact halving.  (IPP-enabled OpenCV builds may round differently.) */
 int vp_resize_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int cn, int dst_w, int dst_h, uint8_t* dst_host);
+/* cv2.warpAffine(src, M, (dst_w, dst_h), flags, borderMode, borderValue) with bilinear interpolation on 8-bit images, cn = 1..4
+ * (modules/preprocessor.py:130-135 rotate with BORDER_REPLICATE, :145-149 translate; utils/transform.py:180-210).  m23: the 2x3
+ * matrix, row-major doubles, mapping source to destination unless VP_WARP_INVERSE_MAP is set.  OpenCV's classical fixed-point path
+ * (every release up to 4.10): coordinates in 22.10 fixed point with 5 fractional bits kept, 15-bit weights, round half up.
+ * border_value: cn bytes or NULL (0).  src and dst must not overlap. */
+enum { VP_BORDER_CONSTANT = 0, VP_BORDER_REPLICATE = 1 };
+enum { VP_WARP_INVERSE_MAP = 16 };
+int vp_warp_affine_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int cn, const double* m23, int flags, int border_mode,
+                      const uint8_t* border_value, uint8_t* dst_host, int dst_w, int dst_h);
 int vp_letterbox_u8_f32(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int dst_w, int dst_h, int pad_value, float* dst_host,
                         float* geom_out);
 int vp_letterbox_dev(vp_ctx* ctx, const uint8_t* src_dev, int w, int h, int dst_w, int dst_h, int pad_value, float* dst_dev, float* geom_out);

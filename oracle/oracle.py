@@ -29,7 +29,7 @@ def build(force=False):
     the build runs under a file lock into a temporary name and is renamed into place, so nobody ever loads a half-written file."""
     import fcntl
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("vp_oracle.c", "vp_oracle_balance.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("vp_oracle.c", "vp_oracle_balance.c", "vp_oracle_warp.c", "Makefile")]
 
     def stale():
         return not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
@@ -133,6 +133,32 @@ def gaussian_blur(img, ksize, sigma1=0.0, sigma2=0.0):
     rc = L.orc_gaussian_blur_u8(_p(img, _u8p), w, h, cn, int(ksize[0]), int(ksize[1]), C.c_double(sigma1), C.c_double(sigma2), _p(out, _u8p))
     if rc != 0:
         raise ValueError(f"orc_gaussian_blur_u8: {rc}")
+    return out
+
+
+def rotation_matrix_2d(center, angle, scale=1.0):
+    """cv2.getRotationMatrix2D(center, angle, scale) -> (2, 3) float64."""
+    M = np.empty(6, np.float64)
+    lib().orc_rotation_matrix_2d(C.c_double(center[0]), C.c_double(center[1]), C.c_double(angle), C.c_double(scale), M.ctypes.data_as(C.c_void_p))
+    return M.reshape(2, 3)
+
+
+def warp_affine(img, M, dsize, inverse_map=False, border="constant", value=0):
+    """cv2.warpAffine(img, M, dsize, flags=INTER_LINEAR [| WARP_INVERSE_MAP], borderMode=BORDER_CONSTANT | BORDER_REPLICATE)."""
+    img = _c(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    dw, dh = int(dsize[0]), int(dsize[1])
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    Md = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(6))
+    cv = np.zeros(4, np.uint8)
+    cv[:] = np.broadcast_to(np.asarray(value, dtype=np.uint8), (4,)) if np.ndim(value) == 0 else np.pad(np.asarray(value, np.uint8), (0, 4 - len(value)))
+    L = lib()
+    L.orc_warp_affine_u8.restype = C.c_int
+    rc = L.orc_warp_affine_u8(_p(img, _u8p), w, h, cn, Md.ctypes.data_as(C.c_void_p), int(bool(inverse_map)), {"constant": 0, "replicate": 1}[border],
+                              _p(cv, _u8p), _p(out, _u8p), dw, dh)
+    if rc != 0:
+        raise ValueError(f"orc_warp_affine_u8: {rc}")
     return out
 
 

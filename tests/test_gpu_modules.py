@@ -45,7 +45,10 @@ def test_facade_matches_oracle(vp, oracle, cv2mod):
     over = cv2.addWeighted(img, 0.7, vis, 0.3, 0)
     assert over.dtype == np.uint8 and over.shape == img.shape
     with pytest.raises(cv2.error):          # named, but outside the accelerated path: fails loudly instead of falling back
-        cv2.warpAffine(img, np.eye(2, 3), (4, 4))
+        cv2.warpAffine(img, np.eye(2, 3), (4, 4), flags=0)   # INTER_NEAREST
+    rot = cv2.getRotationMatrix2D((img.shape[1] / 2, img.shape[0] / 2), 30, 1)
+    assert np.array_equal(cv2.warpAffine(img, rot, (img.shape[1], img.shape[0]), borderMode=cv2.BORDER_REPLICATE),
+                          oracle.warp_affine(img, rot, (img.shape[1], img.shape[0]), border="replicate"))
     assert np.array_equal(cv2.GaussianBlur(img, (5, 5), 0), oracle.gaussian_blur(img, (5, 5)))
     assert cv2.add(10, np.array([[250, 3]], np.uint8)).tolist() == [[255, 13]]
     assert np.allclose(cv2.getRotationMatrix2D((10, 5), 90, 1), [[0, 1, 5], [-1, 0, 15]])

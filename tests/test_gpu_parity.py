@@ -599,3 +599,57 @@ def test_ccl_wide_frames_both_strip_heights(vp, oracle, h, w):
     m[h // 2, :] = 255                                    # and a line through every word of a row
     for numbering in (2, 1):
         _check_ccl(vp, oracle, m, numbering)
+
+
+# ---- warpAffine (modules/preprocessor.py:130-135,145-149; utils/transform.py rotate / translate) ---------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp_affine_u8(vp, oracle, cn):
+    from vision import cv2_facade as cvf
+    rng = np.random.default_rng(77 + cn)
+    for (h, w) in ((37, 53), (120, 200), (1, 9), (64, 1)):
+        img = rng.integers(0, 256, (h, w) if cn == 1 else (h, w, cn), dtype=np.uint8)
+        mats = [np.array([[1, 0, 0], [0, 1, 0]], np.float64), np.float32([[1, 0, 7], [0, 1, -3]]), np.float32([[1, 0, -2.25], [0, 1, 5.5]]),
+                cvf.getRotationMatrix2D((w / 2, h / 2), 30, 1), cvf.getRotationMatrix2D((w / 2, h / 2), -117.3, 1), cvf.getRotationMatrix2D((w / 3, h / 5), 90, 0.7),
+                np.array([[0.3, -1.9, 11.2], [2.2, 0.4, -30.0]]), np.array([[0, 0, 0], [0, 0, 0]], np.float64), rng.normal(0, 1.5, (2, 3))]
+        for M in mats:
+            for (dw, dh) in ((w, h), (w + 13, max(1, h - 5))):
+                for border, bname in ((cvf.BORDER_CONSTANT, "constant"), (cvf.BORDER_REPLICATE, "replicate")):
+                    for inv in (0, cvf.WARP_INVERSE_MAP):
+                        val = (9, 200, 31, 77)[:cn] if border == cvf.BORDER_CONSTANT else 0
+                        got = cvf.warpAffine(img, M, (dw, dh), flags=cvf.INTER_LINEAR | inv, borderMode=border, borderValue=val)
+                        exp = oracle.warp_affine(img, M, (dw, dh), inverse_map=bool(inv), border=bname, value=val)
+                        assert got.shape == exp.shape and np.array_equal(got, exp), (h, w, M, dw, dh, bname, inv)
+
+
+@pytest.mark.gpu
+def test_rotate_translate_utils(vp, oracle):
+    from vision.utils import transform
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    t = transform.translate(img, 40, -25)
+    exp = np.zeros_like(img)
+    exp[:1080 - 25, 40:] = img[25:, :1920 - 40]
+    assert np.array_equal(t, exp)                                   # an integer shift is a copy, whatever the interpolation arithmetic
+    r = transform.rotate(img, 12.5)
+    M = oracle.rotation_matrix_2d((1920 / 2, 1080 / 2), 12.5, 1)
+    assert np.array_equal(r, oracle.warp_affine(img, M, (1920, 1080), border="replicate"))
+    sq = rng.integers(0, 256, (64, 64), dtype=np.uint8)              # a quarter turn about the centre is a permutation of the pixels
+    q = transform.rotate(sq, 90)
+    exp = np.array([[sq[X, min(64 - Y, 63)] for X in range(64)] for Y in range(64)], np.uint8)
+    assert np.array_equal(q, exp)
+
+
+@pytest.mark.gpu
+def test_warp_affine_argument_checks(vp):
+    from vision import _vp
+    ctx = _vp.default_context()
+    img = np.zeros((4, 4), np.uint8); out = np.zeros((4, 4), np.uint8)
+    M = np.eye(2, 3); bad = np.full((2, 3), np.nan)
+    L = _vp.lib()
+    assert L.vp_warp_affine_u8(ctx.handle, _vp.ptr(img), 4, 4, 1, _vp.ptr(M), 0, 0, None, _vp.ptr(out), 4, 4) == 0
+    assert L.vp_warp_affine_u8(ctx.handle, _vp.ptr(img), 4, 4, 1, _vp.ptr(bad), 0, 0, None, _vp.ptr(out), 4, 4) != 0
+    assert L.vp_warp_affine_u8(ctx.handle, _vp.ptr(img), 4, 4, 5, _vp.ptr(M), 0, 0, None, _vp.ptr(out), 4, 4) != 0
+    assert L.vp_warp_affine_u8(ctx.handle, _vp.ptr(img), 4, 4, 1, _vp.ptr(M), 1, 0, None, _vp.ptr(out), 4, 4) != 0     # INTER_* bits are not flags here
+    assert L.vp_warp_affine_u8(ctx.handle, _vp.ptr(img), 4, 4, 1, _vp.ptr(M), 0, 4, None, _vp.ptr(out), 4, 4) != 0     # BORDER_REFLECT_101
+    assert L.vp_warp_affine_u8(ctx.handle, None, 4, 4, 1, _vp.ptr(M), 0, 0, None, _vp.ptr(out), 4, 4) != 0

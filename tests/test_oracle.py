@@ -281,3 +281,60 @@ def test_gaussian_blur_restatement(oracle):
     k = np.array([1, 2, 1])
     s = sum(k[i] * k[j] * p[i:i + 6, j:j + 8] for i in range(3) for j in range(3))
     assert np.array_equal(oracle.gaussian_blur(g.astype(np.uint8), (3, 3)), ((s * 4096 + 32768) >> 16).astype(np.uint8))
+
+
+def test_warp_affine_restatement(oracle):
+    """cv2.warpAffine, classical 8-bit bilinear path: identity and integer shifts are copies, a half-pixel shift is the half-up
+    average of neighbours, a quarter turn is a permutation, a general map agrees with an independent numpy restatement of the
+    22.10 / 5-bit / 15-bit fixed-point rule, and both border modes behave as documented."""
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.warp_affine(img, [[1, 0, 0], [0, 1, 0]], (50, 40)), img)
+    out = oracle.warp_affine(img, [[1, 0, 7], [0, 1, -3]], (50, 40), value=(1, 2, 3))
+    exp = np.empty_like(img)
+    exp[:] = (1, 2, 3)
+    exp[0:37, 7:50] = img[3:40, 0:43]
+    # the row just below the copied block blends source row 39 with the border value at weight 0 -> still the source row... which is
+    # outside (sy = 40 is fully out), so it is the plain border value
+    assert np.array_equal(out, exp)
+    g = rng.integers(0, 256, (8, 16), dtype=np.uint8)
+    a = g.astype(int)
+    left = np.concatenate([a[:, :1], a[:, :-1]], 1)
+    assert np.array_equal(oracle.warp_affine(g, [[1, 0, 0.5], [0, 1, 0]], (16, 8), border="replicate"), ((a + left + 1) >> 1).astype(np.uint8))
+    sq = rng.integers(0, 256, (32, 32), dtype=np.uint8)
+    M = oracle.rotation_matrix_2d((16, 16), 90)
+    assert np.allclose(M, [[0, 1, 0], [-1, 0, 32]])
+    q = oracle.warp_affine(sq, M, (32, 32), border="replicate")
+    assert np.array_equal(q, np.array([[sq[X, min(32 - Y, 31)] for X in range(32)] for Y in range(32)], np.uint8))
+
+    def witness(src, Minv, dw, dh, replicate, cval):
+        sh, sw = src.shape
+        x = np.arange(dw, dtype=np.float64)
+        y = np.arange(dh, dtype=np.float64)
+        ad = np.rint(Minv[0, 0] * x * 1024).astype(np.int64)
+        bd = np.rint(Minv[1, 0] * x * 1024).astype(np.int64)
+        X0 = np.rint((Minv[0, 1] * y + Minv[0, 2]) * 1024).astype(np.int64) + 16
+        Y0 = np.rint((Minv[1, 1] * y + Minv[1, 2]) * 1024).astype(np.int64) + 16
+        X = (X0[:, None] + ad[None, :]) >> 5
+        Y = (Y0[:, None] + bd[None, :]) >> 5
+        sx, sy, fx, fy = X >> 5, Y >> 5, X & 31, Y & 31
+        acc = np.zeros((dh, dw), np.int64)
+        for dy, dx, wgt in ((0, 0, (32 - fx) * (32 - fy)), (0, 1, fx * (32 - fy)), (1, 0, (32 - fx) * fy), (1, 1, fx * fy)):
+            xs, ys = sx + dx, sy + dy
+            inside = (xs >= 0) & (xs < sw) & (ys >= 0) & (ys < sh)
+            v = src[np.clip(ys, 0, sh - 1), np.clip(xs, 0, sw - 1)].astype(np.int64)
+            if not replicate:
+                v = np.where(inside, v, cval)
+            acc += v * wgt * 32
+        return ((acc + (1 << 14)) >> 15).astype(np.uint8)
+
+    src = rng.integers(0, 256, (33, 47), dtype=np.uint8)
+    for M in (np.array([[0.9, 0.3, -4.0], [-0.2, 1.1, 6.5]]), oracle.rotation_matrix_2d((23.5, 16.5), 33.3, 1.2)):
+        Minv = np.linalg.inv(np.vstack([M, [0, 0, 1]]))[:2]
+        for rep in (False, True):
+            got = oracle.warp_affine(src, Minv, (60, 41), inverse_map=True, border="replicate" if rep else "constant", value=99)
+            assert np.array_equal(got, witness(src, Minv, 60, 41, rep, 99))
+        # the forward form inverts the matrix itself; away from rounding ties both give the same picture
+        fw = oracle.warp_affine(src, M, (60, 41), border="replicate")
+        iv = oracle.warp_affine(src, Minv, (60, 41), inverse_map=True, border="replicate")
+        assert np.mean(fw != iv) < 0.02 and np.abs(fw.astype(int) - iv.astype(int)).max() <= 12
