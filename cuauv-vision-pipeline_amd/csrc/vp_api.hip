@@ -444,7 +444,7 @@ int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src, size_t src_stride
 {
     VP_TRY(check_ctx(ctx));
     if (!src || w <= 0 || h <= 0 || h > 65535) return vp_fail(ctx, VP_ERR_INVALID, "vp_cvt_color_u8 arguments");
-    if (code < VP_BGR2LAB || code > VP_HSV2BGR) return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
+    if (code < VP_BGR2LAB || code > VP_BGR2HLS) return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
     const int scn = code == VP_GRAY2BGR ? 1 : 3, dcn = code == VP_BGR2GRAY ? 1 : 3;
     if (src_stride < (size_t)w * scn) return vp_fail(ctx, VP_ERR_INVALID, "src_stride");
     const size_t npx = (size_t)w * h;

@@ -64,6 +64,10 @@ template <>
 struct ModeLds<VP_BGR2HSV> { typedef HsvLds type; };
 template <>
 struct ModeLds<VP_BGR2GRAY> { typedef int type; };
+template <>
+struct ModeLds<VP_BGR2YCRCB> { typedef int type; };
+template <>
+struct ModeLds<VP_BGR2HLS> { typedef int type; };
 
 template <int MODE>
 __device__ __forceinline__ void load_lds(typename ModeLds<MODE>::type& s, const vp_tables& tab)
@@ -237,6 +241,38 @@ int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride,
 
 // ---- standalone conversions (operator API) ----------------------------------------------------
 
+// RGB2YCrCb_i<uchar>: Q14 integers, Y as in BGR2GRAY; stored Y, Cr, Cb
+__device__ __forceinline__ void ycrcb_px(int b, int g, int r, int& c0, int& c1, int& c2)
+{
+    const int Y = (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14;
+    c0 = Y;
+    c1 = min(max(((r - Y) * 11682 + (128 << 14) + (1 << 13)) >> 14, 0), 255);
+    c2 = min(max(((b - Y) * 9241 + (128 << 14) + (1 << 13)) >> 14, 0), 255);
+}
+// RGB2HLS_b: float32 statement sequence of RGB2HLS_f (hrange 180) on src * (1/255); single correctly rounded operations, no contraction
+__device__ __forceinline__ int hls_sat(float v) { return min(max((int)rintf(v), 0), 255); }
+__device__ __forceinline__ void hls_px(int bi, int gi, int ri, int& c0, int& c1, int& c2)
+{
+    const float scale = 1.f / 255.f;
+    const float b = __fmul_rn((float)bi, scale), g = __fmul_rn((float)gi, scale), r = __fmul_rn((float)ri, scale);
+    const float vmax = fmaxf(r, fmaxf(g, b)), vmin = fminf(r, fminf(g, b));
+    float diff = __fsub_rn(vmax, vmin);
+    const float sum = __fadd_rn(vmax, vmin);
+    const float l = __fmul_rn(sum, 0.5f);
+    float hh = 0.f, sat = 0.f;
+    if (diff > 1.1920928955078125e-7f) {
+        sat = l < 0.5f ? __fdiv_rn(diff, sum) : __fdiv_rn(diff, __fsub_rn(__fsub_rn(2.f, vmax), vmin));
+        diff = __fdiv_rn(60.f, diff);
+        if (vmax == r) hh = __fmul_rn(__fsub_rn(g, b), diff);
+        else if (vmax == g) hh = __fadd_rn(__fmul_rn(__fsub_rn(b, r), diff), 120.f);
+        else hh = __fadd_rn(__fmul_rn(__fsub_rn(r, g), diff), 240.f);
+        if (hh < 0.f) hh = __fadd_rn(hh, 360.f);
+    }
+    c0 = hls_sat(__fmul_rn(hh, 0.5f));
+    c1 = hls_sat(__fmul_rn(l, 255.f));
+    c2 = hls_sat(__fmul_rn(sat, 255.f));
+}
+
 template <int CODE>
 __global__ __launch_bounds__(256) void k_cvt_color(const uint8_t* __restrict__ src, size_t stride, int w, int h, vp_tables tab,
                                                    uint8_t* __restrict__ dst, uint8_t* __restrict__ p0,
@@ -257,6 +293,8 @@ __global__ __launch_bounds__(256) void k_cvt_color(const uint8_t* __restrict__ s
     } else {
         int c0 = 0, c1 = 0, c2 = 0;
         if constexpr (CODE == VP_BGR2LAB) lab_px<7>(s, b, g, r, c0, c1, c2);
+        else if constexpr (CODE == VP_BGR2YCRCB) ycrcb_px(b, g, r, c0, c1, c2);
+        else if constexpr (CODE == VP_BGR2HLS) hls_px(b, g, r, c0, c1, c2);
         else hsv_px(s, b, g, r, c0, c1, c2);
         if (dst) { dst[3 * o] = (uint8_t)c0; dst[3 * o + 1] = (uint8_t)c1; dst[3 * o + 2] = (uint8_t)c2; }
         if (p0) p0[o] = (uint8_t)c0;
@@ -287,6 +325,8 @@ int vpk_cvt_color(vp_ctx* ctx, int code, const uint8_t* d_src, size_t stride, in
         case VP_BGR2LAB: hipLaunchKernelGGL((k_cvt_color<VP_BGR2LAB>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
         case VP_BGR2HSV: hipLaunchKernelGGL((k_cvt_color<VP_BGR2HSV>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
         case VP_BGR2GRAY: hipLaunchKernelGGL((k_cvt_color<VP_BGR2GRAY>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2YCRCB: hipLaunchKernelGGL((k_cvt_color<VP_BGR2YCRCB>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2HLS: hipLaunchKernelGGL((k_cvt_color<VP_BGR2HLS>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
         case VP_GRAY2BGR: hipLaunchKernelGGL(k_gray2bgr, grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
         default: return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
     }

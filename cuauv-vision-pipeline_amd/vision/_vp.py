@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvp.so")
 
-BGR2LAB, BGR2HSV, BGR2GRAY, GRAY2BGR, HSV2BGR = 0, 1, 2, 3, 4
+BGR2LAB, BGR2HSV, BGR2GRAY, GRAY2BGR, HSV2BGR, BGR2YCRCB, BGR2HLS = 0, 1, 2, 3, 4, 5, 6
 CB_EQUALIZE_RGB, CB_RGB_CONTRAST, CB_HSV_CONTRAST, CB_HSI_CONTRAST, CB_EXTREMA_CLIPPING, CB_ADAPTIVE_CAST = 1, 2, 4, 8, 16, 32
 CB_DEFAULT = CB_EQUALIZE_RGB | CB_HSV_CONTRAST | CB_EXTREMA_CLIPPING
 MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4

@@ -18,6 +18,7 @@ from vision.utils import feature as _feature
 from vision.utils import transform as _transform
 
 COLOR_BGR2LAB, COLOR_BGR2HSV, COLOR_BGR2GRAY, COLOR_GRAY2BGR, COLOR_HSV2BGR = 44, 40, 6, 8, 54     # cv2's own enum values
+COLOR_BGR2YCrCb, COLOR_BGR2YCR_CB, COLOR_BGR2HLS = 36, 36, 52
 MORPH_RECT, MORPH_CROSS, MORPH_ELLIPSE = 0, 1, 2
 MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
 RETR_EXTERNAL, RETR_LIST = 0, 1
@@ -39,7 +40,8 @@ class error(Exception):
 
 
 _CVT = {COLOR_BGR2LAB: _color.bgr_to_lab, COLOR_BGR2HSV: _color.bgr_to_hsv, COLOR_BGR2GRAY: _color.bgr_to_gray,
-        COLOR_GRAY2BGR: _color.gray_to_bgr, COLOR_HSV2BGR: _color.hsv_to_bgr}
+        COLOR_GRAY2BGR: _color.gray_to_bgr, COLOR_HSV2BGR: _color.hsv_to_bgr, COLOR_BGR2YCrCb: _color.bgr_to_ycrcb,
+        COLOR_BGR2HLS: _color.bgr_to_hls}
 
 
 def cvtColor(src, code):

@@ -65,8 +65,8 @@ bgr_to_lab = _convert_colorspace(_vp.BGR2LAB)
 bgr_to_hsv = _convert_colorspace(_vp.BGR2HSV)
 bgr_to_gray = _convert_colorspace(_vp.BGR2GRAY)
 gray_to_bgr = _convert_colorspace(_vp.GRAY2BGR)
-bgr_to_hls = _unsupported("bgr_to_hls")
-bgr_to_ycrcb = _unsupported("bgr_to_ycrcb")
+bgr_to_hls = _convert_colorspace(_vp.BGR2HLS)
+bgr_to_ycrcb = _convert_colorspace(_vp.BGR2YCRCB)
 bgr_to_luv = _unsupported("bgr_to_luv")
 lab_to_bgr = _unsupported("lab_to_bgr")
 hsv_to_bgr = _convert_colorspace(_vp.HSV2BGR)

@@ -33,7 +33,7 @@ extern "C" {
 typedef struct vp_ctx vp_ctx;
 
 /* colour conversion codes (values are libvp's own, not cv2's) */
-enum { VP_BGR2LAB = 0, VP_BGR2HSV = 1, VP_BGR2GRAY = 2, VP_GRAY2BGR = 3, VP_HSV2BGR = 4 };
+enum { VP_BGR2LAB = 0, VP_BGR2HSV = 1, VP_BGR2GRAY = 2, VP_GRAY2BGR = 3, VP_HSV2BGR = 4, VP_BGR2YCRCB = 5, VP_BGR2HLS = 6 };
 /* morphology ops — utils/transform.py:80-164 */
 enum { VP_MORPH_ERODE = 0, VP_MORPH_DILATE = 1, VP_MORPH_OPEN = 2, VP_MORPH_CLOSE = 3, VP_MORPH_GRADIENT = 4 };
 /* structuring element shapes — cv2.MORPH_RECT / MORPH_CROSS / MORPH_ELLIPSE */
@@ -78,7 +78,8 @@ int vp_get_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* h
 /* ---- per-operator API, host pointers --------------------------------------------------- */
 
 /* utils/color.py:11-32 `_convert_colorspace` (cv2.cvtColor + cv2.split): bgr_to_lab, bgr_to_hsv,
- * bgr_to_gray, gray_to_bgr, plus HSV2BGR (color_balance.cpp:669).  src is (h,w,3) (or (h,w) for GRAY2BGR) with `src_stride` bytes per
+ * bgr_to_gray, gray_to_bgr, bgr_to_ycrcb, bgr_to_hls (modules/preprocessor.py:66-75), plus HSV2BGR (color_balance.cpp:669).
+ * YCrCb is OpenCV's Q14 integer form; HLS is the float32 statement sequence of RGB2HLS_f behind RGB2HLS_b.  src is (h,w,3) (or (h,w) for GRAY2BGR) with `src_stride` bytes per
  * row.  dst_interleaved (tightly packed, may be NULL) receives the converted image; dst_planes[k]
  * (each (h,w) tightly packed, each may be NULL, array may be NULL) receive the split channels. */
 int vp_cvt_color_u8(vp_ctx* ctx, int code, const uint8_t* src_host, size_t src_stride, int w, int h,

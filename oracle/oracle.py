@@ -91,6 +91,14 @@ def bgr2hsv(bgr):
     return _cvt3(lib().orc_bgr2hsv_u8, bgr)
 
 
+def bgr2ycrcb(bgr):
+    return _cvt3(lib().orc_bgr2ycrcb_u8, bgr)
+
+
+def bgr2hls(bgr):
+    return _cvt3(lib().orc_bgr2hls_u8, bgr)
+
+
 def hsv2bgr(hsv, variant=0):
     """cv2.cvtColor(COLOR_HSV2BGR), 8-bit; variant 0 = vector arithmetic form, 1 = scalar form (see vp_oracle_balance.c)."""
     hsv = _c(hsv)

@@ -211,6 +211,63 @@ ORC_API void orc_bgr2gray_u8(const uint8_t* src, size_t sstride, int w, int h, u
     }
 }
 
+/* COLOR_BGR2YCrCb, 8-bit — utils/color.py:26-32 bgr_to_ycrcb, modules/preprocessor.py:71-75.  OpenCV RGB2YCrCb_i<uchar>
+ * (color_yuv.simd.hpp): Q14 integers, Y as in BGR2GRAY, Cr = DESCALE((R - Y) 11682 + 128 2^14, 14), Cb = DESCALE((B - Y) 9241 + ...),
+ * stored Y, Cr, Cb.  Known answers: red -> (76, 255, 85), blue -> (29, 107, 255), greys -> (v, 128, 128). */
+ORC_API void orc_bgr2ycrcb_u8(const uint8_t* src, size_t sstride, int w, int h, uint8_t* dst, size_t dstride)
+{
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++, s += 3, d += 3) {
+            const int b = s[0], g = s[1], r = s[2];
+            const int Y = (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14;
+            const int Cr = ((r - Y) * 11682 + (128 << 14) + (1 << 13)) >> 14;
+            const int Cb = ((b - Y) * 9241 + (128 << 14) + (1 << 13)) >> 14;
+            d[0] = sat_u8(Y); d[1] = sat_u8(Cr); d[2] = sat_u8(Cb);
+        }
+    }
+}
+
+/* COLOR_BGR2HLS, 8-bit — utils/color.py:26-32 bgr_to_hls, modules/preprocessor.py:66-70.  OpenCV RGB2HLS_b (color_hsv.simd.hpp):
+ * the pixel goes to float32 through a multiplication by (1.f/255.f), RGB2HLS_f's scalar statement sequence runs with hrange 180, and
+ * H, L*255, S*255 are stored with round-half-to-even saturation.  Every operation below is a single IEEE float32 operation in the
+ * order of the reference statements (this file is compiled with -ffp-contract=off).  OpenCV's vector form of the same function may
+ * fuse the multiply-add of the hue; that form is not restated. */
+static uint8_t sat_u8_f(float v)
+{
+    const long r = lrintf(v);
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+ORC_API void orc_bgr2hls_u8(const uint8_t* src, size_t sstride, int w, int h, uint8_t* dst, size_t dstride)
+{
+    const float scale = 1.f / 255.f;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* sp = src + (size_t)y * sstride;
+        uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++, sp += 3, d += 3) {
+            const float b = sp[0] * scale, g = sp[1] * scale, r = sp[2] * scale;
+            float hh = 0.f, s = 0.f, l, vmin, vmax, diff;
+            vmax = vmin = r;
+            if (vmax < g) vmax = g;
+            if (vmax < b) vmax = b;
+            if (vmin > g) vmin = g;
+            if (vmin > b) vmin = b;
+            diff = vmax - vmin;
+            l = (vmax + vmin) * 0.5f;
+            if (diff > 1.1920928955078125e-7f) {
+                s = l < 0.5f ? diff / (vmax + vmin) : diff / (2 - vmax - vmin);
+                diff = 60.f / diff;
+                if (vmax == r) hh = (g - b) * diff;
+                else if (vmax == g) hh = (b - r) * diff + 120.f;
+                else hh = (r - g) * diff + 240.f;
+                if (hh < 0.f) hh += 360.f;
+            }
+            d[0] = sat_u8_f(hh * 0.5f); d[1] = sat_u8_f(l * 255.f); d[2] = sat_u8_f(s * 255.f);
+        }
+    }
+}
+
 /* COLOR_GRAY2BGR — modules/bins.py:19: replicate */
 ORC_API void orc_gray2bgr_u8(const uint8_t* src, size_t sstride, int w, int h, uint8_t* dst,
                              size_t dstride)

@@ -33,6 +33,14 @@ known = {
     "gaussian_taps": {"3": [64, 128, 64], "5": [16, 64, 96, 64, 16], "7": [8, 28, 56, 72, 56, 28, 8], "9": [4, 13, 30, 51, 60, 51, 30, 13, 4]},
     # cv2.findContours on a filled 5x4 rectangle at (3,2): top-left, bottom-left, bottom-right, top-right (CHAIN_APPROX_SIMPLE)
     "contour_rect": {"size": [8, 10], "rect": [2, 3, 6, 8], "points": [[3, 2], [3, 5], [7, 5], [7, 2]]},
+    # (B,G,R) -> (Y,Cr,Cb), COLOR_BGR2YCrCb uint8, and -> (H,L,S), COLOR_BGR2HLS uint8 (H in [0,180)): primaries, secondaries, greys
+    "bgr2ycrcb": [[[0, 0, 255], [76, 255, 85]], [[255, 0, 0], [29, 107, 255]], [[0, 255, 0], [150, 21, 43]], [[255, 255, 255], [255, 128, 128]],
+                  [[0, 0, 0], [0, 128, 128]], [[128, 128, 128], [128, 128, 128]]],
+    "bgr2hls": [[[0, 0, 255], [0, 128, 255]], [[0, 255, 0], [60, 128, 255]], [[255, 0, 0], [120, 128, 255]], [[255, 255, 255], [0, 255, 0]],
+                [[0, 0, 0], [0, 0, 0]], [[128, 128, 128], [0, 128, 0]], [[0, 255, 255], [30, 128, 255]], [[255, 255, 0], [90, 128, 255]],
+                [[255, 0, 255], [150, 128, 255]]],
+    # by definition: integer translation by cv2.warpAffine is a shift with the border value elsewhere
+    "warp_translate": {"size": [6, 8], "shift": [3, -2], "border_value": 0},
     # cv2.threshold(THRESH_OTSU) on a two-valued image returns the lower value
     "otsu_two_values": {"values": [10, 200], "threshold": 10},
 }

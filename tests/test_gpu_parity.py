@@ -39,6 +39,10 @@ def test_cvt_color(vp, oracle, h, w):
     assert np.array_equal(gray, oracle.bgr2gray(img)) and np.array_equal(g0, gray)
     back, _ = color.gray_to_bgr(gray)
     assert np.array_equal(back, oracle.gray2bgr(gray))
+    ycc, planes = color.bgr_to_ycrcb(img)
+    assert np.array_equal(ycc, oracle.bgr2ycrcb(img)) and np.array_equal(np.dstack(planes), ycc)
+    hls, planes = color.bgr_to_hls(img)
+    assert np.array_equal(hls, oracle.bgr2hls(img)) and np.array_equal(np.dstack(planes), hls)
 
 
 def test_cvt_color_exhaustive_slices(vp, oracle):
@@ -50,6 +54,19 @@ def test_cvt_color_exhaustive_slices(vp, oracle):
         img = np.dstack([b, g, np.full_like(b, r)])
         assert np.array_equal(color.bgr_to_lab(img)[0], oracle.bgr2lab(img))
         assert np.array_equal(color.bgr_to_hsv(img)[0], oracle.bgr2hsv(img))
+        assert np.array_equal(color.bgr_to_ycrcb(img)[0], oracle.bgr2ycrcb(img))
+        assert np.array_equal(color.bgr_to_hls(img)[0], oracle.bgr2hls(img))
+
+
+def test_cvt_color_all_colours(vp, oracle):
+    """every one of the 2^24 BGR triples, for the conversions whose oracle is fast enough (float32 HLS is the one where a fused or
+    reordered operation on the device would show)"""
+    from vision.utils import color
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.stack([(v & 255), (v >> 8) & 255, v >> 16], axis=1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert np.array_equal(color.bgr_to_hls(img)[0], oracle.bgr2hls(img))
+    assert np.array_equal(color.bgr_to_ycrcb(img)[0], oracle.bgr2ycrcb(img))
+    assert np.array_equal(color.bgr_to_hsv(img)[0], oracle.bgr2hsv(img))
 
 
 def test_cvt_color_strided_view(vp, oracle):

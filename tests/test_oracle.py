@@ -338,3 +338,28 @@ def test_warp_affine_restatement(oracle):
         fw = oracle.warp_affine(src, M, (60, 41), border="replicate")
         iv = oracle.warp_affine(src, Minv, (60, 41), inverse_map=True, border="replicate")
         assert np.mean(fw != iv) < 0.02 and np.abs(fw.astype(int) - iv.astype(int)).max() <= 12
+
+
+def test_ycrcb_hls_known_answers(oracle):
+    """COLOR_BGR2YCrCb / COLOR_BGR2HLS, 8-bit: the published primaries / secondaries / greys; Y equals BGR2GRAY; greys have no chroma
+    and no saturation; HLS lightness is the rounded mean of the extreme channels."""
+    import json
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")))
+    for bgr, exp in G["bgr2ycrcb"]:
+        assert oracle.bgr2ycrcb(np.array([[bgr]], np.uint8))[0, 0].tolist() == exp
+    for bgr, exp in G["bgr2hls"]:
+        assert oracle.bgr2hls(np.array([[bgr]], np.uint8))[0, 0].tolist() == exp
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    ycc, hls = oracle.bgr2ycrcb(img), oracle.bgr2hls(img)
+    assert np.array_equal(ycc[:, :, 0], oracle.bgr2gray(img))
+    mx, mn = img.max(axis=2).astype(np.float64), img.min(axis=2).astype(np.float64)
+    assert np.abs(hls[:, :, 1] - (mx + mn) / 2).max() <= 0.5 + 1e-3
+    assert hls[:, :, 0].max() <= 180     # a hue just under 360 degrees rounds up to 180: the float path has no wrap after rounding
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    assert np.array_equal(oracle.bgr2ycrcb(grey)[0], np.stack([np.arange(256), np.full(256, 128), np.full(256, 128)], 1))
+    assert np.array_equal(oracle.bgr2hls(grey)[0], np.stack([np.zeros(256), np.arange(256), np.zeros(256)], 1))
+    # hue agrees with the integer HSV hue to within the two roundings
+    hsv = oracle.bgr2hsv(img)
+    dh = np.abs(hls[:, :, 0].astype(int) - hsv[:, :, 0].astype(int))
+    assert np.minimum(dh, 180 - dh).max() <= 1
