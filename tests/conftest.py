@@ -24,6 +24,7 @@ def oracle():
 @pytest.fixture(scope="session")
 def vp():
     """libvp binding with a live context; fails loudly (no skip) when the HIP library is absent."""
+    import torch  # noqa: F401  -- before libvp: both must share the HIP runtime torch ships, whichever test file runs first
     from vision import _vp
     _vp.lib()
     _vp.default_context()
