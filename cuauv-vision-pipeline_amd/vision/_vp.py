@@ -111,6 +111,29 @@ _SIGS = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  A process must end up on ONE runtime:
+    with torch imported first libvp binds to torch's copy by soname; the other way round torch would load a second copy next to
+    /opt/rocm's and see no devices.  So when torch is installed but not imported yet, its runtime is loaded first, by path —
+    torch itself is not imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads libvp.so (once).  Raises VpError when the HIP extension has not been built."""
     global _lib
@@ -120,6 +143,7 @@ def lib():
                 if not os.path.exists(LIB_PATH):
                     raise VpError(f"{LIB_PATH} is missing: build it with `python cuauv-vision-pipeline_amd/build.py` "
                                   "(there is no CPU fallback)")
+                _share_hip_runtime_with_torch()
                 l = C.CDLL(LIB_PATH)
                 for name, (res, args) in _SIGS.items():
                     fn = getattr(l, name)

@@ -190,3 +190,19 @@ def test_red_buoy_module_style(vp, oracle, monkeypatch):
     m = oracle.contour_moments(best)
     assert area == m["area"] and (x, y) == (int(m["m10"] / m["m00"]), int(m["m01"] / m["m00"]))
     assert shm.red_buoy_results.area.get() == area
+
+
+def test_torch_after_libvp_in_one_process():
+    """libvp first, PyTorch afterwards: both must end up on one HIP runtime (vision._vp preloads the one torch ships)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = %r\n"
+            "from vision import _vp\n"
+            "ctx = _vp.default_context()\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "t = torch.arange(8, device='cuda')\n"
+            "assert int(t.sum()) == 28\n"
+            "print('ok')\n") % ([os.path.join(root, "cuauv-vision-pipeline_amd"), root],)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
