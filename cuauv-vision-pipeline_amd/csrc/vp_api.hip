@@ -1163,6 +1163,23 @@ int vp_resize_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int dw, 
     return vp_synchronize(ctx);
 }
 
+int vp_canny_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, double t1, double t2, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || h > 65535 || (size_t)w * h > ((size_t)1 << 30) || cn < 1 || cn > 4 || !std::isfinite(t1) || !std::isfinite(t2))
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_canny_u8 arguments");
+    if (t1 > t2) std::swap(t1, t2);
+    const int low = (int)std::floor(std::min(std::max(t1, -1.0), 1e9)), high = (int)std::floor(std::min(std::max(t2, -1.0), 1e9));
+    const size_t npx = (size_t)w * h;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(npx * cn) + vp_align(npx) + vp_canny_ws_bytes(w, h) + 1024));
+    TAKE(d_src, uint8_t*, npx * cn);
+    TAKE(d_dst, uint8_t*, npx);
+    VP_TRY(h2d(ctx, d_src, src, npx * cn));
+    VP_TRY(vpk_canny_u8(ctx, d_src, w, h, cn, low, high, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, npx));
+    return vp_synchronize(ctx);
+}
+
 int vp_warp_affine_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, const double* m23, int flags, int border_mode,
                       const uint8_t* border_value, uint8_t* dst, int dw, int dh)
 {

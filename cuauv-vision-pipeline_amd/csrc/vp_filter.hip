@@ -168,3 +168,134 @@ int vpk_hist_u8(vp_ctx* ctx, const uint8_t* d_src, size_t n, u32* d_hist)
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
+
+// ---- cv2.Canny(image, t1, t2), 3x3 aperture, L1 gradient (utils/feature.py:43-101) -----------------------------------------------
+// canny.cpp in four data-parallel steps: (1) Sobel derivatives with replicated borders, the channel with the largest |dx| + |dy| wins
+// (first on ties); (2) non-maximum suppression with OpenCV's integer direction test (TG22 = 13573 in Q15) against the neighbours'
+// magnitudes, 0 outside the image, giving a bit plane of survivors and one of survivors above the high threshold; (3) hysteresis =
+// 8-connected components of the survivor plane (the labelling kernels of vp_ccl.hip) that hold a pixel of the strong plane — the
+// result of OpenCV's stack flood does not depend on its visiting order; (4) 255 where a survivor's component is marked.
+__global__ __launch_bounds__(256) void k_canny_grad(const uint8_t* __restrict__ src, int w, int h, int cn, uint16_t* __restrict__ mag,
+                                                    short2* __restrict__ grad)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+    const uint8_t* r0 = src + (size_t)ym * w * cn;
+    const uint8_t* r1 = src + (size_t)y * w * cn;
+    const uint8_t* r2 = src + (size_t)yp * w * cn;
+    int bm = -1, bdx = 0, bdy = 0;
+    for (int c = 0; c < cn; c++) {
+        const int a00 = r0[xm * cn + c], a01 = r0[x * cn + c], a02 = r0[xp * cn + c];
+        const int a10 = r1[xm * cn + c], a12 = r1[xp * cn + c];
+        const int a20 = r2[xm * cn + c], a21 = r2[x * cn + c], a22 = r2[xp * cn + c];
+        const int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+        const int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+        const int m = abs(dx) + abs(dy);
+        if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+    }
+    mag[(size_t)y * w + x] = (uint16_t)bm;              // <= 2040
+    grad[(size_t)y * w + x] = make_short2((short)bdx, (short)bdy);
+}
+
+// block = 256 consecutive pixels of a row; a wave's ballot is one 64-pixel word of each plane
+__global__ __launch_bounds__(256) void k_canny_nms(const uint16_t* __restrict__ mag, const short2* __restrict__ grad, int w, int h, int ww, int low,
+                                                   int high, u64* __restrict__ cand, u64* __restrict__ strong)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    bool keep = false, hi = false;
+    if (x < w) {
+        const uint16_t* a = mag + (size_t)y * w + x;
+        const int m = a[0];
+        if (m > low) {
+            const short2 g = grad[(size_t)y * w + x];
+            const int xs = g.x, ys = g.y;
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * 13573;
+            auto at = [&](int dy, int dx) -> int {
+                const int xx = x + dx, yy = y + dy;
+                return (xx >= 0 && xx < w && yy >= 0 && yy < h) ? (int)mag[(size_t)yy * w + xx] : 0;
+            };
+            if (ay < tg22x) keep = m > at(0, -1) && m >= at(0, 1);
+            else if (ay > tg22x + (ax << 16)) keep = m > at(-1, 0) && m >= at(1, 0);
+            else {
+                const int s = (xs ^ ys) < 0 ? -1 : 1;
+                keep = m > at(-1, -s) && m > at(1, s);
+            }
+            hi = keep && m > high;
+        }
+    }
+    const u64 bc = __ballot(keep), bs = __ballot(hi);
+    const int word = x >> 6;
+    if ((threadIdx.x & 63) == 0 && word < ww) {
+        cand[(size_t)y * ww + word] = bc;
+        strong[(size_t)y * ww + word] = bs;
+    }
+}
+
+// one thread per word of the strong plane: marks the components that hold an edge seed
+__global__ __launch_bounds__(256) void k_canny_mark(const u64* __restrict__ strong, const int32_t* __restrict__ labels, int w, int h, int ww,
+                                                    uint8_t* __restrict__ seen)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)h * ww) return;
+    u64 s = strong[i];
+    const int y = (int)(i / ww), j = (int)(i - (size_t)y * ww);
+    while (s) {
+        const int b = __ffsll((long long)s) - 1;
+        s &= s - 1;
+        seen[labels[(size_t)y * w + 64 * j + b]] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_canny_out(const int32_t* __restrict__ labels, const uint8_t* __restrict__ seen, size_t n, uint8_t* __restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int l = labels[i];
+    dst[i] = (l > 0 && seen[l]) ? 255 : 0;
+}
+
+size_t vp_canny_ws_bytes(int w, int h)
+{
+    const size_t npx = (size_t)w * h, bitbytes = (size_t)h * vp_ww(w) * 8;
+    return vp_align(npx * 2) + vp_align(npx * 4) + 2 * vp_align(bitbytes) + vp_align(npx * 4) + vp_align(vp_ccl_nids(w, h) + 2) + vp_align(4) +
+           vp_ccl_ws_bytes(w, h, 1, 1) + 4096;
+}
+
+int vpk_canny_u8(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int cn, int low, int high, uint8_t* d_dst)
+{
+    const size_t npx = (size_t)w * h;
+    const int ww = vp_ww(w);
+    const size_t bitbytes = (size_t)h * ww * 8;
+    uint16_t* d_mag = (uint16_t*)vp_ws_take(ctx, npx * 2);
+    short2* d_grad = (short2*)vp_ws_take(ctx, npx * 4);
+    u64* d_cand = (u64*)vp_ws_take(ctx, bitbytes);
+    u64* d_strong = (u64*)vp_ws_take(ctx, bitbytes);
+    int32_t* d_labels = (int32_t*)vp_ws_take(ctx, npx * 4);
+    const size_t nseen = vp_ccl_nids(w, h) + 2;          // labels are 1 .. number of components <= number of segments
+    uint8_t* d_seen = (uint8_t*)vp_ws_take(ctx, nseen);
+    int32_t* d_nl = (int32_t*)vp_ws_take(ctx, 4);
+    vp_ccl_ws ws;
+    vp_ccl_ws_carve(ctx, w, h, 1, 1, &ws);
+    if (!d_mag || !d_grad || !d_cand || !d_strong || !d_labels || !d_seen || !d_nl || !ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc ||
+        !ws.wordlabel || !ws.bgpart)
+        return vp_fail(ctx, VP_ERR_NOMEM, "canny workspace");
+    hipStream_t s = ctx->stream;
+    const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    {
+        vp_prof_scope ps(ctx, VPK_OTHER);
+        hipLaunchKernelGGL(k_canny_grad, grid, dim3(256), 0, s, d_src, w, h, cn, d_mag, d_grad);
+        hipLaunchKernelGGL(k_canny_nms, grid, dim3(256), 0, s, d_mag, d_grad, w, h, ww, low, high, d_cand, d_strong);
+        VP_HIP(ctx, hipMemsetAsync(d_seen, 0, nseen, s));
+    }
+    const int rc = vpk_ccl(ctx, d_cand, w, h, 1, VP_CCL_PIXEL, ws, d_labels, nullptr, nullptr, 1, d_nl);
+    if (rc != VP_OK) return rc;
+    {
+        vp_prof_scope ps(ctx, VPK_OTHER);
+        hipLaunchKernelGGL(k_canny_mark, dim3((unsigned)(((size_t)h * ww + 255) / 256)), dim3(256), 0, s, d_strong, d_labels, w, h, ww, d_seen);
+        hipLaunchKernelGGL(k_canny_out, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, d_labels, d_seen, npx, d_dst);
+    }
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

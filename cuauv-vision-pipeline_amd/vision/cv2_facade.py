@@ -315,6 +315,24 @@ def resize(src, dsize, interpolation=INTER_LINEAR):
     return out
 
 
+def Canny(image, threshold1, threshold2, apertureSize=3, L2gradient=False):
+    """cv2.Canny on uint8 images with the defaults the reference uses (utils/feature.py:66,101): 3x3 Sobel, L1 gradient magnitude."""
+    from vision import _vp
+    if apertureSize != 3 or L2gradient:
+        raise error("Canny: only apertureSize=3 with the L1 gradient is on the accelerated path")
+    image = np.ascontiguousarray(image)
+    if image.dtype != np.uint8 or image.ndim not in (2, 3) or image.size == 0:
+        raise error("Canny: expected a non-empty uint8 image")
+    cn = 1 if image.ndim == 2 else image.shape[2]
+    if cn > 4:
+        raise error("Canny: at most 4 channels")
+    out = np.empty(image.shape[:2], np.uint8)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_canny_u8(ctx.handle, _vp.ptr(image), image.shape[1], image.shape[0], cn, float(threshold1), float(threshold2),
+                                    _vp.ptr(out)), ctx.handle)
+    return out
+
+
 def drawContours(image, contours, contourIdx, color, thickness=1):
     sel = contours if contourIdx < 0 else [contours[contourIdx]]
     _draw.draw_contours(image, [np.asarray(c) for c in sel], color, thickness)

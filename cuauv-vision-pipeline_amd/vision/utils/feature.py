@@ -114,8 +114,20 @@ def _outside_path(name):
 
 min_enclosing_circle = _outside_path("min_enclosing_circle")
 min_enclosing_ellipse = _outside_path("min_enclosing_ellipse")
-canny = _outside_path("canny")
-simple_canny = _outside_path("simple_canny")
+
+
+def canny(mat: np.ndarray, lower: int, upper: int) -> np.ndarray:
+    """utils/feature.py:43-66 (cv2.Canny with the default 3x3 aperture and L1 gradient) on the GPU (libvp vp_canny_u8)."""
+    from vision import cv2_facade
+    return cv2_facade.Canny(mat, lower, upper)
+
+
+def simple_canny(mat: np.ndarray, sigma: float = 0.33, use_mean: bool = False) -> np.ndarray:
+    """utils/feature.py:69-101: thresholds (1 -/+ sigma) x median (or mean) of the image, truncated to int and clamped to [0, 255]."""
+    mid = np.mean(mat) if use_mean else np.median(mat)
+    lower = int(max(0, (1.0 - sigma) * mid))
+    upper = int(min(255, (1.0 + sigma) * mid))
+    return canny(mat, lower, upper)
 find_corners = _outside_path("find_corners")
 find_circles = _outside_path("find_circles")
 find_lines = _outside_path("find_lines")

@@ -249,6 +249,10 @@ int vp_gaussian_blur_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int 
  * (modules/preprocessor.py:136-144): OpenCV's generic fixed-point path, including the 2x2 box average it substitutes at an
  * exact halving.  (IPP-enabled OpenCV builds may round differently.) */
 int vp_resize_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int cn, int dst_w, int dst_h, uint8_t* dst_host);
+/* cv2.Canny(image, threshold1, threshold2) with the default 3x3 aperture and L1 gradient on 8-bit images, cn = 1..4
+ * (utils/feature.py:43-101 canny / simple_canny): Sobel derivatives, non-maximum suppression with OpenCV's integer direction test,
+ * hysteresis as connected components of the surviving pixels that hold a pixel above the high threshold.  dst: (h, w) 0 / 255. */
+int vp_canny_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int cn, double threshold1, double threshold2, uint8_t* dst_host);
 /* cv2.warpAffine(src, M, (dst_w, dst_h), flags, borderMode, borderValue) with bilinear interpolation on 8-bit images, cn = 1..4
  * (modules/preprocessor.py:130-135 rotate with BORDER_REPLICATE, :145-149 translate; utils/transform.py:180-210).  m23: the 2x3
  * matrix, row-major doubles, mapping source to destination unless VP_WARP_INVERSE_MAP is set.  OpenCV's classical fixed-point path

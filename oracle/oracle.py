@@ -170,6 +170,20 @@ def warp_affine(img, M, dsize, inverse_map=False, border="constant", value=0):
     return out
 
 
+def canny(img, t1, t2):
+    """cv2.Canny(img, t1, t2) with the default 3x3 aperture and L1 gradient, uint8 images with 1..4 channels."""
+    img = _c(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    out = np.empty((h, w), np.uint8)
+    L = lib()
+    L.orc_canny_u8.restype = C.c_int
+    rc = L.orc_canny_u8(_p(img, _u8p), w, h, cn, C.c_double(t1), C.c_double(t2), _p(out, _u8p))
+    if rc != 0:
+        raise ValueError(f"orc_canny_u8: {rc}")
+    return out
+
+
 def bgr2gray(bgr):
     bgr = _c(bgr)
     h, w, _ = bgr.shape

@@ -1,5 +1,5 @@
 /*
- * vp_oracle_warp.c — CPU ORACLE, part 3: cv2.warpAffine with bilinear interpolation on 8-bit images
+ * vp_oracle_warp.c — CPU ORACLE, part 3: cv2.warpAffine with bilinear interpolation on 8-bit images and cv2.Canny (at the end)
  * (modules/preprocessor.py:130-135,145-149; utils/transform.py:180-210 rotate / translate).
  *
  * TEST INFRASTRUCTURE ONLY (same rules as vp_oracle.c): imported by tests/, never by the product.
@@ -21,6 +21,7 @@
  * one grey level on non-integer maps; integer translations are identical in both.
  */
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,4 +107,81 @@ ORC_API void orc_rotation_matrix_2d(double cx, double cy, double angle_deg, doub
     const double alpha = cos(a) * scale, beta = sin(a) * scale;
     M23[0] = alpha; M23[1] = beta; M23[2] = (1 - alpha) * fcx - beta * fcy;
     M23[3] = -beta; M23[4] = alpha; M23[5] = beta * fcx + (1 - alpha) * fcy;
+}
+
+/* ---- cv2.Canny(image, threshold1, threshold2) with the defaults apertureSize = 3, L2gradient = false (utils/feature.py:43-101 canny /
+ * simple_canny) — OpenCV canny.cpp restated sequentially:
+ *   Sobel 3x3 derivatives (16-bit, BORDER_REPLICATE); for several channels the channel with the largest |dx| + |dy| (first on ties);
+ *   thresholds ordered, then floored to int; a pixel with magnitude m > low survives non-maximum suppression when
+ *     |dy| 2^15 < |dx| TG22            : m >  left  and m >= right                (TG22 = round(tan 22.5 deg 2^15) = 13573)
+ *     |dy| 2^15 > |dx| (TG22 + 2^16)   : m >  above and m >= below
+ *     otherwise (diagonal)             : m >  both diagonal neighbours on the line of the gradient (sign of dx ^ dy picks the diagonal)
+ *   with magnitude 0 outside the image; survivors above `high` are edges, the others become edges when 8-connected to an edge through
+ *   survivors (stack flood); output 255 / 0. */
+ORC_API int orc_canny_u8(const uint8_t* src, int w, int h, int cn, double t1, double t2, uint8_t* dst)
+{
+    if (!src || !dst || w <= 0 || h <= 0 || cn < 1 || cn > 4) return -1;
+    if (t1 > t2) { const double t = t1; t1 = t2; t2 = t; }
+    const int low = (int)floor(t1), high = (int)floor(t2);
+    const size_t n = (size_t)w * h;
+    int* mag = (int*)calloc((size_t)(w + 2) * (h + 2), sizeof(int));
+    short* dxs = (short*)malloc(n * sizeof(short));
+    short* dys = (short*)malloc(n * sizeof(short));
+    uint8_t* map = (uint8_t*)malloc((size_t)(w + 2) * (h + 2));
+    size_t* stack = (size_t*)malloc(n * sizeof(size_t));
+    if (!mag || !dxs || !dys || !map || !stack) { free(mag); free(dxs); free(dys); free(map); free(stack); return -2; }
+    const size_t ms = (size_t)w + 2;
+#define PX(yy, xx, c) ((int)src[((size_t)warp_clip((yy), 0, h) * w + warp_clip((xx), 0, w)) * cn + (c)])
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int bm = -1, bdx = 0, bdy = 0;
+            for (int c = 0; c < cn; c++) {
+                const int dx = (PX(y - 1, x + 1, c) + 2 * PX(y, x + 1, c) + PX(y + 1, x + 1, c)) - (PX(y - 1, x - 1, c) + 2 * PX(y, x - 1, c) + PX(y + 1, x - 1, c));
+                const int dy = (PX(y + 1, x - 1, c) + 2 * PX(y + 1, x, c) + PX(y + 1, x + 1, c)) - (PX(y - 1, x - 1, c) + 2 * PX(y - 1, x, c) + PX(y - 1, x + 1, c));
+                const int m = abs(dx) + abs(dy);
+                if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+            }
+            mag[(size_t)(y + 1) * ms + x + 1] = bm;
+            dxs[(size_t)y * w + x] = (short)bdx;
+            dys[(size_t)y * w + x] = (short)bdy;
+        }
+#undef PX
+    memset(map, 1, (size_t)(w + 2) * (h + 2));
+    size_t sp = 0;
+    const int TG22 = 13573;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int* a = mag + (size_t)(y + 1) * ms + x + 1;
+            const int m = a[0];
+            uint8_t* pm = map + (size_t)(y + 1) * ms + x + 1;
+            int keep = 0;
+            if (m > low) {
+                const int xs = dxs[(size_t)y * w + x], ys = dys[(size_t)y * w + x];
+                const int ax = abs(xs), ay = abs(ys) << 15;
+                const int tg22x = ax * TG22;
+                if (ay < tg22x) keep = m > a[-1] && m >= a[1];
+                else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) keep = m > a[-(ptrdiff_t)ms] && m >= a[ms];
+                    else {
+                        const int s = (xs ^ ys) < 0 ? -1 : 1;
+                        keep = m > a[-(ptrdiff_t)ms - s] && m > a[(ptrdiff_t)ms + s];
+                    }
+                }
+            }
+            if (keep) {
+                if (m > high) { *pm = 2; stack[sp++] = (size_t)(pm - map); }
+                else *pm = 0;
+            }
+        }
+    while (sp) {
+        uint8_t* m = map + stack[--sp];
+        const ptrdiff_t nb[8] = {-(ptrdiff_t)ms - 1, -(ptrdiff_t)ms, -(ptrdiff_t)ms + 1, -1, 1, (ptrdiff_t)ms - 1, (ptrdiff_t)ms, (ptrdiff_t)ms + 1};
+        for (int k = 0; k < 8; k++)
+            if (!m[nb[k]]) { m[nb[k]] = 2; stack[sp++] = (size_t)(m + nb[k] - map); }
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) dst[(size_t)y * w + x] = map[(size_t)(y + 1) * ms + x + 1] == 2 ? 255 : 0;
+    free(mag); free(dxs); free(dys); free(map); free(stack);
+    return 0;
 }

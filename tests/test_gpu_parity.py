@@ -670,3 +670,32 @@ def test_warp_affine_argument_checks(vp):
     assert L.vp_warp_affine_u8(ctx.handle, _vp.ptr(img), 4, 4, 1, _vp.ptr(M), 1, 0, None, _vp.ptr(out), 4, 4) != 0     # INTER_* bits are not flags here
     assert L.vp_warp_affine_u8(ctx.handle, _vp.ptr(img), 4, 4, 1, _vp.ptr(M), 0, 4, None, _vp.ptr(out), 4, 4) != 0     # BORDER_REFLECT_101
     assert L.vp_warp_affine_u8(ctx.handle, None, 4, 4, 1, _vp.ptr(M), 0, 0, None, _vp.ptr(out), 4, 4) != 0
+
+
+# ---- Canny (utils/feature.py:43-101) ----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_canny_u8(vp, oracle):
+    from vision.utils import feature
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(31)
+    cases = []
+    for (h, w) in ((1, 1), (1, 40), (37, 1), (2, 2), (63, 65), (120, 257), (200, 320)):
+        for cn in (1, 3):
+            shape = (h, w) if cn == 1 else (h, w, cn)
+            cases.append(rng.integers(0, 256, shape, dtype=np.uint8))                                        # noise: every pixel a candidate
+            sm = ndi.gaussian_filter(rng.normal(0, 1, shape), (2, 2) + ((0,) if cn > 1 else ()))
+            cases.append(np.clip(128 + 700 * sm, 0, 255).astype(np.uint8))                                   # smooth: long edge chains
+    cases.append(F.s1_buoy(3, 640, 360))
+    cases.append(np.ascontiguousarray(F.s1_buoy(4, 640, 360)[:, :, 2]))
+    cases.append(rng.integers(0, 256, (40, 50, 4), dtype=np.uint8))
+    for img in cases:
+        for (t1, t2) in ((50, 150), (450, 150), (0, 0), (10.9, 30.2), (300, 900), (5000, 6000), (0, 2039)):
+            got = feature.canny(img, t1, t2)
+            assert got.shape == img.shape[:2] and np.array_equal(got, oracle.canny(img, t1, t2)), (img.shape, t1, t2)
+    big = F.s1_buoy(0, 1920, 1080)
+    assert np.array_equal(feature.canny(big, 40, 120), oracle.canny(big, 40, 120))
+    g = np.ascontiguousarray(big[:, :, 1])
+    mid = np.median(g)
+    assert np.array_equal(feature.simple_canny(g), oracle.canny(g, int(max(0, 0.67 * mid)), int(min(255, 1.33 * mid))))
+    with pytest.raises(Exception):
+        feature.canny(np.zeros((4, 4), np.float32), 1, 2)

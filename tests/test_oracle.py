@@ -363,3 +363,30 @@ def test_ycrcb_hls_known_answers(oracle):
     hsv = oracle.bgr2hsv(img)
     dh = np.abs(hls[:, :, 0].astype(int) - hsv[:, :, 0].astype(int))
     assert np.minimum(dh, 180 - dh).max() <= 1
+
+
+def test_canny_restatement(oracle):
+    """cv2.Canny (3x3, L1): a vertical step marks the column on the dark side of the step only (m > left, m >= right); a flat image has
+    no edges; thresholds are ordered and floored; and hysteresis equals 'components of the low-threshold survivors that hold a
+    high-threshold survivor' (scipy labelling as the independent witness of the stack flood)."""
+    img = np.zeros((12, 20), np.uint8)
+    img[:, 10:] = 200
+    e = oracle.canny(img, 50, 100)
+    assert e[:, 9].min() == 255 and np.count_nonzero(e) == 12
+    assert np.array_equal(oracle.canny(img.T.copy(), 50, 100), e.T)
+    assert not oracle.canny(np.full((9, 9), 77, np.uint8), 0, 0).any()
+    assert not oracle.canny(img, 801, 900).any() and oracle.canny(img, 799.9, 799.9).any()     # the step's gradient magnitude is 800
+    rng = np.random.default_rng(21)
+    for cn in (1, 3):
+        base = ndi.gaussian_filter(rng.normal(0, 1, (90, 130) + ((cn,) if cn > 1 else ())), (3, 3) + ((0,) if cn > 1 else ()))
+        g = np.clip(128 + 900 * base, 0, 255).astype(np.uint8)
+        lo, hi = 150, 420
+        e = oracle.canny(g, lo, hi)
+        assert np.array_equal(e, oracle.canny(g, hi, lo)) and np.array_equal(e, oracle.canny(g, lo + 0.7, hi + 0.2))
+        weak, strong = oracle.canny(g, lo, lo) > 0, oracle.canny(g, hi, hi) > 0
+        assert (strong <= weak).all() and 0 < strong.sum() < weak.sum()
+        lab, n = ndi.label(weak, structure=np.ones((3, 3)))
+        keep = np.zeros(n + 1, bool)
+        keep[np.unique(lab[strong])] = True
+        keep[0] = False
+        assert np.array_equal(e > 0, keep[lab])
