@@ -1163,6 +1163,28 @@ int vp_resize_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, int dw, 
     return vp_synchronize(ctx);
 }
 
+int vp_adaptive_threshold_mean_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, double max_value, int type, int block, double c, uint8_t* dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!src || !dst || w <= 0 || h <= 0 || h > 65535 || (type != VP_THRESH_BINARY && type != VP_THRESH_BINARY_INV) || !std::isfinite(max_value) ||
+        !std::isfinite(c) || std::fabs(c) > 1e6)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_adaptive_threshold_mean_u8 arguments");
+    if (block < 3 || (block & 1) == 0) return vp_fail(ctx, VP_ERR_INVALID, "adaptive threshold: block size must be odd and > 1");
+    if (block > 151) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "adaptive threshold: block size above 151");
+    const size_t npx = (size_t)w * h;
+    if (max_value < 0) { memset(dst, 0, npx); return VP_OK; }
+    const int imax = (int)std::min(255.0, std::max(0.0, std::nearbyint(max_value)));
+    const int idelta = type == VP_THRESH_BINARY ? (int)std::ceil(c) : (int)std::floor(c);
+    VP_TRY(vp_ws_reserve(ctx, 2 * vp_align(npx) + vp_align(npx * 2) + 1024));
+    TAKE(d_src, uint8_t*, npx);
+    TAKE(d_dst, uint8_t*, npx);
+    TAKE(d_tmp, uint16_t*, npx * 2);
+    VP_TRY(h2d(ctx, d_src, src, npx));
+    VP_TRY(vpk_adaptive_threshold_mean(ctx, d_src, w, h, imax, idelta, type == VP_THRESH_BINARY_INV, block, d_tmp, d_dst));
+    VP_TRY(d2h(ctx, dst, d_dst, npx));
+    return vp_synchronize(ctx);
+}
+
 int vp_canny_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int cn, double t1, double t2, uint8_t* dst)
 {
     VP_TRY(check_ctx(ctx));

@@ -299,3 +299,46 @@ int vpk_canny_u8(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int cn, int lo
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
+
+// ---- cv2.adaptiveThreshold(src, maxValue, ADAPTIVE_THRESH_MEAN_C, type, blockSize, C) (utils/color.py:220-254) ------------------------
+// mean = exact nearest integer of the block sum / blockSize^2 over a window with replicated borders (what all of OpenCV's box-filter
+// roundings give for odd block sizes up to 151), then src - mean > -ceil(C) (BINARY) or src - mean <= -floor(C) (BINARY_INV).
+#define AT_TILE 1024
+__global__ __launch_bounds__(256) void k_box_h(const uint8_t* __restrict__ src, int w, int r, uint16_t* __restrict__ tmp)
+{
+    extern __shared__ uint8_t at_lds[];
+    const int y = blockIdx.y, x0 = blockIdx.x * AT_TILE;
+    const int nx = min(AT_TILE, w - x0);
+    const uint8_t* row = src + (size_t)y * w;
+    for (int i = threadIdx.x; i < nx + 2 * r; i += 256) at_lds[i] = row[min(max(x0 - r + i, 0), w - 1)];
+    __syncthreads();
+    for (int o = threadIdx.x; o < nx; o += 256) {
+        u32 s = 0;
+        for (int k = 0; k <= 2 * r; k++) s += at_lds[o + k];
+        tmp[(size_t)y * w + x0 + o] = (uint16_t)s;
+    }
+}
+__global__ __launch_bounds__(256) void k_box_v_adaptive(const uint8_t* __restrict__ src, const uint16_t* __restrict__ tmp, int w, int h, int r, int imax,
+                                                        int idelta, int inv, uint8_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    u32 s = 0;
+    for (int k = -r; k <= r; k++) s += tmp[(size_t)min(max(y + k, 0), h - 1) * w + x];
+    const u32 d = (u32)(2 * r + 1) * (u32)(2 * r + 1);
+    const int mean = (int)((2ull * s + d) / (2ull * d));
+    const int diff = (int)src[(size_t)y * w + x] - mean;
+    const bool on = inv ? diff <= -idelta : diff > -idelta;
+    dst[(size_t)y * w + x] = (uint8_t)(on ? imax : 0);
+}
+
+// d_tmp: w*h uint16
+int vpk_adaptive_threshold_mean(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int imax, int idelta, int inv, int block, uint16_t* d_tmp, uint8_t* d_dst)
+{
+    const int r = block / 2;
+    vp_prof_scope ps(ctx, VPK_OTHER);
+    hipLaunchKernelGGL(k_box_h, dim3((unsigned)((w + AT_TILE - 1) / AT_TILE), (unsigned)h), dim3(256), (size_t)AT_TILE + 2 * r + 16, ctx->stream, d_src, w, r, d_tmp);
+    hipLaunchKernelGGL(k_box_v_adaptive, dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, ctx->stream, d_src, d_tmp, w, h, r, imax, idelta, inv, d_dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}

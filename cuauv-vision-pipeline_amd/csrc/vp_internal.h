@@ -110,6 +110,7 @@ int vpk_nms(vp_ctx* ctx, const float* d_boxes, const float* d_scores, int n, flo
 // ---- filters (vp_filter.hip) -----------------------------------------------------------------------
 int vpk_threshold_u8(vp_ctx* ctx, const uint8_t* d_src, size_t n, int ithresh, int imaxval, int type, uint8_t* d_dst);
 int vpk_hist_u8(vp_ctx* ctx, const uint8_t* d_src, size_t n, u32* d_hist);   // d_hist: 256 counters
+int vpk_adaptive_threshold_mean(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int imax, int idelta, int inv, int block, uint16_t* d_tmp, uint8_t* d_dst);
 size_t vp_canny_ws_bytes(int w, int h);
 int vpk_canny_u8(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int cn, int low, int high, uint8_t* d_dst);
 void vp_gaussian_taps(int n, double sigma, uint16_t* out);   // n odd, <= 511

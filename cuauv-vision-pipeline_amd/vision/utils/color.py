@@ -243,12 +243,43 @@ def otsu_threshold(mat: np.ndarray):
     _vp.check(_vp.lib().vp_otsu_threshold_u8(ctx.handle, _vp.ptr(mat), mat.size, 255.0, 0, _vp.C.byref(t), _vp.ptr(out)), ctx.handle)
     return t.value, out
 
-adaptive_threshold_mean = _outside_path("adaptive_threshold_mean")
-adaptive_threshold_mean_inv = _outside_path("adaptive_threshold_mean_inv")
+
+
+def _adaptive_mean(mat: np.ndarray, neighborhood_size: int, bias: float, kind: int) -> np.ndarray:
+    mat = np.ascontiguousarray(_u8_image(mat, 1))
+    out = np.empty_like(mat)
+    ctx = _vp.default_context()
+    _vp.check(_vp.lib().vp_adaptive_threshold_mean_u8(ctx.handle, _vp.ptr(mat), mat.shape[1], mat.shape[0], 255.0, kind, int(neighborhood_size),
+                                                      float(bias), _vp.ptr(out)), ctx.handle)
+    return out
+
+
+def adaptive_threshold_mean(mat: np.ndarray, neighborhood_size: int, bias: float = 0) -> np.ndarray:
+    """utils/color.py:220-235 (cv2.adaptiveThreshold, ADAPTIVE_THRESH_MEAN_C, THRESH_BINARY): 255 where the pixel exceeds the mean of
+    its neighbourhood minus the bias."""
+    return _adaptive_mean(mat, neighborhood_size, bias, 0)
+
+
+def adaptive_threshold_mean_inv(mat: np.ndarray, neighborhood_size: int, bias: float = 0) -> np.ndarray:
+    """utils/color.py:238-254 (THRESH_BINARY_INV): 255 where the pixel does not exceed the mean of its neighbourhood minus the bias."""
+    return _adaptive_mean(mat, neighborhood_size, bias, 1)
+
+
 adaptive_threshold_gaussian = _outside_path("adaptive_threshold_gaussian")
 adaptive_threshold_gaussian_inv = _outside_path("adaptive_threshold_gaussian_inv")
 kmeans = _outside_path("kmeans")
-mask_from_labels = _outside_path("mask_from_labels")
+
+
+def mask_from_labels(labels: np.ndarray, centers: np.ndarray) -> List[np.ndarray]:
+    """utils/color.py:326-345: one 0 / 255 mask per centre (plain numpy in the reference as well)."""
+    acc = []
+    for i, _c in enumerate(centers):
+        mask = np.zeros(labels.shape, dtype=np.uint8)
+        mask[labels == i] = 255
+        acc.append(mask)
+    return acc
+
+
 mask_from_labels_target_color = _outside_path("mask_from_labels_target_color")
 white_balance_bgr = _outside_path("white_balance_bgr")
 white_balance_bgr_blur = _outside_path("white_balance_bgr_blur")

@@ -249,6 +249,11 @@ int vp_gaussian_blur_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int 
  * (modules/preprocessor.py:136-144): OpenCV's generic fixed-point path, including the 2x2 box average it substitutes at an
  * exact halving.  (IPP-enabled OpenCV builds may round differently.) */
 int vp_resize_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int cn, int dst_w, int dst_h, uint8_t* dst_host);
+/* cv2.adaptiveThreshold(src, max_value, ADAPTIVE_THRESH_MEAN_C, type, block_size, c) on a single-channel 8-bit image
+ * (utils/color.py:220-254 adaptive_threshold_mean / adaptive_threshold_mean_inv).  type: VP_THRESH_BINARY or VP_THRESH_BINARY_INV;
+ * block_size odd, 3..151 (the range in which OpenCV's three roundings of the box mean provably coincide).  dst may equal src. */
+int vp_adaptive_threshold_mean_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, double max_value, int type, int block_size, double c,
+                                  uint8_t* dst_host);
 /* cv2.Canny(image, threshold1, threshold2) with the default 3x3 aperture and L1 gradient on 8-bit images, cn = 1..4
  * (utils/feature.py:43-101 canny / simple_canny): Sobel derivatives, non-maximum suppression with OpenCV's integer direction test,
  * hysteresis as connected components of the surviving pixels that hold a pixel above the high threshold.  dst: (h, w) 0 / 255. */

@@ -184,6 +184,19 @@ def canny(img, t1, t2):
     return out
 
 
+def adaptive_threshold_mean(img, max_value, inv, block, c):
+    """cv2.adaptiveThreshold(img, max_value, ADAPTIVE_THRESH_MEAN_C, THRESH_BINARY_INV if inv else THRESH_BINARY, block, c)."""
+    img = _c(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    L = lib()
+    L.orc_adaptive_threshold_mean_u8.restype = C.c_int
+    rc = L.orc_adaptive_threshold_mean_u8(_p(img, _u8p), w, h, C.c_double(max_value), int(bool(inv)), int(block), C.c_double(c), _p(out, _u8p))
+    if rc != 0:
+        raise ValueError(f"orc_adaptive_threshold_mean_u8: {rc}")
+    return out
+
+
 def bgr2gray(bgr):
     bgr = _c(bgr)
     h, w, _ = bgr.shape

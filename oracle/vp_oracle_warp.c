@@ -185,3 +185,40 @@ ORC_API int orc_canny_u8(const uint8_t* src, int w, int h, int cn, double t1, do
     free(mag); free(dxs); free(dys); free(map); free(stack);
     return 0;
 }
+
+/* ---- cv2.adaptiveThreshold(src, maxValue, ADAPTIVE_THRESH_MEAN_C, type, blockSize, C) (utils/color.py:220-254 adaptive_threshold_mean /
+ * _inv) — thresh.cpp: mean = boxFilter(src, blockSize x blockSize, normalised, BORDER_REPLICATE) rounded to uint8, then a table over
+ * src - mean + 255: THRESH_BINARY keeps src - mean > -ceil(C), THRESH_BINARY_INV keeps src - mean <= -floor(C).
+ * The rounding of the mean: OpenCV has three code paths (16-bit sums with a Q23 reciprocal for windows of at most 256 pixels,
+ * float32 in the vector body and double in the scalar tail otherwise); for odd block sizes up to 151 all three equal the exact
+ * nearest integer of sum / blockSize^2 (no ties exist for an odd divisor) — checked exhaustively over every possible sum in
+ * tests/test_oracle.py — so the restatement is the exact integer rounding.  type: 0 = THRESH_BINARY, 1 = THRESH_BINARY_INV. */
+ORC_API int orc_adaptive_threshold_mean_u8(const uint8_t* src, int w, int h, double max_value, int type, int block, double C, uint8_t* dst)
+{
+    if (!src || !dst || w <= 0 || h <= 0 || block < 3 || (block & 1) == 0 || (type != 0 && type != 1)) return -1;
+    const size_t n = (size_t)w * h;
+    if (max_value < 0) { memset(dst, 0, n); return 0; }
+    long mv = lrint(max_value);
+    const int imax = (int)(mv < 0 ? 0 : (mv > 255 ? 255 : mv));
+    const int idelta = type == 0 ? (int)ceil(C) : (int)floor(C);
+    const int r = block / 2, d = block * block;
+    uint32_t* hs = (uint32_t*)malloc(n * sizeof(uint32_t));
+    if (!hs) return -2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int k = -r; k <= r; k++) s += src[(size_t)y * w + warp_clip(x + k, 0, w)];
+            hs[(size_t)y * w + x] = s;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int k = -r; k <= r; k++) s += hs[(size_t)warp_clip(y + k, 0, h) * w + x];
+            const int mean = (int)((2 * (uint64_t)s + (uint64_t)d) / (2 * (uint64_t)d));
+            const int diff = (int)src[(size_t)y * w + x] - mean;
+            const int on = type == 0 ? diff > -idelta : diff <= -idelta;
+            dst[(size_t)y * w + x] = (uint8_t)(on ? imax : 0);
+        }
+    free(hs);
+    return 0;
+}

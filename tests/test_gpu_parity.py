@@ -699,3 +699,23 @@ def test_canny_u8(vp, oracle):
     assert np.array_equal(feature.simple_canny(g), oracle.canny(g, int(max(0, 0.67 * mid)), int(min(255, 1.33 * mid))))
     with pytest.raises(Exception):
         feature.canny(np.zeros((4, 4), np.float32), 1, 2)
+
+
+@pytest.mark.gpu
+def test_adaptive_threshold_mean_u8(vp, oracle):
+    from vision.utils import color
+    rng = np.random.default_rng(41)
+    for (h, w) in ((1, 1), (1, 33), (40, 1), (37, 53), (200, 1500), (1080, 1920)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for bs, c in ((3, 0), (5, 2), (15, -3.5), (17, 4.2), (151, 0.5)):
+            if h * w > 500000 and bs > 17:
+                continue
+            assert np.array_equal(color.adaptive_threshold_mean(img, bs, c), oracle.adaptive_threshold_mean(img, 255, False, bs, c)), (h, w, bs, c)
+            assert np.array_equal(color.adaptive_threshold_mean_inv(img, bs, c), oracle.adaptive_threshold_mean(img, 255, True, bs, c)), (h, w, bs, c)
+    img = rng.integers(0, 256, (20, 20), dtype=np.uint8)
+    for bad in (4, 1, 0, -3, 153):
+        with pytest.raises(vp.VpError):
+            color.adaptive_threshold_mean(img, bad)
+    labels = rng.integers(0, 3, (6, 7))
+    masks = color.mask_from_labels(labels, np.zeros((3, 3)))
+    assert len(masks) == 3 and all(np.array_equal(m, np.where(labels == i, 255, 0)) for i, m in enumerate(masks))

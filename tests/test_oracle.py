@@ -390,3 +390,37 @@ def test_canny_restatement(oracle):
         keep[np.unique(lab[strong])] = True
         keep[0] = False
         assert np.array_equal(e > 0, keep[lab])
+
+
+def test_adaptive_threshold_mean_restatement(oracle):
+    """cv2.adaptiveThreshold (mean): OpenCV's three roundings of the box mean — Q23 reciprocal on 16-bit sums (windows up to 256 pixels),
+    float32 product, double product — coincide with the exact nearest integer for every possible sum and every odd block size up to
+    151 (so one arithmetic can be restated); the oracle agrees with a direct numpy evaluation; bias and type behave as documented."""
+    import math
+    for bs in list(range(3, 17, 2)) + [17, 31, 51, 99, 151]:
+        d = bs * bs
+        s = np.arange(0, 255 * d + 1, dtype=np.int64)
+        exact = (2 * s + d) // (2 * d)
+        assert np.array_equal(np.rint(s * (1.0 / d)).astype(np.int64), exact)
+        assert np.array_equal(np.rint((s.astype(np.float32) * np.float32(1.0 / d)).astype(np.float64)).astype(np.int64), exact)
+        if d <= 256:
+            scalef = (1 << 23) / d
+            div_scale, div_delta = math.floor(scalef), d // 2
+            if scalef - div_scale < 0.5:
+                div_delta += 1
+            else:
+                div_scale += 1
+            assert np.array_equal(((s + div_delta) * div_scale) >> 23, exact)
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (31, 45), dtype=np.uint8)
+    for bs, c in ((3, 0), (5, 2), (11, -3.5), (7, 4.2)):
+        r = bs // 2
+        p = np.pad(img.astype(np.int64), r, mode="edge")
+        ssum = sum(p[i:i + 31, j:j + 45] for i in range(bs) for j in range(bs))
+        mean = (2 * ssum + bs * bs) // (2 * bs * bs)
+        diff = img.astype(np.int64) - mean
+        assert np.array_equal(oracle.adaptive_threshold_mean(img, 255, False, bs, c), np.where(diff > -math.ceil(c), 255, 0).astype(np.uint8))
+        assert np.array_equal(oracle.adaptive_threshold_mean(img, 200.4, True, bs, c), np.where(diff <= -math.floor(c), 200, 0).astype(np.uint8))
+    flat = np.full((9, 9), 90, np.uint8)
+    assert not oracle.adaptive_threshold_mean(flat, 255, False, 3, 0).any() and oracle.adaptive_threshold_mean(flat, 255, False, 3, 1).all()
+    assert not oracle.adaptive_threshold_mean(flat, -1, True, 3, 0).any()
