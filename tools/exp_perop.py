@@ -16,6 +16,10 @@ lab, (l, a, b) = t("bgr_to_lab", lambda: color.bgr_to_lab(f))
 th = t("range_threshold", lambda: color.range_threshold(a, 150, 255))
 op = t("morph_remove_noise", lambda: T.morph_remove_noise(th, k))
 cl = t("morph_close_holes", lambda: T.morph_close_holes(op, k))
+t("canny(50, 150)", lambda: feature.canny(f, 50, 150))
+t("adaptive_threshold_mean(15)", lambda: color.adaptive_threshold_mean(a, 15, 2))
+t("rotate(12.5 deg)", lambda: T.rotate(f, 12.5))
+t("bgr_to_hls", lambda: color.bgr_to_hls(f))
 t("connected_components+labels", lambda: feature.connected_components(cl, max_labels=256, want_labels=True))
 t("connected_components stats", lambda: feature.connected_components(cl, max_labels=256, want_labels=False))
 t("outer_contours", lambda: feature.outer_contours(cl))
