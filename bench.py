@@ -187,6 +187,20 @@ def main():
                                                "steps": ksteps, "contours_per_frame": [int(info[:, 0].min()), int(info[:, 0].max())],
                                                "points_per_frame": [int(info[:, 1].min()), int(info[:, 1].max())]}
 
+        # and the chain when the caller asks for the statistics only (no mask images, no label image): what a module that steers by
+        # blob centroids needs; the masks stay bit-packed in HBM
+        b2 = _vp.ChainBuffers()
+        b2.bgr, b2.stats, b2.centroids, b2.nlabels = bufs.bgr, bufs.stats, bufs.centroids, bufs.nlabels
+        ctx.chain_run(desc, b2, B)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(ksteps):
+            ctx.chain_run(desc, b2, B)
+        sync()
+        dt = time.perf_counter() - t0
+        extras["chain_stats_only"] = {"frames_per_s_per_gpu": round(B * ksteps / dt, 1), "ms_per_step": round(1e3 * dt / ksteps, 4), "steps": ksteps,
+                                      "outputs": "stats, centroids, nlabels"}
+
     # HBM-side bytes per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
     # separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py); collected at batch 128
     traffic_tab = {}
