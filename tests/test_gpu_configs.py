@@ -74,3 +74,43 @@ def test_config4_4k_batch_shard(vp, oracle):
         lab = out["labels"][i]
         assert np.array_equal(lab > 0, out["cleaned"][i] > 0) and lab.max() == nl - 1
         assert np.array_equal(np.bincount(lab.ravel(), minlength=nl), out["stats"][i][:nl, 4])
+
+
+def test_one_call_over_more_than_2_pow_32_pixels(vp):
+    """Maximum sizes: 2,100 frames of 1080p in one vp_chain_run (4.35e9 pixels, 12 GiB in, 37 GiB out, ~40 GiB of workspace) — every
+    frame's masks, labels and statistics must equal those of the same frame in a batch of 8 (64-bit indexing throughout).  Needs
+    ~100 GiB of free device memory; skipped on anything smaller than the 288 GB part."""
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    if free < 120 * 2**30:
+        pytest.skip("needs ~100 GiB of free device memory")
+    W, H, B, D = 1920, 1080, 2100, 8
+    ctx = vp.Context(0)
+    try:
+        desc = vp.make_chain_desc(W, H, vp.BGR2LAB, (0, 150, 0), (255, 255, 255), [(vp.MORPH_OPEN, 5, 5), (vp.MORPH_CLOSE, 5, 5)], ccl=1, max_labels=64)
+        small = torch.from_numpy(np.stack([F.s1_buoy(i, W, H) for i in range(D)])).cuda()
+
+        def run(d):
+            n = d.shape[0]
+            t = {"thr": torch.empty((n, H, W), dtype=torch.uint8, device="cuda"), "cln": torch.empty((n, H, W), dtype=torch.uint8, device="cuda"),
+                 "lab": torch.empty((n, H, W), dtype=torch.int32, device="cuda"), "st": torch.zeros((n, 64, 5), dtype=torch.int32, device="cuda"),
+                 "ce": torch.zeros((n, 64, 2), dtype=torch.float64, device="cuda"), "nl": torch.zeros((n,), dtype=torch.int32, device="cuda")}
+            b = vp.ChainBuffers()
+            b.bgr = d.data_ptr()
+            b.threshed, b.cleaned, b.labels, b.stats, b.centroids, b.nlabels = (t[k].data_ptr() for k in ("thr", "cln", "lab", "st", "ce", "nl"))
+            torch.cuda.synchronize()
+            ctx.chain_run(desc, b, n)
+            ctx.synchronize()
+            return t
+
+        ref = run(small)
+        big = small.repeat((B + D - 1) // D, 1, 1, 1)[:B].contiguous()
+        out = run(big)
+        reps = (B + D - 1) // D
+        for k in ref:
+            exp = ref[k].repeat((reps,) + (1,) * (ref[k].dim() - 1))[:B]
+            assert torch.equal(out[k], exp), k
+            del exp
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
