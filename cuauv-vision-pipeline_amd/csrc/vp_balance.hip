@@ -19,7 +19,7 @@
 #include "vp_internal.h"
 
 #define CB_MAX_TILES 1024
-#define CB_COPIES 16
+#define CB_COPIES 8
 
 struct cb_params {
     int w, h, n;
