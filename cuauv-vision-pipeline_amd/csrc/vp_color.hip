@@ -199,8 +199,8 @@ static int launch_thresh(vp_ctx* ctx, const uint8_t* d_bgr, size_t stride, int w
     if (flat) {
         const size_t ngroups = (size_t)n * h * w / 16;
         size_t blocks = (ngroups + 255) / 256;
-        static const int bpc = getenv("VP_COLOR_BPC") ? atoi(getenv("VP_COLOR_BPC")) : 32;
-        const size_t cap = (size_t)ctx->num_cu * (bpc > 0 ? bpc : 32);
+        static const int bpc = getenv("VP_COLOR_BPC") ? atoi(getenv("VP_COLOR_BPC")) : 64;
+        const size_t cap = (size_t)ctx->num_cu * (bpc > 0 ? bpc : 64);
         if (blocks > cap) blocks = cap;
         dim3 grid((unsigned)blocks);
         if (d_mask && d_bits)
