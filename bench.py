@@ -48,6 +48,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the chain + contours side measurement")
     ap.add_argument("--max-labels", type=int, default=256)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of exactly --steps steps each (every one bracketed by barrier + synchronize, MAX over ranks); "
+                         "`value` comes from the median region (SURVEY 8d: median of 5)")
+    ap.add_argument("--traffic-file", default=os.path.join("profiles", "r02", "traffic.json"),
+                    help="rocprofv3 --pmc summary (tools/pmc_traffic.py) to take roofline.traffic from; used only when its recorded "
+                         "source digest equals the running build and it holds the exact kernel instantiation that was timed")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run the N-rank code path with every rank on cuda:0 and a gloo group (a one-GPU box cannot host "
                          "an RCCL group); the printed value is then not a scaling number")
@@ -151,7 +157,9 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-    elapsed = timed_steps(lambda: ctx.chain_run(desc, bufs, B), sync, args.steps, dist, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+    region_s = [timed_steps(lambda: ctx.chain_run(desc, bufs, B), sync, args.steps, dist, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+                for _ in range(max(1, args.regions))]
+    elapsed = sorted(region_s)[len(region_s) // 2]          # median region (every region is exactly K steps)
 
     # ---- per-kernel attribution with HIP events on the launch stream (same K steps again) ----------
     ctx.profile_begin(args.steps * 16)
@@ -201,17 +209,63 @@ def main():
         extras["chain_stats_only"] = {"frames_per_s_per_gpu": round(B * ksteps / dt, 1), "ms_per_step": round(1e3 * dt / ksteps, 4), "steps": ksteps,
                                       "outputs": "stats, centroids, nlabels"}
 
-    # HBM-side bytes per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
-    # separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py); collected at batch 128
-    traffic_tab = {}
-    if args.batch == 128:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*traffic.json")))
-        if cands:
-            try:
-                traffic_tab = json.load(open(cands[-1]))
-            except Exception:
-                traffic_tab = {}
+        # the other frame families of SURVEY 8d through the same entry point (not `value`): S2 = the bins chain
+        # (modules/bins.py:13-27: BGR2HSV, inRange on three channels, OPEN 5x5, labelling) and S3 = uniform noise, once through the
+        # bench chain and once straight into the labelling (grey >= 128, no morphology: about half the pixels set, tens of thousands
+        # of components per frame, max_labels sized for them)
+        def side_run(tag, gen, mode, lo, hi, mops, ml, what):
+            nb = min(B, 32)
+            fr = [gen(rank * 1000 + i, W, H) for i in range(4)]
+            d_in = torch.from_numpy(np.stack([fr[i % 4] for i in range(nb)])).cuda()
+            st = torch.zeros((nb, ml, 5), dtype=torch.int32, device="cuda")
+            ce = torch.zeros((nb, ml, 2), dtype=torch.float64, device="cuda")
+            nl = torch.zeros((nb,), dtype=torch.int32, device="cuda")
+            dsc = _vp.make_chain_desc(W, H, mode, lo, hi, mops, ccl=1, numbering=_vp.CCL_BLOCK2X2, max_labels=ml)
+            bb = _vp.ChainBuffers()
+            bb.bgr, bb.threshed, bb.cleaned, bb.labels = d_in.data_ptr(), d_thr.data_ptr(), d_cln.data_ptr(), d_lab.data_ptr()
+            bb.stats, bb.centroids, bb.nlabels = st.data_ptr(), ce.data_ptr(), nl.data_ptr()
+            ctx.chain_run(dsc, bb, nb)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(ksteps):
+                ctx.chain_run(dsc, bb, nb)
+            sync()
+            dt = time.perf_counter() - t0
+            nls = nl.cpu().numpy()
+            extras[tag] = {"frames_per_s_per_gpu": round(nb * ksteps / dt, 1), "ms_per_step": round(1e3 * dt / ksteps, 4), "steps": ksteps,
+                           "frames_per_step": nb, "workload": what, "max_labels": ml, "labels_per_frame_seen": [int(nls.min()), int(nls.max())]}
+        side_run("s2_bins_chain", F.s2_bins, _vp.BGR2HSV, (10, 20, 60), (30, 100, 255), [(_vp.MORPH_OPEN, 5, 5)], args.max_labels,
+                 "S2 1080p: BGR->HSV inRange[10,20,60]-[30,100,255] -> OPEN 5x5 -> CCL + stats, all outputs")
+        side_run("s3_noise_chain", F.s3_noise, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), morph, args.max_labels,
+                 "S3 1080p uniform noise through the bench chain (the OPEN removes nearly every pixel)")
+        side_run("s3_noise_labelling", F.s3_noise, _vp.BGR2GRAY, (128, 0, 0), (255, 255, 255), [], 131072,
+                 "S3 1080p uniform noise: grey >= 128 -> CCL + stats with no morphology (worst-case component count)")
+
+    # HBM-side bytes per launch (rocprofv3 PMC passes of THIS command with --no-extras --no-cpu-baseline: FETCH_SIZE and WRITE_SIZE in
+    # separate runs, corrected as MI355X_MICROARCH.md prescribes, tools/pmc_traffic.py).  The file is named on the command line and is
+    # used only if (a) it was collected from the very kernel sources this build was made from and (b) it holds exactly one
+    # instantiation of the kernel that was timed - otherwise the field is null rather than a number of unknown provenance.
+    traffic_tab, traffic_src = {}, None
+    tpath = args.traffic_file if os.path.isabs(args.traffic_file) else os.path.join(ROOT, args.traffic_file)
+    if args.batch == 128 and os.path.exists(tpath):
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("vp_build", os.path.join(ROOT, "cuauv-vision-pipeline_amd", "build.py"))
+            vb = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(vb)
+            tab = json.load(open(tpath))
+            if tab.get("_meta", {}).get("csrc_sha256") == vb.source_digest():
+                traffic_tab, traffic_src = tab, os.path.relpath(tpath, ROOT)
+            else:
+                traffic_src = os.path.relpath(tpath, ROOT) + " (stale: collected from other kernel sources, ignored)"
+        except Exception as e:   # evidence file unreadable: report no traffic
+            traffic_src = f"{args.traffic_file}: {e}"
+
+    def traffic_of(prof_name):
+        # profile names are the kernels' base names; the file is keyed by full instantiation
+        base = {"k_color_thresh": "k_color_thresh_flat", "k_morph_bits": "k_morph_bits"}.get(prof_name, prof_name)
+        hits = [k for k in traffic_tab if k != "_meta" and (k == base or k.startswith(base + "<") or k.startswith(base + "_"))]
+        return (hits[0], traffic_tab[hits[0]]["traffic_bytes_per_launch"]) if len(hits) == 1 else (None, None)
 
     roof = None
     kernels = {}
@@ -222,12 +276,18 @@ def main():
         avg_s = 1e-3 * prof[dom][0] / prof[dom][1]
         kb = KERNEL_BYTES_PER_PX[dom] * W * H * B
         achieved = kb / avg_s / 1e9
+        inst, traffic = traffic_of(dom)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": next((v["traffic_bytes_per_launch"] for k, v in traffic_tab.items() if k.startswith(dom)), None),
-                "bytes_per_launch": int(kb), "avg_launch_us": round(1e6 * avg_s, 2),
+                "traffic": traffic, "traffic_kernel": inst, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": int(kb), "avg_launch_us": round(1e6 * avg_s, 2),
                 "chain_achieved_GBps": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9, 1),
                 "chain_frac": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS, 4)}
+        for k in kernels:
+            inst_k, t_k = traffic_of(k)
+            if t_k is not None:
+                kernels[k]["measured_traffic_bytes_per_launch"] = t_k
+                kernels[k]["instantiation"] = inst_k
 
     cpu = None
     real_cv2 = None
@@ -291,6 +351,7 @@ def main():
         out = {
             "metric": "frames/sec for color->threshold->morph->CCL at 1080p",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "regions": len(region_s), "region_ms_per_step": [round(1e3 * r / args.steps, 4) for r in region_s], "value_from": "median region",
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: preprocessor+red_buoy fused chain, S1 synthetic 1080p frames resident in HBM: "

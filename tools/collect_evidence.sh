@@ -1,9 +1,9 @@
 #!/bin/bash
-# Run on the GPU box from the repo root:  tools/collect_evidence.sh <tag>     (e.g. r01/d)
+# Run on the GPU box from the repo root:  tools/collect_evidence.sh <tag>     (e.g. r02/a)
 # Produces gpurun_out/evidence/<tag>_{bench.json,kernel_stats.csv,traffic.json}; copy them into profiles/ afterwards.
 # rocprofv3 passes are separate, as MI355X_MICROARCH.md prescribes: one --kernel-trace --stats pass, one --pmc pass per counter.
 set -e
-tag=${1:-r01/x}
+tag=${1:-r02/x}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/evidence
 mkdir -p $out/$(dirname $tag)
@@ -12,10 +12,12 @@ python3 bench.py --steps 30 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_b
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks -o ks -- python3 $root/bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# counter passes see the timed chain only (--no-extras: no second instantiation of any kernel, no contour code reusing the labelling kernels)
+pmc_cmd="bench.py --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-extras"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 $root/$pmc_cmd > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 $root/$pmc_cmd > /dev/null 2>&1
 cd $root
-python3 tools/pmc_traffic.py $(find $out/pf -name '*counter_collection.csv' | head -1) $(find $out/pw -name '*counter_collection.csv' | head -1) $out/${tag}_traffic.json > /dev/null
+python3 tools/pmc_traffic.py $(find $out/pf -name '*counter_collection.csv' | head -1) $(find $out/pw -name '*counter_collection.csv' | head -1) $out/${tag}_traffic.json rocprofv3 --pmc "FETCH_SIZE|WRITE_SIZE" -- python3 $pmc_cmd > /dev/null
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kb -o kb -- python3 $root/tools/exp_balance.py > $out/${tag}_balance.txt 2>&1
 cp $(find $out/kb -name '*kernel_stats.csv' | head -1) $out/${tag}_balance_kernel_stats.csv
