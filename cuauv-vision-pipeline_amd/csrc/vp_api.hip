@@ -68,6 +68,12 @@ vp_ctx* vp_create(int device)
         hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
     }
     hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (hipStreamCreateWithFlags(&ctx->fb_stream, hipStreamNonBlocking) != hipSuccess) { vp_fail(nullptr, VP_ERR_HIP, "side stream"); delete ctx; return nullptr; }
+    hipEventCreateWithFlags(&ctx->ev_fb_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_fb_join, hipEventDisableTiming);
+    ctx->ccl_levels = 2;
+    ctx->ccl_mcap = -1;
+    if (const char* env = getenv("VP_CCL_LEVELS")) { const int v = atoi(env); if (v == 1 || v == 2) ctx->ccl_levels = v; }
     // tables: gamma u16[256] | cbrt u16[2048] | sdiv i32[256] | hdiv i32[256]
     std::vector<uint16_t> gamma(256), cbrt(3072);
     std::vector<int32_t> sdiv(256), hdiv(256);
@@ -102,6 +108,9 @@ int vp_destroy(vp_ctx* ctx)
     hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 4; i++) { hipStreamDestroy(ctx->aux[i]); hipEventDestroy(ctx->ev_join[i]); }
     hipEventDestroy(ctx->ev_fork);
+    hipStreamDestroy(ctx->fb_stream);
+    hipEventDestroy(ctx->ev_fb_fork);
+    hipEventDestroy(ctx->ev_fb_join);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VP_OK;
@@ -119,6 +128,8 @@ int vp_set_option(vp_ctx* ctx, int option, int value)
 {
     if (!ctx) return VP_ERR_INVALID;
     if (option == VP_OPT_CHAIN_STREAMS && value >= 1 && value <= 4) { ctx->chain_streams = value; return VP_OK; }
+    if (option == VP_OPT_CCL_LEVELS && (value == 1 || value == 2)) { ctx->ccl_levels = value; return VP_OK; }
+    if (option == VP_OPT_CCL_MERGE_CAP && value >= -1) { ctx->ccl_mcap = value; return VP_OK; }
     return vp_fail(ctx, VP_ERR_INVALID, "vp_set_option");
 }
 
@@ -182,7 +193,8 @@ int vp_profile_end(vp_ctx* ctx, double* total_ms, int32_t* launches)
 const char* vp_profile_kernel_name(int id)
 {
     static const char* names[VP_PROF_KERNELS] = {"k_color_thresh", "k_morph_bits", "k_ccl_local", "k_ccl_boundary", "k_ccl_flatten", "k_ccl_rank",
-                                                  "k_ccl_bg", "k_ccl_stats", "k_ccl_final", "k_ccl_write", "memset", "other"};
+                                                  "k_ccl_bg", "k_ccl_stats", "k_ccl_final", "k_ccl_write", "memset", "other",
+                                                  "k_ccl2_local", "k_ccl2_merge", "k_ccl2_write"};
     return (id >= 0 && id < VP_PROF_KERNELS) ? names[id] : "?";
 }
 
@@ -722,7 +734,7 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, 
     TAKE(d_nl, int32_t*, 4);
     vp_ccl_ws ws;
     vp_ccl_ws_carve(ctx, w, h, 1, max_labels, &ws);
-    if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+    if (!vp_ccl_ws_ok(ws)) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
     VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
     VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
     VP_TRY(vpk_ccl(ctx, d_bits, w, h, 1, numbering, ws, labels ? d_labels : nullptr, d_stats, d_cent, max_labels, d_nl));
@@ -870,7 +882,7 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
     memset(&ws, 0, sizeof ws);
     if (d->ccl) {
         vp_ccl_ws_carve(ctx, w, h, n, d->max_labels, &ws);
-        if (!ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc || !ws.wordlabel || !ws.bgpart) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
+        if (!vp_ccl_ws_ok(ws)) return vp_fail(ctx, VP_ERR_NOMEM, "ccl workspace");
     }
     if ((!st.empty() && (need_clean_bits || b->cleaned)) || (st.empty() && b->cleaned)) {
         if (st.empty()) {

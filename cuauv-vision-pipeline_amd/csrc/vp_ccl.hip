@@ -33,7 +33,10 @@
 #include "vp_internal.h"
 #include "vp_ccl_dev.h"
 #include <limits.h>
+#include <string.h>
 #include <cstdlib>
+#include <algorithm>
+#include <vector>
 
 struct ccl_acc {   // 48 B
     u32 area;
@@ -46,6 +49,8 @@ struct contrib { u32 area; int minx, maxx, miny, maxy; u32 pad; u64 sx, sy; };
 
 #define RK_PARTS 8
 #define BG_PARTS 8
+#define C2_RC 128              // two-level labelling (vp_ccl2.inl): stride of the per-strip component tables
+struct c2_box { int minx, maxx, miny, maxy; };
 
 size_t vp_ccl_nids(int w, int h)
 {
@@ -53,11 +58,17 @@ size_t vp_ccl_nids(int w, int h)
     return (2 * hb * wb + 127) / 128 * 128;
 }
 
+// strips of the strip-local pass never exceed h / 8 + 1 (ccl_make_geom picks 8, 16 or 32 rows)
+static size_t c2_strips_max(int h) { return (size_t)(h + 7) / 8; }
+
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
 {
     const size_t nids = vp_ccl_nids(w, h);
+    const size_t ns = c2_strips_max(h) * (size_t)n;
     return vp_align(nids * 4 * n) * 2 + vp_align(nids / 8 * n) * 2 + vp_align(sizeof(ccl_acc) * (size_t)max_labels * n) +
-           vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) + 2048;
+           vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) +
+           vp_align(ns * 4) + vp_align(ns * C2_RC * sizeof(contrib)) + vp_align(ns * sizeof(c2_box)) + vp_align(ns * C2_RC * 4) +
+           vp_align((size_t)n * 4) + 4096;
 }
 
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out)
@@ -70,6 +81,18 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->acc = vp_ws_take(ctx, sizeof(ccl_acc) * (size_t)max_labels * n);
     out->wordlabel = (u32*)vp_ws_take(ctx, (size_t)n * h * vp_ww(w) * 4);
     out->bgpart = vp_ws_take(ctx, sizeof(contrib) * BG_PARTS * (size_t)n);
+    const size_t ns = c2_strips_max(h) * (size_t)n;
+    out->c2_ncomp = (u32*)vp_ws_take(ctx, ns * 4);
+    out->c2_recs = vp_ws_take(ctx, ns * C2_RC * sizeof(contrib));
+    out->c2_bgbox = vp_ws_take(ctx, ns * sizeof(c2_box));
+    out->c2_label = (u32*)vp_ws_take(ctx, ns * C2_RC * 4);
+    out->c2_crowded = (u32*)vp_ws_take(ctx, (size_t)n * 4);
+}
+
+bool vp_ccl_ws_ok(const vp_ccl_ws& ws)
+{
+    return ws.parent && ws.seglabel && ws.flags && ws.prefix && ws.acc && ws.wordlabel && ws.bgpart && ws.c2_ncomp && ws.c2_recs &&
+           ws.c2_bgbox && ws.c2_label && ws.c2_crowded;
 }
 
 // ---- whole-image global-memory path (fallback for images too wide for the LDS strip kernel) ---------------
@@ -107,13 +130,14 @@ __global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, 
 // One block per (frame, strip of CL_ROWS rows).
 // dynamic LDS: lbits[nw] u64 | wbase[nw + 2] u32 | lparent[cap] | lgid[cap] | lmin[cap] (cap <= nw + 2: lmin reuses wbase)
 __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
-                                                   u32* __restrict__ flags, int strips, int cap)
+                                                   u32* __restrict__ flags, int strips, int cap, const u32* __restrict__ only)
 {
     extern __shared__ __attribute__((aligned(16))) u64 cl_lds[];
     __shared__ u32 wsum[4];
     __shared__ u32 total_s;
     const int ww = G.ww;
     const int frame = blockIdx.x / strips, strip = blockIdx.x - frame * strips;
+    if (only && !only[frame]) return;   // fallback launch of the two-level path: this frame was resolved there
     const int y0 = strip * G.rows;
     const int nrows = min(G.rows, G.h - y0);
     const int nwmax = G.rows * ww;
@@ -128,8 +152,10 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
 }
 
 // vertical unions across strip boundaries: grid (strips - 1, n), block = 64 threads over the words of the row
-__global__ __launch_bounds__(64) void k_ccl_boundary(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent, u32* __restrict__ flags)
+__global__ __launch_bounds__(64) void k_ccl_boundary(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent, u32* __restrict__ flags,
+                                                     const u32* __restrict__ only)
 {
+    if (only && !only[blockIdx.y]) return;
     const int y = (blockIdx.x + 1) * G.rows;
     const u64* fb = bits + (size_t)blockIdx.y * G.h * G.ww;
     u32* p = parent + (size_t)blockIdx.y * G.nids;
@@ -180,8 +206,9 @@ __device__ __forceinline__ void wave_combine(contrib& c)
 // blocks [RK_PARTS, RK_PARTS + BG_PARTS): background pixels of a slice of the frame reduced to one record.
 __global__ __launch_bounds__(256) void k_ccl_rank(ccl_geom G, const u32* __restrict__ flags, u32* __restrict__ prefix,
                                                   int32_t* __restrict__ nlabels, ccl_acc* __restrict__ acc, int max_labels,
-                                                  const u64* __restrict__ bits, contrib* __restrict__ bgpart)
+                                                  const u64* __restrict__ bits, contrib* __restrict__ bgpart, const u32* __restrict__ only)
 {
+    if (only && !only[blockIdx.y]) return;
     __shared__ u32 wsum[4];
     __shared__ u32 wsum2[4];
     __shared__ u32 bcast;
@@ -317,8 +344,9 @@ struct st_table {
 __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent,
                                                    const u32* __restrict__ flags, const u32* __restrict__ prefix,
                                                    u32* __restrict__ seglabel, u32* __restrict__ wordlabel,
-                                                   ccl_acc* __restrict__ acc, int max_labels)
+                                                   ccl_acc* __restrict__ acc, int max_labels, const u32* __restrict__ only)
 {
+    if (only && !only[blockIdx.y]) return;
     __shared__ st_table T;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < G.h * G.ww;
@@ -436,8 +464,9 @@ __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits,
 // grid: (ceil(max_labels/256), n)
 __global__ __launch_bounds__(256) void k_ccl_final(const ccl_acc* __restrict__ acc, const contrib* __restrict__ bgpart,
                                                    const int32_t* __restrict__ nlabels, int max_labels, int32_t* __restrict__ stats,
-                                                   double* __restrict__ cent)
+                                                   double* __restrict__ cent, const u32* __restrict__ only)
 {
+    if (only && !only[blockIdx.y]) return;
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= max_labels) return;
     const int f = blockIdx.y;
@@ -567,30 +596,57 @@ static void ccl_make_geom(ccl_geom& G, int w, int h, int numbering, int invert, 
     if (const char* e = getenv("VP_CL_ROWS")) { const int r = atoi(e); if ((r == 8 || r == 16 || r == 32) && ((u32)r * (u32)G.wb) % 32u == 0) G.rows = r; }
 }
 
-// union-find phase only: parent[] (every segment points at a smaller id of its component, roots at themselves)
-// and the exact root bitmap in flags[]
-static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags)
+#include "vp_ccl2.inl"
+
+// LDS of the strip-local kernels: lbits | wbase | lparent | lgid (| lmin when it cannot share wbase's words)
+static size_t ccl_local_lds(const ccl_geom& G, size_t& cap)
 {
-    const int h = G.h;
-    const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
-    hipStream_t s = ctx->stream;
-    const int strips = (h + G.rows - 1) / G.rows;
     const size_t nwmax = (size_t)G.rows * G.ww;
     // Foreground: room for one segment per word of the strip (a full mask) + 2, the size of the wbase array whose LDS lmin then
     // reuses; denser strips (speckle) take the global fallback.  Background pass of the contour code: every empty word is a
     // segment and every foreground edge adds one, so it gets its own lmin array and 1024 more entries.
     static const char* cap_env = getenv("VP_CL_CAP");
-    size_t cap = G.invert ? nwmax + 1024 : nwmax + 2;
+    cap = G.invert ? nwmax + 1024 : nwmax + 2;
     if (cap_env && (size_t)atoi(cap_env) >= 64 && (size_t)atoi(cap_env) < cap) cap = (size_t)atoi(cap_env);
     size_t lds_local = nwmax * 8 + (nwmax + 2) * 4 + (cap <= nwmax + 2 ? 2 : 3) * cap * 4;
     if (lds_local > 64 * 1024 && G.invert) { cap = nwmax + 2; lds_local = nwmax * 8 + (nwmax + 2) * 4 + 2 * cap * 4; }
+    return lds_local;
+}
+
+// union-find phase only: parent[] (every segment points at a smaller id of its component, roots at themselves)
+// and the exact root bitmap in flags[]; `only` (nullable): per-frame switch, frames whose entry is 0 are left alone
+static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags, const u32* only = nullptr)
+{
+    const int h = G.h;
+    const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
+    hipStream_t s = ctx->stream;
+    const int strips = (h + G.rows - 1) / G.rows;
+    size_t cap;
+    const size_t lds_local = ccl_local_lds(G, cap);
     if (lds_local <= 64 * 1024) {
-        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips, (int)cap); }
-        if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags); }
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips, (int)cap, only); }
+        if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags, only); }
     } else {
         { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)G.nw32 * 4 * n, s)); }
         { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_init, wgrid, dim3(256), 0, s, d_bits, G, parent, flags); }
         { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_link, wgrid, dim3(256), 0, s, d_bits, G, parent, flags); }
+    }
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
+// the one-level kernels after the union-find: ranks, per-label statistics, stats rows; on ctx->stream
+static int ccl_one_level_tail(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, const vp_ccl_ws& ws, int32_t* d_stats,
+                              double* d_centroids, int max_labels, int32_t* d_nlabels, const u32* only)
+{
+    const dim3 wgrid((unsigned)((G.h * G.ww + 255) / 256), (unsigned)n);
+    hipStream_t s = ctx->stream;
+    { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart, only); }
+    { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels, only); }
+    if (d_stats || d_centroids) {
+        vp_prof_scope ps(ctx, VPK_CCL_FINAL);
+        hipLaunchKernelGGL(k_ccl_final, dim3((unsigned)((max_labels + 255) / 256), (unsigned)n), dim3(256), 0, s, (const ccl_acc*)ws.acc,
+                           (const contrib*)ws.bgpart, d_nlabels, max_labels, d_stats, d_centroids, only);
     }
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
@@ -603,27 +659,75 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
     if (max_labels < 1) return vp_fail(ctx, VP_ERR_INVALID, "max_labels");
     ccl_geom G;
     ccl_make_geom(G, w, h, numbering, 0, 0);
-    const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
     hipStream_t s = ctx->stream;
-    int rc = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags);
-    if (rc != VP_OK) return rc;
-    { vp_prof_scope ps(ctx, VPK_CCL_RANK); hipLaunchKernelGGL(k_ccl_rank, dim3(RK_PARTS + BG_PARTS, (unsigned)n), dim3(256), 0, s, G, ws.flags, ws.prefix, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_bits, (contrib*)ws.bgpart); }
-    { vp_prof_scope ps(ctx, VPK_CCL_STATS); hipLaunchKernelGGL(k_ccl_stats, wgrid, dim3(256), 0, s, d_bits, G, ws.parent, ws.flags, ws.prefix, ws.seglabel, ws.wordlabel, (ccl_acc*)ws.acc, max_labels); }
-    if (d_stats || d_centroids) {
-        vp_prof_scope ps(ctx, VPK_CCL_FINAL);
-        hipLaunchKernelGGL(k_ccl_final, dim3((unsigned)((max_labels + 255) / 256), (unsigned)n), dim3(256), 0, s, (const ccl_acc*)ws.acc,
-                           (const contrib*)ws.bgpart, d_nlabels, max_labels, d_stats, d_centroids);
+    const int strips = (h + G.rows - 1) / G.rows;
+    const u32 gpr = (u32)((w + 3) / 4);
+    const u32 magic = (u32)((0x100000000ull + gpr - 1) / gpr);
+
+    // ---- two-level path (vp_ccl2.inl) ----------------------------------------------------------------------------------
+    const size_t nwmax = (size_t)G.rows * G.ww;
+    const size_t cap2 = nwmax + 2;
+    const size_t rc = 96;   // components per strip with LDS accumulators (44 B each): 19.6 KB per block at 1080p, eight blocks per CU
+    const size_t lds2 = nwmax * 8 + (nwmax + 2) * 4 + cap2 * 4 + rc * 44;
+    const bool two_level = ctx->ccl_levels == 2 && lds2 <= 64 * 1024 && strips <= C2_MAXSTRIPS && (G.rows % WR_ROWS) == 0 &&
+                           (size_t)strips <= c2_strips_max(h);
+    if (two_level) {
+        const int mcap = (ctx->ccl_mcap >= 0 && ctx->ccl_mcap < C2_MCAP) ? ctx->ccl_mcap : C2_MCAP;
+        { vp_prof_scope ps(ctx, VPK_CCL2_LOCAL);
+          hipLaunchKernelGGL(k_ccl2_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds2, s, d_bits, G, strips, (int)cap2, (int)rc, ws.c2_ncomp,
+                             (contrib*)ws.c2_recs, (c2_box*)ws.c2_bgbox, ws.wordlabel, ws.seglabel); }
+        { vp_prof_scope ps(ctx, VPK_CCL2_MERGE);
+          hipLaunchKernelGGL(k_ccl2_merge, dim3((unsigned)n), dim3(C2_THREADS), 0, s, d_bits, G, strips, mcap, ws.c2_ncomp, (const contrib*)ws.c2_recs,
+                             (const c2_box*)ws.c2_bgbox, ws.wordlabel, ws.seglabel, ws.c2_label, ws.c2_crowded, d_nlabels, d_stats, d_centroids, max_labels); }
+        VP_HIP(ctx, hipGetLastError());
+        // Crowded frames: the one-level kernels.  They are launched whatever the frames hold (the flags live on the device) and leave
+        // at once for frames the merge resolved: five launches of about 2.5 us each.  (On a side stream beside the label write they
+        // cost more, not less: their blocks compete with the write's for dispatch - 647 against 638 us per step of 128 frames.)
+        int rc2 = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags, ws.c2_crowded);
+        if (rc2 == VP_OK) rc2 = ccl_one_level_tail(ctx, d_bits, G, n, ws, d_stats, d_centroids, max_labels, d_nlabels, ws.c2_crowded);
+        if (rc2 != VP_OK) return rc2;
+        if (d_labels) {
+            vp_prof_scope ps(ctx, VPK_CCL2_WRITE);
+            const dim3 wr_grid((unsigned)((h + WR_ROWS - 1) / WR_ROWS), (unsigned)n);
+            hipLaunchKernelGGL(k_ccl2_write, wr_grid, dim3(256), 0, s, d_bits, G, strips, (int)rc, ws.seglabel, ws.wordlabel, ws.c2_label, ws.c2_crowded, d_labels, gpr, magic);
+        }
+        VP_HIP(ctx, hipGetLastError());
+        return VP_OK;
     }
+
+    // ---- one-level path -------------------------------------------------------------------------------------------------
+    int rc1 = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags);
+    if (rc1 != VP_OK) return rc1;
+    rc1 = ccl_one_level_tail(ctx, d_bits, G, n, ws, d_stats, d_centroids, max_labels, d_nlabels, nullptr);
+    if (rc1 != VP_OK) return rc1;
     if (d_labels) {
         vp_prof_scope ps(ctx, VPK_CCL_WRITE);
         const u32 total_rows = (u32)((size_t)n * h);
-        const u32 gpr = (u32)((w + 3) / 4);
-        const u32 magic = (u32)((0x100000000ull + gpr - 1) / gpr);
         hipLaunchKernelGGL(k_ccl_write, dim3((total_rows + WR_ROWS - 1) / WR_ROWS), dim3(256), 0, s, d_bits, G, ws.seglabel, ws.wordlabel, d_labels,
                            total_rows, gpr, magic);
     }
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
+
+#ifdef VP_PROBE
+// measurement builds: per probe point, the ticks summed over the blocks that reached point 15 (ran to the end) in out[k*16 + i],
+// their number in out[k*16 + 15]; slots are cleared afterwards
+extern "C" int vp_debug_probe(double* out32)
+{
+    static std::vector<unsigned int> h((size_t)2 * C2_PROBE_BLOCKS * 16);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_c2_probe), h.size() * 4) != hipSuccess) return -1;
+    for (int i = 0; i < 32; i++) out32[i] = 0;
+    for (int k = 0; k < 2; k++)
+        for (int b = 0; b < C2_PROBE_BLOCKS; b++) {
+            const unsigned int* r = &h[((size_t)k * C2_PROBE_BLOCKS + b) * 16];
+            if (r[15] == 0xffffffffu || r[14] != 0x600dc0deu) continue;
+            for (int i = 0; i < 14; i++) out32[k * 16 + i] += r[i];
+            out32[k * 16 + 15] += 1;
+        }
+    std::fill(h.begin(), h.end(), 0u);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_c2_probe), h.data(), h.size() * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #include "vp_contours.inl"

@@ -127,6 +127,16 @@ __device__ __forceinline__ u32 lds_find(volatile u32* p, u32 x)
         x = g;
     }
 }
+// read-only walk to the root: safe beside other walkers and beside threads that overwrite their OWN entry with its root
+// (a path-halving find is not: its delayed `p[x] = grandparent` can land after x's owner stored the root there)
+__device__ __forceinline__ u32 lds_root(const volatile u32* p, u32 x)
+{
+    for (;;) {
+        const u32 q = p[x];
+        if (q == x) return x;
+        x = q;
+    }
+}
 __device__ __forceinline__ void lds_unite(u32* p, u32 a, u32 b)
 {
     for (;;) {
@@ -145,28 +155,21 @@ __device__ __forceinline__ void lds_unite(u32* p, u32 a, u32 b)
     for (int r = threadIdx.x >> 5; r < nrows; r += 8)           \
         for (int j = threadIdx.x & 31, i = r * ww + j; j < ww; j += 32, i += 32)
 
-// Strip-local labelling of CL_ROWS (or fewer) rows whose (possibly inverted) bit words are already staged in LDS as
-// lbits[nrows][ww]; called by all 256 threads of a block.  Resolves the strip's components entirely in LDS and writes
-// parent[id] = smallest id of the segment's strip-local component (init + link in one pass); clears the strip's slice
-// of the root bitmap and marks the strip-local representatives.  wbase needs nrows*ww + 2 words, lparent / lgid / lmin
-// `cap` words each, wsum 4 words and total_s 1 word of LDS.  fb = the frame's bit image in global memory (only the
-// dense-strip fallback reads it, for rows of this strip).  lmin may alias wbase when cap <= nrows*ww + 2.
-__device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lbits, u32* wbase, u32* lparent, u32* lgid, u32* lmin,
-                                                u32* wsum, u32* total_s, int y0, int nrows, int strip, int strips,
-                                                const u64* __restrict__ fb, u32* __restrict__ gp, u32* __restrict__ gf, u32 cap = CL_CAP)
+// Strip-local union-find over the word segments of CL_ROWS (or fewer) rows whose (possibly inverted) bit words are already
+// staged in LDS as lbits[nrows][ww]; called by all 256 threads of a block.  Returns S, the number of segments of the strip
+// (block-uniform).  For 0 < S <= cap it leaves in LDS: wbase[word] = local index of the word's first segment (indices follow
+// the words in row-major order, segments of a word by position), lgid[ci] = segment id (when WANT_GID), lparent[] = a forest whose trees are the
+// strip's components (links point at smaller indices); *my_first = local index of the first segment of the calling thread's
+// first word in CL_FOR_WORDS order (its segments are numbered consecutively in that order).  The last unions may still be in
+// flight: callers synchronise before reading lparent.  wbase needs nrows*ww + 2 words, lparent / lgid `cap` words each, wsum 4
+// words and total_s 1 word of LDS.
+struct cl_noprobe { __device__ __forceinline__ void operator()(int) const {} };
+template <bool WANT_GID = true, typename PROBE = cl_noprobe>
+__device__ __forceinline__ u32 ccl_local_unions(const ccl_geom& G, const u64* lbits, u32* wbase, u32* lparent, u32* lgid,
+                                                u32* wsum, u32* total_s, int y0, int nrows, u32 cap, u32* my_first, PROBE probe = PROBE())
 {
     const int ww = G.ww;
     const int tid = threadIdx.x;
-    // this strip's slice of the root bitmap (ids of G.rows rows = a multiple of 32 ids, so slices never share a word:
-    // 32 rows always are, 16 rows when ceil(w/2) is even - ccl_make_geom only picks 16 then)
-    {
-        const u32 rows_ids = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;   // ids per row pair / per row
-        const u32 lo = (G.numbering == VP_CCL_BLOCK2X2) ? (u32)(y0 >> 1) * rows_ids : (u32)y0 * rows_ids;
-        const u32 w0 = lo >> 5;
-        const u32 w1 = (strip == strips - 1) ? G.nw32 : ((G.numbering == VP_CCL_BLOCK2X2) ? ((u32)((y0 + G.rows) >> 1) * rows_ids) >> 5
-                                                                                         : ((u32)(y0 + G.rows) * rows_ids) >> 5);
-        for (u32 i = w0 + tid; i < w1; i += 256) gf[i] = 0u;
-    }
     u32 cnt = 0;
     CL_FOR_WORDS(r, j, i) cnt += nstarts(lbits[i]);
     // block exclusive scan of the per-thread segment counts
@@ -179,27 +182,9 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
     if (tid == 0) { u32 run = 0; for (int k = 0; k < 4; k++) { const u32 t = wsum[k]; wsum[k] = run; run += t; } *total_s = run; }
     __syncthreads();
     const u32 S = *total_s;
-    if (S == 0) return;
-    if (S > cap) {
-        // dense strip: same algorithm in global memory, restricted to this strip's rows
-        CL_FOR_WORDS(r, j, i) {
-            u64 st = lbits[i] & ~(lbits[i] << 1);
-            while (st) {
-                const int s = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                const u32 id = seg_id(G, y0 + r, 64 * j + s);
-                st_rlx(gp + id, id);
-                atomicOr(gf + (id >> 5), 1u << (id & 31));
-            }
-        }
-        __threadfence();
-        __syncthreads();
-        CL_FOR_WORDS(r, j, i) {
-            const u64 w = lbits[i];
-            if (w) global_link_word(fb, G, gp, gf, y0 + r, j, (y0 + r) * ww + j, w, true, r > 0);
-        }
-        return;
-    }
+    *my_first = wsum[wv] + inc - cnt;
+    if (S == 0 || S > cap) return S;
+    probe(1);
     {
         // Segments get their local index here, and the segments of one row that continue across word boundaries get their run's
         // first segment as parent straight away: a scan over the 32 words a half-wave holds (a word of all ones passes the
@@ -221,7 +206,7 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
                     const int s = __ffsll((long long)st) - 1;
                     st &= st - 1;
                     lparent[run] = run;
-                    lgid[run] = seg_id(G, y0 + r, 64 * j + s);
+                    if (WANT_GID) lgid[run] = seg_id(G, y0 + r, 64 * j + s);
                     run++;
                 }
                 // f_j(x) = (pass && x != NONE) ? x : val  -  leader of the run that leaves word j through bit 63, given the one entering
@@ -245,6 +230,7 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
         }
     }
     __syncthreads();
+    probe(2);
     CL_FOR_WORDS(r, j, i) {
         const u64 w = lbits[i];
         if (!w) continue;
@@ -277,6 +263,53 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
             if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) lds_unite(lparent, me, wbase[i - ww + 1]);
             me++;
         }
+    }
+    return S;
+}
+
+// Strip-local labelling for the one-level path: resolves the strip's components entirely in LDS and writes
+// parent[id] = smallest id of the segment's strip-local component (init + link in one pass); clears the strip's slice
+// of the root bitmap and marks the strip-local representatives.  LDS as for ccl_local_unions plus lmin (`cap` words; may alias
+// wbase when cap <= nrows*ww + 2).  fb = the frame's bit image in global memory (only the dense-strip fallback reads it, for
+// rows of this strip).
+__device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lbits, u32* wbase, u32* lparent, u32* lgid, u32* lmin,
+                                                u32* wsum, u32* total_s, int y0, int nrows, int strip, int strips,
+                                                const u64* __restrict__ fb, u32* __restrict__ gp, u32* __restrict__ gf, u32 cap = CL_CAP)
+{
+    const int ww = G.ww;
+    const int tid = threadIdx.x;
+    // this strip's slice of the root bitmap (ids of G.rows rows = a multiple of 32 ids, so slices never share a word:
+    // 32 rows always are, 16 rows when ceil(w/2) is even - ccl_make_geom only picks 16 then)
+    {
+        const u32 rows_ids = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;   // ids per row pair / per row
+        const u32 lo = (G.numbering == VP_CCL_BLOCK2X2) ? (u32)(y0 >> 1) * rows_ids : (u32)y0 * rows_ids;
+        const u32 w0 = lo >> 5;
+        const u32 w1 = (strip == strips - 1) ? G.nw32 : ((G.numbering == VP_CCL_BLOCK2X2) ? ((u32)((y0 + G.rows) >> 1) * rows_ids) >> 5
+                                                                                         : ((u32)(y0 + G.rows) * rows_ids) >> 5);
+        for (u32 i = w0 + tid; i < w1; i += 256) gf[i] = 0u;
+    }
+    u32 my_first;
+    const u32 S = ccl_local_unions(G, lbits, wbase, lparent, lgid, wsum, total_s, y0, nrows, cap, &my_first);
+    if (S == 0) return;
+    if (S > cap) {
+        // dense strip: same algorithm in global memory, restricted to this strip's rows
+        CL_FOR_WORDS(r, j, i) {
+            u64 st = lbits[i] & ~(lbits[i] << 1);
+            while (st) {
+                const int s = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                const u32 id = seg_id(G, y0 + r, 64 * j + s);
+                st_rlx(gp + id, id);
+                atomicOr(gf + (id >> 5), 1u << (id & 31));
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        CL_FOR_WORDS(r, j, i) {
+            const u64 w = lbits[i];
+            if (w) global_link_word(fb, G, gp, gf, y0 + r, j, (y0 + r) * ww + j, w, true, r > 0);
+        }
+        return;
     }
     __syncthreads();
     // lmin may share its LDS with wbase, which the unions above were the last to read

@@ -278,8 +278,7 @@ int vpk_canny_u8(vp_ctx* ctx, const uint8_t* d_src, int w, int h, int cn, int lo
     int32_t* d_nl = (int32_t*)vp_ws_take(ctx, 4);
     vp_ccl_ws ws;
     vp_ccl_ws_carve(ctx, w, h, 1, 1, &ws);
-    if (!d_mag || !d_grad || !d_cand || !d_strong || !d_labels || !d_seen || !d_nl || !ws.parent || !ws.seglabel || !ws.flags || !ws.prefix || !ws.acc ||
-        !ws.wordlabel || !ws.bgpart)
+    if (!d_mag || !d_grad || !d_cand || !d_strong || !d_labels || !d_seen || !d_nl || !vp_ccl_ws_ok(ws))
         return vp_fail(ctx, VP_ERR_NOMEM, "canny workspace");
     hipStream_t s = ctx->stream;
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);

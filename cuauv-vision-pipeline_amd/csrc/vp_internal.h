@@ -16,7 +16,7 @@ struct vp_tables {          // device copies of the OpenCV integer tables
 };
 
 enum { VPK_COLOR = 0, VPK_MORPH, VPK_CCL_LOCAL, VPK_CCL_BOUNDARY, VPK_CCL_FLATTEN, VPK_CCL_RANK, VPK_CCL_BG, VPK_CCL_STATS,
-       VPK_CCL_FINAL, VPK_CCL_WRITE, VPK_MEMSET, VPK_OTHER };
+       VPK_CCL_FINAL, VPK_CCL_WRITE, VPK_MEMSET, VPK_OTHER, VPK_CCL2_LOCAL, VPK_CCL2_MERGE, VPK_CCL2_WRITE, VPK_COUNT };
 
 struct vp_prof {
     bool on;
@@ -41,6 +41,10 @@ struct vp_ctx {
     int chain_streams;            // sub-batches of a chain run on this many internal streams (>= 1)
     hipStream_t aux[4];
     hipEvent_t ev_fork, ev_join[4];
+    hipStream_t fb_stream;        // side stream of the labelling: the one-level kernels for crowded frames run here, beside the label write
+    hipEvent_t ev_fb_fork, ev_fb_join;
+    int ccl_levels;               // 2: two-level labelling with the one-level kernels as fallback (default); 1: one-level only
+    int ccl_mcap;                 // components per frame the merge block accepts (-1: its LDS capacity); tests lower it to force the fallback
     vp_prof prof;
     char err[256];
 };
@@ -146,7 +150,14 @@ struct vp_ccl_ws {           // per-batch scratch, all device pointers
     void* acc;               // [n][max_labels] accumulators
     u32* wordlabel;          // [n][h*ww]      label of the first segment of each word
     void* bgpart;            // [n][8]         background partial records
+    // two-level path (vp_ccl2.inl); wordlabel / seglabel double as its per-word / per-segment component indices
+    u32* c2_ncomp;           // [n][strips]            components per strip (0xffffffff: strip not resolved in LDS)
+    void* c2_recs;           // [n][strips][C2_RC]     component records (statistics + numbering key)
+    void* c2_bgbox;          // [n][strips]            bounding box of the strip's zero pixels
+    u32* c2_label;           // [n][strips][C2_RC]     (strip, component) -> label
+    u32* c2_crowded;         // [n]                    1: frame left to the one-level kernels
 };
+bool vp_ccl_ws_ok(const vp_ccl_ws& ws);
 size_t vp_ccl_nids(int w, int h);   // multiple of 32
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels);
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out);

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvp.so")
+LIB_PATH = os.environ.get("VP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvp.so")   # VP_LIB: measurement builds (tools/build_probe.sh)
 
 BGR2LAB, BGR2HSV, BGR2GRAY, GRAY2BGR, HSV2BGR, BGR2YCRCB, BGR2HLS = 0, 1, 2, 3, 4, 5, 6
 CB_EQUALIZE_RGB, CB_RGB_CONTRAST, CB_HSV_CONTRAST, CB_HSI_CONTRAST, CB_EXTREMA_CLIPPING, CB_ADAPTIVE_CAST = 1, 2, 4, 8, 16, 32
@@ -23,7 +23,9 @@ RETR_EXTERNAL, RETR_LIST = 0, 1
 CHAIN_APPROX_NONE, CHAIN_APPROX_SIMPLE = 1, 2
 CHAIN_MAX_MORPH = 8
 OPT_CHAIN_STREAMS = 1
-PROF_KERNELS = 12
+OPT_CCL_LEVELS = 2
+OPT_CCL_MERGE_CAP = 3
+PROF_KERNELS = 15
 
 
 class VpError(RuntimeError):

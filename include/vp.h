@@ -58,8 +58,12 @@ void* vp_get_stream(vp_ctx* ctx);
 int vp_synchronize(vp_ctx* ctx);
 /* Options.  VP_OPT_CHAIN_STREAMS (1..4, default 1): vp_chain_run splits a batch into that many sub-batches
  * on internal streams (fork/join around the context's stream); results are identical for every value.
- * Measured on MI355X: no gain over 1 (the kernels of the two halves slow each other down), hence the default. */
-enum { VP_OPT_CHAIN_STREAMS = 1 };
+ * Measured on MI355X: no gain over 1 (the kernels of the two halves slow each other down), hence the default.
+ * VP_OPT_CCL_LEVELS (1 or 2, default 2): 2 = strip-local components merged by one block per frame, frames that do not fit
+ * finished by the one-level kernels; 1 = one-level kernels only.  Results are identical.
+ * VP_OPT_CCL_MERGE_CAP (-1 = capacity of the merge block, or a smaller count): strip components per frame above which a frame
+ * is handed to the one-level kernels (test hook: 0 sends every non-empty frame there). */
+enum { VP_OPT_CHAIN_STREAMS = 1, VP_OPT_CCL_LEVELS = 2, VP_OPT_CCL_MERGE_CAP = 3 };
 int vp_set_option(vp_ctx* ctx, int option, int value);
 /* HIP-event stopwatch on the context's stream (bench.py: roofline.achieved). */
 int vp_timer_start(vp_ctx* ctx);
@@ -67,7 +71,7 @@ int vp_timer_stop(vp_ctx* ctx, float* elapsed_ms); /* records, synchronises, ret
 /* Per-kernel attribution: between vp_profile_begin and vp_profile_end every kernel the context
  * launches is bracketed by HIP events on its stream.  vp_profile_end synchronises and fills
  * total_ms[id] / launches[id] for id < VP_PROF_KERNELS (names: vp_profile_kernel_name). */
-#define VP_PROF_KERNELS 12
+#define VP_PROF_KERNELS 15
 int vp_profile_begin(vp_ctx* ctx, int max_records);
 int vp_profile_end(vp_ctx* ctx, double* total_ms, int32_t* launches);
 const char* vp_profile_kernel_name(int id);
