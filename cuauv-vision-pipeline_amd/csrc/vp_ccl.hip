@@ -667,14 +667,17 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
     // ---- two-level path (vp_ccl2.inl) ----------------------------------------------------------------------------------
     const size_t nwmax = (size_t)G.rows * G.ww;
     const size_t cap2 = nwmax + 2;
-    const size_t rc = 96;   // components per strip with LDS accumulators (44 B each): 19.6 KB per block at 1080p, eight blocks per CU
-    const size_t lds2 = nwmax * 8 + (nwmax + 2) * 4 + cap2 * 4 + rc * 44;
-    const bool two_level = ctx->ccl_levels == 2 && lds2 <= 64 * 1024 && strips <= C2_MAXSTRIPS && (G.rows % WR_ROWS) == 0 &&
-                           (size_t)strips <= c2_strips_max(h);
+    const size_t rc = 96;   // components per strip with LDS accumulators (44 B each)
+    size_t tail_words = std::max(rc * 11, cap2);    // union queue, then root -> list place (cap words), then the accumulators
+    tail_words += tail_words & 1;
+    const size_t list_words = nwmax + (nwmax + 1) / 2 + ((nwmax + (nwmax + 1) / 2) & 1);   // wbase + word list, padded to 8 bytes
+    const size_t lds2 = nwmax * 8 + (list_words + cap2 + tail_words) * 4;                   // 1080p: 21.8 KB, seven blocks per CU
+    const bool two_level = ctx->ccl_levels == 2 && lds2 <= 64 * 1024 && G.ww <= 64 && G.rows <= CL_ROWS && strips <= C2_MAXSTRIPS &&
+                           (G.rows % WR_ROWS) == 0 && (G.rows % 8) == 0 && (size_t)strips <= c2_strips_max(h);
     if (two_level) {
         const int mcap = (ctx->ccl_mcap >= 0 && ctx->ccl_mcap < C2_MCAP) ? ctx->ccl_mcap : C2_MCAP;
         { vp_prof_scope ps(ctx, VPK_CCL2_LOCAL);
-          hipLaunchKernelGGL(k_ccl2_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds2, s, d_bits, G, strips, (int)cap2, (int)rc, ws.c2_ncomp,
+          hipLaunchKernelGGL(k_ccl2_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds2, s, d_bits, G, strips, (int)cap2, (int)rc, (int)tail_words, ws.c2_ncomp,
                              (contrib*)ws.c2_recs, (c2_box*)ws.c2_bgbox, ws.wordlabel, ws.seglabel); }
         { vp_prof_scope ps(ctx, VPK_CCL2_MERGE);
           hipLaunchKernelGGL(k_ccl2_merge, dim3((unsigned)n), dim3(C2_THREADS), 0, s, d_bits, G, strips, mcap, ws.c2_ncomp, (const contrib*)ws.c2_recs,
@@ -689,7 +692,9 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
         if (d_labels) {
             vp_prof_scope ps(ctx, VPK_CCL2_WRITE);
             const dim3 wr_grid((unsigned)((h + WR_ROWS - 1) / WR_ROWS), (unsigned)n);
-            hipLaunchKernelGGL(k_ccl2_write, wr_grid, dim3(256), 0, s, d_bits, G, strips, (int)rc, ws.seglabel, ws.wordlabel, ws.c2_label, ws.c2_crowded, d_labels, gpr, magic);
+            static const int wv = getenv("VP_WR_VARIANT") ? atoi(getenv("VP_WR_VARIANT")) : 0;
+            if (wv == 3) hipLaunchKernelGGL(k_ccl2_write<3>, wr_grid, dim3(256), 0, s, d_bits, G, strips, (int)rc, ws.seglabel, ws.wordlabel, ws.c2_label, ws.c2_crowded, d_labels, gpr, magic);
+            else hipLaunchKernelGGL(k_ccl2_write<0>, wr_grid, dim3(256), 0, s, d_bits, G, strips, (int)rc, ws.seglabel, ws.wordlabel, ws.c2_label, ws.c2_crowded, d_labels, gpr, magic);
         }
         VP_HIP(ctx, hipGetLastError());
         return VP_OK;

@@ -33,28 +33,41 @@ __device__ unsigned int g_c2_probe[2][C2_PROBE_BLOCKS][16];
 #define C2_THREADS 1024
 #define C2_PER (C2_MCAP / C2_THREADS)
 
-// grid: n * strips blocks of 256 threads.
-// dynamic LDS: lbits[nw] u64 | wbase[nw + 2] u32 (later: list index of each root) | lparent[cap] | accumulators of rc components (44 B each)
-__global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits, ccl_geom G, int strips, int cap, int rc,
+// grid: n * strips blocks of 256 threads; frames up to 64 words wide (row masks are 64-bit).
+//
+// Built for masks that are mostly background with a few blobs:
+//   * three 64-bit masks per row (word non-zero / all ones / bit 63 set), made by ballots while the strip is staged, answer the
+//     questions about neighbouring words that would otherwise be LDS reads and scans: "does this word's first segment continue a
+//     run from the left, and where does that run start" is a few bit operations;
+//   * everything after staging walks the list of NON-ZERO words only, so lanes are busy on sparse masks;
+//   * vertical links are not union-find unions: a contact between a segment and a segment of the row above is one
+//     atomicMin(parent[leader of my run], leader of the run above) - leaders of a row above always have smaller indices, so the
+//     parent pointers form a forest by construction.  Only when a run touches two DIFFERENT runs above (the returned old value tells)
+//     does a real union remain; those go to a small queue and are united afterwards (compare-and-swap union-find).
+// dynamic LDS: lbits[nw] u64 | wbase[nw] u32 | nzlist[nw] u16 (+pad) | lparent[cap] | tail: union queue, then root -> list index, then
+// accumulators of rc components (44 B each)
+__global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits, ccl_geom G, int strips, int cap, int rc, int tail_words,
                                                     u32* __restrict__ ncomp, contrib* __restrict__ recs, c2_box* __restrict__ bgbox,
                                                     u32* __restrict__ wordcomp, u32* __restrict__ segcomp)
 {
     extern __shared__ __attribute__((aligned(16))) u64 cl_lds[];
+    __shared__ u64 m_nz[CL_ROWS], m_ones[CL_ROWS], m_b63[CL_ROWS];
+    __shared__ u32 rowoff[CL_ROWS + 1];
     __shared__ u32 wsum[4];
-    __shared__ u32 total_s;
     __shared__ c2_box bgp[4];
-    __shared__ u32 nroots_s;
+    __shared__ u32 nroots_s, nqueue_s;
     const int ww = G.ww;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = tid & 31;
     const int frame = blockIdx.x / strips, strip = blockIdx.x - frame * strips;
     const int y0 = strip * G.rows;
     const int nrows = min(G.rows, G.h - y0);
     const int nwmax = G.rows * ww;
     u64* lbits = cl_lds;
     u32* wbase = reinterpret_cast<u32*>(cl_lds + nwmax);
-    u32* lparent = wbase + (nwmax + 2);
-    u32* lidx = wbase;                                 // list index of a root, under the root's local index (wbase is dead by then)
-    u64* a_sx = reinterpret_cast<u64*>(lparent + cap); // cap even and the offset a multiple of 8 (host)
+    unsigned short* nzlist = reinterpret_cast<unsigned short*>(wbase + nwmax);
+    u32* lparent = wbase + nwmax + (nwmax + 1) / 2 + ((nwmax + (nwmax + 1) / 2) & 1);   // 8-byte aligned
+    u32* tail = lparent + cap;                         // cap is even (host)
+    u64* a_sx = reinterpret_cast<u64*>(tail);
     u64* a_sy = a_sx + rc;
     u32* a_area = reinterpret_cast<u32*>(a_sy + rc);
     int* a_minx = reinterpret_cast<int*>(a_area + rc);
@@ -65,27 +78,36 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
     const u64* fb = bits + (size_t)frame * G.h * ww;
     const size_t sidx = (size_t)frame * strips + strip;
     const u64 lastmask = (G.w & 63) ? ((1ull << (G.w & 63)) - 1ull) : ~0ull;
-    // stage the strip; bounding box of its zero pixels on the way (the frame's background row needs it, its sums follow from the
-    // foreground's)
-    c2_box bb = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
     C2_PROBE_BEGIN;
-    CL_FOR_WORDS(r, j, i) {
-        const u64 w = fb[(size_t)(y0 + r) * ww + j];
-        lbits[i] = w;
-        u64 z = ~w;
-        if (j == ww - 1) z &= lastmask;
-        if (z) {
-            bb.minx = min(bb.minx, 64 * j + (__ffsll((long long)z) - 1));
-            bb.maxx = max(bb.maxx, 64 * j + 63 - __clzll(z));
-            bb.miny = min(bb.miny, y0 + r);
-            bb.maxy = max(bb.maxy, y0 + r);
+    // ---- stage the strip, row masks, bounding box of the zero pixels (the frame's background row needs it) ----------------------
+    c2_box bb = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+    bool multi_mine = false;
+    for (int rr = 0; rr < G.rows; rr += 8) {
+        const int r = rr + (tid >> 5);
+        u64 acc_nz = 0, acc_ones = 0, acc_b63 = 0;     // used by lanes 0 and 32: masks of the row their half-wave holds
+        for (int j0 = 0; j0 < ww; j0 += 32) {
+            const int j = j0 + l32;
+            const bool valid = r < nrows && j < ww;
+            const u64 w = valid ? fb[(size_t)(y0 + r) * ww + j] : 0ull;
+            if (r < G.rows && j < ww) lbits[r * ww + j] = w;
+            multi_mine |= nstarts(w) > 1u;
+            u64 z = ~w;
+            if (j == ww - 1) z &= lastmask;
+            if (valid && z) {
+                bb.minx = min(bb.minx, 64 * j + (__ffsll((long long)z) - 1));
+                bb.maxx = max(bb.maxx, 64 * j + 63 - __clzll(z));
+                bb.miny = min(bb.miny, y0 + r);
+                bb.maxy = max(bb.maxy, y0 + r);
+            }
+            const u64 b_nz = __ballot(w != 0ull), b_ones = __ballot(w == ~0ull), b_63 = __ballot((w >> 63) != 0ull);
+            const int sh = (lane & 32);                // half of the ballot that belongs to this lane's row
+            acc_nz |= ((b_nz >> sh) & 0xffffffffull) << j0;
+            acc_ones |= ((b_ones >> sh) & 0xffffffffull) << j0;
+            acc_b63 |= ((b_63 >> sh) & 0xffffffffull) << j0;
         }
+        if (l32 == 0 && r < G.rows) { m_nz[r] = acc_nz; m_ones[r] = acc_ones; m_b63[r] = acc_b63; }
     }
-    if (tid < rc) {
-        a_sx[tid] = 0; a_sy[tid] = 0; a_area[tid] = 0; a_key[tid] = 0xffffffffu;
-        a_minx[tid] = INT_MAX; a_maxx[tid] = INT_MIN; a_miny[tid] = INT_MAX; a_maxy[tid] = INT_MIN;
-    }
-    if (tid == 0) nroots_s = 0;
+    if (tid == 0) { nroots_s = 0; nqueue_s = 0; }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         bb.minx = min(bb.minx, __shfl_xor(bb.minx, d));
@@ -94,7 +116,7 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
         bb.maxy = max(bb.maxy, __shfl_xor(bb.maxy, d));
     }
     if (lane == 0) bgp[wv] = bb;
-    __syncthreads();
+    const bool any_multi = __syncthreads_or(multi_mine);
     if (tid == 0) {
         for (int k = 1; k < 4; k++) {
             bb.minx = min(bb.minx, bgp[k].minx); bb.maxx = max(bb.maxx, bgp[k].maxx);
@@ -102,18 +124,161 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
         }
         bgbox[sidx] = bb;
     }
-    u32 my_first;
-    C2_PROBE(0, 0);   // staged + background box
-    auto probe = [&](int i) { C2_PROBE(0, i); };   // 1: counted + scanned, 2: indices + row leaders
-    const u32 S = ccl_local_unions<false>(G, lbits, wbase, lparent, nullptr, wsum, &total_s, y0, nrows, (u32)cap, &my_first, probe);
-    if (S == 0 || S > (u32)cap) {
-        if (tid == 0) ncomp[sidx] = S ? C2_DENSE : 0u;
+    // ---- list of the non-zero words, row-major -----------------------------------------------------------------------------------
+    if (wv == 0) {
+        const u32 c = lane < G.rows ? (u32)__popcll(m_nz[lane]) : 0u;
+        u32 inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane <= G.rows) rowoff[lane] = inc - c;    // lane == rows: the total (c = 0 there)
+    }
+    __syncthreads();
+    const u32 nnz = rowoff[G.rows];
+    C2_PROBE(0, 0);   // staged, masks, background box
+    if (nnz == 0) {
+        if (tid == 0) ncomp[sidx] = 0u;
+        return;
+    }
+    for (int rr = 0; rr < G.rows; rr += 8) {
+        const int r = rr + (tid >> 5);
+        const u64 nzr = m_nz[r];
+        for (int j0 = 0; j0 < ww; j0 += 32) {
+            const int j = j0 + l32;
+            if (j < ww && ((nzr >> j) & 1ull)) nzlist[rowoff[r] + (u32)__popcll(nzr & ((1ull << j) - 1ull))] = (unsigned short)((r << 8) | j);
+        }
+    }
+    __syncthreads();
+    // ---- index of every word's first segment ------------------------------------------------------------------------------------------
+    u32 S;
+    if (!any_multi) {
+        S = nnz;                                       // one segment per non-zero word: the index is the place in the list
+        for (u32 t = tid; t < nnz; t += 256) { const u32 e = nzlist[t]; wbase[(e >> 8) * ww + (e & 255u)] = t; }
+    } else {
+        // exclusive scan of the segment counts in list order: thread = CH consecutive entries
+        const u32 CH = (nnz + 255u) / 256u;
+        const u32 t0 = (u32)tid * CH;
+        u32 cnt = 0;
+        for (u32 t = t0; t < min(t0 + CH, nnz); t++) { const u32 e = nzlist[t]; cnt += nstarts(lbits[(e >> 8) * ww + (e & 255u)]); }
+        u32 inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        u32 off = 0, tot = 0;
+        for (int k = 0; k < 4; k++) { if (k < wv) off += wsum[k]; tot += wsum[k]; }
+        S = tot;
+        u32 run = off + inc - cnt;
+        if (S <= (u32)cap)
+            for (u32 t = t0; t < min(t0 + CH, nnz); t++) {
+                const u32 e = nzlist[t];
+                const u32 i = (e >> 8) * ww + (e & 255u);
+                wbase[i] = run;
+                run += nstarts(lbits[i]);
+            }
+    }
+    if (S > (u32)cap) {                                // block-uniform
+        if (tid == 0) ncomp[sidx] = C2_DENSE;
         return;
     }
     __syncthreads();
-    C2_PROBE(0, 3);   // unions
-    // every segment points at its root (read-only walks: each thread overwrites only its own entries); a root takes the next free
-    // place of the strip's list - the list is unordered, the merge orders components by key
+    C2_PROBE(0, 1);   // word list, segment indices
+    // does the first segment of word (r, j) continue a run that comes in from the left?
+    auto continues = [&](int r, int j, u64 w) -> bool { return (w & 1ull) && j > 0 && ((m_b63[r] >> (j - 1)) & 1ull); };
+    // index of the segment a run reaching word (r, j) from the left started with (only called when continues(r, j))
+    auto run_leader = [&](int r, int j) -> u32 {
+        const u64 notfull = ~m_ones[r] & ((1ull << j) - 1ull);     // words left of j that are not all ones
+        const int jl = notfull ? 63 - __clzll(notfull) : -1;        // the nearest one; words jl+1 .. j-1 are all ones
+        if (jl >= 0 && ((m_b63[r] >> jl) & 1ull)) { const int i = r * ww + jl; return wbase[i] + nstarts(lbits[i]) - 1u; }   // its last segment
+        return wbase[r * ww + jl + 1];                              // the run starts with the all-ones word after it
+    };
+    // ---- parents: own index, or the run's first segment ----------------------------------------------------------------------------
+    for (u32 t = tid; t < nnz; t += 256) {
+        const u32 e = nzlist[t];
+        const int r = (int)(e >> 8), j = (int)(e & 255u), i = r * ww + j;
+        const u64 w = lbits[i];
+        const u32 base = wbase[i];
+        lparent[base] = continues(r, j, w) ? run_leader(r, j) : base;
+        const u32 ns = nstarts(w);
+        for (u32 k = 1; k < ns; k++) lparent[base + k] = base + k;
+    }
+    __syncthreads();
+    C2_PROBE(0, 2);   // parents set, runs linked
+    // ---- vertical contacts --------------------------------------------------------------------------------------------------------
+    {
+        u64* queue = reinterpret_cast<u64*>(tail);
+        const u32 qcap = (u32)tail_words / 2u;
+        auto link = [&](u32 L, u32 La) {                            // leader L of a run of this row touches leader La above (La < L)
+            const u32 old = atomicMin(lparent + L, La);
+            if (old != L && old != La) {                            // L already hung under another run above: those two are one component
+                const u32 q = atomicAdd(&nqueue_s, 1u);
+                if (q < qcap) queue[q] = ((u64)old << 32) | (u64)La;
+            }
+        };
+        for (u32 t = tid; t < nnz; t += 256) {
+            const u32 e = nzlist[t];
+            const int r = (int)(e >> 8), j = (int)(e & 255u), i = r * ww + j;
+            if (r == 0) continue;
+            const u64 um = lbits[i - ww];
+            const bool ul63 = j > 0 && ((m_b63[r - 1] >> (j - 1)) & 1ull);
+            const u64 urw = j + 1 < ww ? lbits[i - ww + 1] : 0ull;
+            if (!(um | (u64)ul63 | (urw & 1ull))) continue;
+            const u64 w = lbits[i];
+            const u32 base = wbase[i];
+            const u32 ubase = um ? wbase[i - ww] : 0u;
+            const u64 ustarts = um & ~(um << 1);
+            const bool um_cont = um && continues(r - 1, j, um);     // the first segment of the word above is not its run's leader
+            u64 rem = w;
+            u32 me = base;
+            while (rem) {
+                const int s = __ffsll((long long)rem) - 1;
+                const int en = run_end(rem, s);
+                const u64 Sg = bit_range(s, en);
+                rem &= ~Sg;
+                const u32 L = (me == base && continues(r, j, w)) ? lparent[base] : me;   // non-leader entries are not written in this phase
+                u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
+                while (c) {
+                    const int b = __ffsll((long long)c) - 1;
+                    const u32 k = (u32)__popcll(ustarts & ((2ull << b) - 1ull)) - 1u;    // ordinal of the run of `um` that holds bit b
+                    const u32 a = ubase + k;
+                    link(L, (k == 0 && um_cont) ? lparent[a] : a);
+                    c &= ~bit_range(b, run_end(um, b));
+                }
+                if ((Sg & 1ull) && ul63 && !(um & 1ull)) {          // diagonal contact with the last segment of the word above-left
+                    const int il = i - ww - 1;
+                    const u64 ul = lbits[il];
+                    const u32 nsl = nstarts(ul);
+                    const u32 a = wbase[il] + nsl - 1u;
+                    link(L, (nsl == 1u && continues(r - 1, j - 1, ul)) ? lparent[a] : a);
+                }
+                if ((Sg >> 63) && (urw & 1ull) && !(um >> 63)) link(L, wbase[i - ww + 1]);   // above-right: that segment starts its run
+                me++;
+            }
+        }
+    }
+    __syncthreads();
+    C2_PROBE(0, 3);   // vertical links
+    // ---- the rare real unions ---------------------------------------------------------------------------------------------------
+    {
+        const u32 nq = nqueue_s;                                    // block-uniform
+        if (nq > (u32)tail_words / 2u) {
+            if (tid == 0) ncomp[sidx] = C2_DENSE;
+            return;
+        }
+        if (nq) {
+            const u64* queue = reinterpret_cast<const u64*>(tail);
+            for (u32 q = tid; q < nq; q += 256) { const u64 pr = queue[q]; lds_unite(lparent, (u32)(pr >> 32), (u32)pr); }
+            __syncthreads();
+        }
+    }
+    // ---- roots: pointer jumping, then a short walk; a root takes the next free place of the strip's (unordered) list -----------------
+    u32* lidx = tail;                                               // list index under the root's segment index
+    for (int round = 0; round < 5; round++)
+        for (u32 ci = tid; ci < S; ci += 256) {
+            const u32 pp = lparent[ci];
+            const u32 g = lparent[pp];
+            if (g != pp) lparent[ci] = g;                           // any value stored is an ancestor: no barrier needed between rounds
+        }
+    __syncthreads();
     for (u32 c0 = 0; c0 < S; c0 += 256) {
         const u32 ci = c0 + tid;
         bool isroot = false;
@@ -124,19 +289,26 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
         }
         const unsigned long long m = __ballot(isroot);
         if (m) {
-            u32 base = 0;
-            if (lane == 0) base = atomicAdd(&nroots_s, (u32)__popcll(m));
-            base = __shfl(base, 0);
-            if (isroot) lidx[ci] = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            u32 basek = 0;
+            if (lane == 0) basek = atomicAdd(&nroots_s, (u32)__popcll(m));
+            basek = __shfl(basek, 0);
+            if (isroot) lidx[ci] = basek + (u32)__popcll(m & ((1ull << lane) - 1ull));
         }
     }
     __syncthreads();
-    C2_PROBE(0, 4);   // roots stored, list indices
     const u32 R = nroots_s;
     if (R > (u32)rc) {
         if (tid == 0) ncomp[sidx] = C2_DENSE;
         return;
     }
+    for (u32 ci = tid; ci < S; ci += 256) lparent[ci] = lidx[lparent[ci]];   // segment -> place of its component in the list
+    __syncthreads();
+    C2_PROBE(0, 4);   // roots, list places
+    if (tid < rc) {
+        a_sx[tid] = 0; a_sy[tid] = 0; a_area[tid] = 0; a_key[tid] = 0xffffffffu;
+        a_minx[tid] = INT_MAX; a_maxx[tid] = INT_MIN; a_miny[tid] = INT_MAX; a_maxy[tid] = INT_MIN;
+    }
+    __syncthreads();
     auto acc_add = [&](u32 k, const contrib& c) {
         atomicAdd(a_area + k, c.area);
         atomicAdd((unsigned long long*)(a_sx + k), (unsigned long long)c.sx);
@@ -147,71 +319,70 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
         atomicMax(a_maxy + k, c.maxy);
         atomicMin(a_key + k, c.pad);
     };
-    // second walk over the words, in the order that numbered the segments: statistics and numbering key (smallest segment id) of
-    // every component, component index of every word's first segment (dense) and of the segments of words that hold several
+    // ---- statistics and numbering key (smallest segment id) of every component; component index of every word's first segment
+    // (dense) and of the segments of words that hold several ----------------------------------------------------------------------
     {
-        u32 run = my_first;
-        const int l32 = tid & 31;
         u32* wc = wordcomp + (size_t)frame * G.h * ww;
         u32* sc = segcomp + (size_t)frame * G.nids;
         const u32 NONE = 0xffffffffu;
-        for (int rr = 0; rr < G.rows; rr += 8) {
-            const int r = rr + (tid >> 5);
-            for (int j0 = 0; j0 < ww; j0 += 32) {
-                const int j = j0 + l32;
-                const bool valid = r < nrows && j < ww;
-                const u64 w = valid ? lbits[r * ww + j] : 0ull;
-                const int y = y0 + r;
-                u64 rem = w;
-                const bool multi = nstarts(w) > 1u;
-                contrib c0;
-                contrib_zero(c0);
-                c0.pad = NONE;
-                u32 k0 = NONE;
-                if (w) {
-                    const int s = __ffsll((long long)rem) - 1;
-                    const int e = run_end(rem, s);
-                    rem &= ~bit_range(s, e);
-                    k0 = lidx[lparent[run]];
-                    run++;
-                    wc[(size_t)y * ww + j] = k0;
-                    const u32 id = seg_id(G, y, 64 * j + s);
-                    if (multi) sc[id] = k0;
-                    const u32 len = (u32)(e - s + 1);
-                    const int xs = 64 * j + s, xe = 64 * j + e;
-                    c0.area = len; c0.sx = (u64)len * (u64)(xs + xe) / 2ull; c0.sy = (u64)len * (u64)y;
-                    c0.minx = xs; c0.maxx = xe; c0.miny = c0.maxy = y; c0.pad = id;
-                }
-                // a wave whose first segments all belong to one component (the inside of a blob, a full mask) combines them
-                // with shuffles and adds once instead of queueing 64 lanes on the same LDS words
-                const unsigned long long act = __ballot(k0 != NONE);
-                if (act) {
-                    const int lead = __ffsll((long long)act) - 1;
-                    const u32 ref = __shfl(k0, lead);
-                    if (__popcll(act) >= 8 && __all(k0 == NONE || k0 == ref)) {
-                        wave_combine(c0);
+        for (u32 t0 = 0; t0 < nnz; t0 += 256) {
+            const u32 t = t0 + tid;
+            contrib c0;
+            contrib_zero(c0);
+            c0.pad = NONE;
+            u32 k0 = NONE;
+            u64 rem = 0;
+            int j = 0, y = 0;
+            u32 nextseg = 0;
+            if (t < nnz) {
+                const u32 e = nzlist[t];
+                const int r = (int)(e >> 8);
+                j = (int)(e & 255u);
+                y = y0 + r;
+                const int i = r * ww + j;
+                const u64 w = lbits[i];
+                const u32 base = wbase[i];
+                const int s = __ffsll((long long)w) - 1;
+                const int en = run_end(w, s);
+                rem = w & ~bit_range(s, en);
+                k0 = lparent[base];
+                nextseg = base + 1u;
+                wc[(size_t)y * ww + j] = k0;
+                const u32 id = seg_id(G, y, 64 * j + s);
+                if (rem) sc[id] = k0;
+                const u32 len = (u32)(en - s + 1);
+                const int xs = 64 * j + s, xe = 64 * j + en;
+                c0.area = len; c0.sx = (u64)len * (u64)(xs + xe) / 2ull; c0.sy = (u64)len * (u64)y;
+                c0.minx = xs; c0.maxx = xe; c0.miny = c0.maxy = y; c0.pad = id;
+            }
+            // a wave whose first segments all belong to one component (the inside of a blob, a full mask) combines them
+            // with shuffles and adds once instead of queueing 64 lanes on the same LDS words
+            const unsigned long long act = __ballot(k0 != NONE);
+            if (act) {
+                const int lead = __ffsll((long long)act) - 1;
+                const u32 ref = __shfl(k0, lead);
+                if (__popcll(act) >= 8 && __all(k0 == NONE || k0 == ref)) {
+                    wave_combine(c0);
 #pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) c0.pad = min(c0.pad, (u32)__shfl_xor(c0.pad, d));
-                        if (lane == lead) acc_add(ref, c0);
-                    } else if (k0 != NONE) {
-                        acc_add(k0, c0);
-                    }
+                    for (int d = 1; d < 64; d <<= 1) c0.pad = min(c0.pad, (u32)__shfl_xor(c0.pad, d));
+                    if (lane == lead) acc_add(ref, c0);
+                } else if (k0 != NONE) {
+                    acc_add(k0, c0);
                 }
-                while (rem) {
-                    const int s = __ffsll((long long)rem) - 1;
-                    const int e = run_end(rem, s);
-                    rem &= ~bit_range(s, e);
-                    const u32 k = lidx[lparent[run]];
-                    run++;
-                    const u32 id = seg_id(G, y, 64 * j + s);
-                    sc[id] = k;
-                    contrib c;
-                    const u32 len = (u32)(e - s + 1);
-                    const int xs = 64 * j + s, xe = 64 * j + e;
-                    c.area = len; c.sx = (u64)len * (u64)(xs + xe) / 2ull; c.sy = (u64)len * (u64)y;
-                    c.minx = xs; c.maxx = xe; c.miny = c.maxy = y; c.pad = id;
-                    acc_add(k, c);
-                }
+            }
+            while (rem) {
+                const int s = __ffsll((long long)rem) - 1;
+                const int en = run_end(rem, s);
+                rem &= ~bit_range(s, en);
+                const u32 k = lparent[nextseg++];
+                const u32 id = seg_id(G, y, 64 * j + s);
+                sc[id] = k;
+                contrib c;
+                const u32 len = (u32)(en - s + 1);
+                const int xs = 64 * j + s, xe = 64 * j + en;
+                c.area = len; c.sx = (u64)len * (u64)(xs + xe) / 2ull; c.sy = (u64)len * (u64)y;
+                c.minx = xs; c.maxx = xe; c.miny = c.maxy = y; c.pad = id;
+                acc_add(k, c);
             }
         }
     }
@@ -270,9 +441,28 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     __shared__ c2_box bgs;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ww = G.ww;
+    const u64* fb = bits + (size_t)f * G.h * ww;
+    const u32* wc = wordcomp + (size_t)f * G.h * ww;
+    const u32* sc = segcomp + (size_t)f * G.nids;
     C2_PROBE_BEGIN;
-    // list sizes -> offsets
+    // Everything that does not depend on the list sizes is requested first, so that it travels with them: the strips' background
+    // boxes and, per thread, the first boundary word it will unite across (bit words of the two rows and their component indices).
     const u32 nc_raw = tid < strips ? ncomp[(size_t)f * strips + tid] : 0u;
+    c2_box mybox = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+    if (tid < strips) mybox = bgbox[(size_t)f * strips + tid];
+    const int items = (strips - 1) * ww;
+    u64 p_w = 0, p_um = 0, p_ul = 0, p_ur = 0;
+    u32 p_ks = 0, p_kum = 0, p_kul = 0, p_kur = 0;
+    int p_b = 0, p_j = 0;
+    if (tid < items) {
+        p_b = tid / ww; p_j = tid - p_b * ww;
+        const size_t idx = (size_t)(p_b + 1) * G.rows * ww + p_j;
+        p_w = fb[idx]; p_um = fb[idx - ww];
+        p_ks = wc[idx]; p_kum = wc[idx - ww];
+        if (p_j > 0) { p_ul = fb[idx - ww - 1]; p_kul = wc[idx - ww - 1]; }
+        if (p_j + 1 < ww) { p_ur = fb[idx - ww + 1]; p_kur = wc[idx - ww + 1]; }
+    }
+    // list sizes -> offsets
     const bool dense = nc_raw == C2_DENSE;
     u32 C;
     const u32 ex = c2_block_scan_excl(dense ? 0u : nc_raw, wtot, &C);
@@ -285,49 +475,44 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     }
     if (tid == 0) crowded[f] = 0u;
     C2_PROBE(1, 0);   // list sizes read and scanned
-    // component records -> LDS (wave per strip)
-    for (int s = wv; s < strips; s += C2_THREADS / 64) {
-        const u32 b0 = sbase[s], cnt = sbase[s + 1] - b0;
-        const contrib* src = recs + ((size_t)f * strips + s) * C2_RC;
-        for (u32 k = lane; k < cnt; k += 64) {
-            const contrib c = src[k];
-            const u32 i = b0 + k;
-            par[i] = i;
-            key[i] = c.pad;
-            a_area[i] = c.area; a_minx[i] = c.minx; a_maxx[i] = c.maxx; a_miny[i] = c.miny; a_maxy[i] = c.maxy;
-            a_sx[i] = c.sx; a_sy[i] = c.sy;
+    // component records -> LDS: component i = tid + q * C2_THREADS sits at place i - sbase[s] of the list of the strip s it falls in
+    u32 slot[C2_PER];                        // strip * C2_RC + place, for the label table
+#pragma unroll
+    for (int q = 0; q < C2_PER; q++) {
+        const u32 i = (u32)tid + (u32)q * C2_THREADS;
+        slot[q] = 0xffffffffu;
+        if (i < C) {
+            int lo = 0, hi = strips;         // largest s with sbase[s] <= i
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= i) lo = mid; else hi = mid; }
+            slot[q] = (u32)lo * C2_RC + (i - sbase[lo]);
         }
     }
-    // background box
-    if (tid < strips) {
-        const c2_box b = bgbox[(size_t)f * strips + tid];
-        if (b.minx != INT_MAX) {
-            atomicMin(&bgs.minx, b.minx); atomicMax(&bgs.maxx, b.maxx);
-            atomicMin(&bgs.miny, b.miny); atomicMax(&bgs.maxy, b.maxy);
+    contrib rec[C2_PER];
+#pragma unroll
+    for (int q = 0; q < C2_PER; q++)
+        if (slot[q] != 0xffffffffu) rec[q] = recs[(size_t)f * strips * C2_RC + slot[q]];
+#pragma unroll
+    for (int q = 0; q < C2_PER; q++) {
+        const u32 i = (u32)tid + (u32)q * C2_THREADS;
+        if (slot[q] != 0xffffffffu) {
+            par[i] = i;
+            key[i] = rec[q].pad;
+            a_area[i] = rec[q].area; a_minx[i] = rec[q].minx; a_maxx[i] = rec[q].maxx; a_miny[i] = rec[q].miny; a_maxy[i] = rec[q].maxy;
+            a_sx[i] = rec[q].sx; a_sy[i] = rec[q].sy;
         }
+    }
+    if (tid < strips && mybox.minx != INT_MAX) {
+        atomicMin(&bgs.minx, mybox.minx); atomicMax(&bgs.maxx, mybox.maxx);
+        atomicMin(&bgs.miny, mybox.miny); atomicMax(&bgs.maxy, mybox.maxy);
     }
     __syncthreads();
     C2_PROBE(1, 1);   // records in LDS
     // unions across the strip boundaries: one thread per word of the first row of strips 1 ..
     {
-        const u64* fb = bits + (size_t)f * G.h * ww;
-        const u32* wc = wordcomp + (size_t)f * G.h * ww;
-        const u32* sc = segcomp + (size_t)f * G.nids;
-        const int items = (strips - 1) * ww;
-        for (int t = tid; t < items; t += C2_THREADS) {
-            const int b = t / ww, j = t - b * ww;
+        auto unite_word = [&](int b, int j, u64 w, u64 um, u64 ul, u64 ur, u32 k_self, u32 k_um, u32 k_ul, u32 k_ur) {
+            if (!w || !(um | (ul >> 63) | (ur & 1ull))) return;
             const int y = (b + 1) * G.rows;
-            const size_t idx = (size_t)y * ww + j;
-            const u64 w = fb[idx];
-            const u64 um = fb[idx - ww];
-            const u64 ul = j > 0 ? fb[idx - ww - 1] : 0ull;
-            const u64 ur = j + 1 < ww ? fb[idx - ww + 1] : 0ull;
-            if (!w || !(um | (ul >> 63) | (ur & 1ull))) continue;
             const u32 lo = sbase[b], hi = sbase[b + 1];
-            const u32 k_self = wc[idx];
-            const u32 k_um = um ? wc[idx - ww] : 0u;
-            const u32 k_ul = (ul >> 63) ? wc[idx - ww - 1] : 0u;
-            const u32 k_ur = (ur & 1ull) ? wc[idx - ww + 1] : 0u;
             const int um_first = um ? __ffsll((long long)um) - 1 : 0;
             u64 rem = w;
             bool first = true;
@@ -352,6 +537,17 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
                 }
                 if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) lds_unite(par, me, lo + k_ur);
             }
+        };
+        if (tid < items) unite_word(p_b, p_j, p_w, p_um, p_ul, p_ur, p_ks, p_kum, p_kul, p_kur);
+        for (int t = tid + C2_THREADS; t < items; t += C2_THREADS) {
+            const int b = t / ww, j = t - b * ww;
+            const size_t idx = (size_t)(b + 1) * G.rows * ww + j;
+            const u64 w = fb[idx];
+            const u64 um = fb[idx - ww];
+            const u64 ul = j > 0 ? fb[idx - ww - 1] : 0ull;
+            const u64 ur = j + 1 < ww ? fb[idx - ww + 1] : 0ull;
+            if (!w || !(um | (ul >> 63) | (ur & 1ull))) continue;
+            unite_word(b, j, w, um, ul, ur, wc[idx], um ? wc[idx - ww] : 0u, (ul >> 63) ? wc[idx - ww - 1] : 0u, (ur & 1ull) ? wc[idx - ww + 1] : 0u);
         }
     }
     __syncthreads();
@@ -361,7 +557,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     u32 nroot_mine = 0;
 #pragma unroll
     for (int q = 0; q < C2_PER; q++) {
-        const u32 i = (u32)tid * C2_PER + q;
+        const u32 i = (u32)tid + (u32)q * C2_THREADS;
         root[q] = 0xffffffffu;
         if (i < C) {
             root[q] = lds_root(par, i);
@@ -374,7 +570,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     u32 pos = c2_block_scan_excl(nroot_mine, wtot, &R);   // (its barriers also complete the keys)
 #pragma unroll
     for (int q = 0; q < C2_PER; q++) {
-        const u32 i = (u32)tid * C2_PER + q;
+        const u32 i = (u32)tid + (u32)q * C2_THREADS;
         if (i < C && root[q] == i) rkeys[pos++] = key[i];
     }
     __syncthreads();
@@ -382,7 +578,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     // cv2's label of a component = 1 + number of components with a smaller key (keys are distinct)
 #pragma unroll
     for (int q = 0; q < C2_PER; q++) {
-        const u32 i = (u32)tid * C2_PER + q;
+        const u32 i = (u32)tid + (u32)q * C2_THREADS;
         const bool isroot = i < C && root[q] == i;
         if (__any(isroot)) {
             const u32 mine = isroot ? key[i] : 0u;
@@ -393,24 +589,21 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     }
     __syncthreads();
     C2_PROBE(1, 4);   // ranks
-    // statistics of absorbed components move to their roots
+    // statistics of absorbed components move to their roots; (strip, component) -> label table
 #pragma unroll
     for (int q = 0; q < C2_PER; q++) {
-        const u32 i = (u32)tid * C2_PER + q;
-        if (i < C && root[q] != i) {
+        const u32 i = (u32)tid + (u32)q * C2_THREADS;
+        if (i < C) {
             const u32 r = root[q];
-            atomicAdd(a_area + r, a_area[i]);
-            atomicAdd((unsigned long long*)(a_sx + r), (unsigned long long)a_sx[i]);
-            atomicAdd((unsigned long long*)(a_sy + r), (unsigned long long)a_sy[i]);
-            atomicMin(a_minx + r, a_minx[i]); atomicMax(a_maxx + r, a_maxx[i]);
-            atomicMin(a_miny + r, a_miny[i]); atomicMax(a_maxy + r, a_maxy[i]);
+            complabel[(size_t)f * strips * C2_RC + slot[q]] = lab[r];
+            if (r != i) {
+                atomicAdd(a_area + r, a_area[i]);
+                atomicAdd((unsigned long long*)(a_sx + r), (unsigned long long)a_sx[i]);
+                atomicAdd((unsigned long long*)(a_sy + r), (unsigned long long)a_sy[i]);
+                atomicMin(a_minx + r, a_minx[i]); atomicMax(a_maxx + r, a_maxx[i]);
+                atomicMin(a_miny + r, a_miny[i]); atomicMax(a_maxy + r, a_maxy[i]);
+            }
         }
-    }
-    // (strip, component) -> label table
-    for (int s = wv; s < strips; s += C2_THREADS / 64) {
-        const u32 b0 = sbase[s], cnt = sbase[s + 1] - b0;
-        u32* dst = complabel + ((size_t)f * strips + s) * C2_RC;
-        for (u32 k = lane; k < cnt; k += 64) dst[k] = lab[par[b0 + k]];
     }
     __syncthreads();
     C2_PROBE(1, 5);   // statistics moved, label table written
@@ -423,7 +616,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
         u64 t_sx = 0, t_sy = 0;
 #pragma unroll
         for (int q = 0; q < C2_PER; q++) {
-            const u32 i = (u32)tid * C2_PER + q;
+            const u32 i = (u32)tid + (u32)q * C2_THREADS;
             if (i < C && root[q] == i) {
                 const u32 l = lab[i];
                 t_area += a_area[i]; t_sx += a_sx[i]; t_sy += a_sy[i];
@@ -453,6 +646,12 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
             atomicAdd((unsigned long long*)&tot_sy, (unsigned long long)t_sy);
         }
     }
+    // rows past the last label read as zeros
+    for (int l = nl + tid; l < max_labels; l += C2_THREADS) {
+        const size_t o = (size_t)f * max_labels + l;
+        if (stats) { int32_t* sp = stats + o * 5; sp[0] = sp[1] = sp[2] = sp[3] = sp[4] = 0; }
+        if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
+    }
     __syncthreads();
     if (tid == 0) {
         const u64 W = (u64)G.w, H = (u64)G.h;
@@ -473,14 +672,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
             cent[o * 2 + 1] = (double)sy / (double)area;
         }
     }
-    C2_PROBE(1, 6);   // rows of the roots and the background
-    // rows past the last label read as zeros
-    for (int l = nl + tid; l < max_labels; l += C2_THREADS) {
-        const size_t o = (size_t)f * max_labels + l;
-        if (stats) { int32_t* sp = stats + o * 5; sp[0] = sp[1] = sp[2] = sp[3] = sp[4] = 0; }
-        if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
-    }
-    C2_PROBE(1, 7);   // zero rows
+    C2_PROBE(1, 6);   // rows
     C2_PROBE(1, 15);
 #ifdef VP_PROBE
     if (tid == 0 && blockIdx.x < C2_PROBE_BLOCKS) g_c2_probe[1][blockIdx.x][14] = 0x600dc0deu;
@@ -493,6 +685,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
 // block-uniform.  Frames resolved by the two-level path carry component indices in the word / segment arrays and take the label
 // from the strip's table, staged in LDS by loads issued together with the first batch of bit words (one global round trip, as
 // before); crowded frames, finished by the one-level kernels, carry labels there.
+template <int VARIANT>
 __global__ __launch_bounds__(256, 8) void k_ccl2_write(const u64* __restrict__ bits, ccl_geom G, int strips, int rc, const u32* __restrict__ segcomp,
                                                     const u32* __restrict__ wordcomp, const u32* __restrict__ complabel,
                                                     const u32* __restrict__ crowded, int32_t* __restrict__ labels, u32 gpr, u32 gpr_magic)
@@ -561,6 +754,7 @@ __global__ __launch_bounds__(256, 8) void k_ccl2_write(const u64* __restrict__ b
                 if (m2[k]) lb[k] = ltab[lb[k]];
             }
         }
+        if (VARIANT == 3) __syncthreads();
 #pragma unroll
         for (int k = 0; k < WR_K; k++) {
             if (!live[k]) continue;
