@@ -658,6 +658,69 @@ static int morph_basic_dev(vp_ctx* ctx, int dilate, const norm_se& se, const uin
     return VP_OK;
 }
 
+// workspace a morphology call needs besides its source / result images
+static size_t morph_ws_bytes(const norm_se& se, int w, int h, int cn)
+{
+    const size_t nbytes = (size_t)w * h * cn;
+    const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
+    const size_t offbytes = ((size_t)se.kw * se.kh + se.kw + se.kh) * 4 + 64;
+    const size_t tabbytes = se.allones ? 0 : 7 * nbytes;   // running min/max tables of the span form
+    return 4 * vp_align(nbytes) + 2 * vp_align(bitbytes) + vp_align(offbytes) + vp_align(tabbytes) + 4096;
+}
+
+// One morphology operation between device images (d_dst may equal neither d_src nor overlap it); temporaries are carved from the
+// workspace, which the caller has reserved (morph_ws_bytes).  binary_hint: 1 = the image is known to hold only 0 / 255 (a mask this
+// library produced), 0 = unknown: one flag comes back from the device to decide between the bit-plane and the grey-level path.
+static int morph_core(vp_ctx* ctx, int op, const norm_se& se, const uint8_t* d_src, int w, int h, int cn, int binary_hint, uint8_t* d_dst)
+{
+    const size_t nbytes = (size_t)w * h * cn;
+    const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
+    const size_t offbytes = ((size_t)se.kw * se.kh + se.kw + se.kh) * 4 + 64;
+    const size_t tabbytes = se.allones ? 0 : 7 * nbytes;
+    uint8_t* d_tab = tabbytes ? (uint8_t*)vp_ws_take(ctx, tabbytes) : nullptr;
+    if (tabbytes && !d_tab) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
+    TAKE(d_b, uint8_t*, nbytes);
+    TAKE(d_c, uint8_t*, nbytes);
+    TAKE(d_tmp, uint8_t*, nbytes);
+    TAKE(bits_a, u64*, bitbytes);
+    TAKE(bits_b, u64*, bitbytes);
+    TAKE(d_offs, int16_t*, offbytes);
+    TAKE(d_flag, int*, 4);
+    bool binary = false;
+    if (cn == 1 && se.allones) {
+        // a 0/255 mask can take the bit-plane path; anything else is grey-level
+        if (binary_hint == 1) {
+            VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, bits_a, nullptr));
+            binary = true;
+        } else {
+            VP_HIP(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+            VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, bits_a, d_flag));
+            int flag = 1;
+            VP_TRY(d2h(ctx, &flag, d_flag, 4));
+            VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            binary = flag == 0;
+        }
+    }
+    if (binary && op != VP_MORPH_GRADIENT) {
+        // whole op (incl. OPEN/CLOSE) as one fused bit-plane launch
+        std::vector<vp_bitstage> st;
+        rect_se k = {se.kw, se.kh, se.ax, se.ay};
+        if (!(se.iterations == 0 || se.kw * se.kh == 1)) stages_for_op(st, op, k);
+        VP_TRY(run_bit_stages(ctx, st, bits_a, bits_b, w, h, 1, nullptr, d_dst));
+    } else if (op == VP_MORPH_ERODE || op == VP_MORPH_DILATE) {
+        VP_TRY(morph_basic_dev(ctx, op == VP_MORPH_DILATE, se, d_src, w, h, cn, binary, d_dst, d_tmp, bits_a, bits_b, d_offs, d_tab));
+    } else if (op == VP_MORPH_OPEN || op == VP_MORPH_CLOSE) {
+        const int first = op == VP_MORPH_CLOSE;
+        VP_TRY(morph_basic_dev(ctx, first, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs, d_tab));
+        VP_TRY(morph_basic_dev(ctx, !first, se, d_b, w, h, cn, binary, d_dst, d_tmp, bits_a, bits_b, d_offs, d_tab));
+    } else {  // GRADIENT = dilate - erode
+        VP_TRY(morph_basic_dev(ctx, 1, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs, d_tab));
+        VP_TRY(morph_basic_dev(ctx, 0, se, d_src, w, h, cn, binary, d_c, d_tmp, bits_a, bits_b, d_offs, d_tab));
+        VP_TRY(vpk_absdiff_sub_u8(ctx, d_b, d_c, nbytes, d_dst));
+    }
+    return VP_OK;
+}
+
 int vp_morph_u8(vp_ctx* ctx, int op, const uint8_t* src, int w, int h, int cn, const uint8_t* kernel, int kw, int kh, int ax, int ay,
                 int iterations, uint8_t* dst)
 {
@@ -667,52 +730,58 @@ int vp_morph_u8(vp_ctx* ctx, int op, const uint8_t* src, int w, int h, int cn, c
     norm_se se;
     if (normalise_se(kernel, kw, kh, ax, ay, iterations, &se) != VP_OK) return vp_fail(ctx, VP_ERR_INVALID, "structuring element");
     const size_t nbytes = (size_t)w * h * cn;
-    const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
-    const size_t offbytes = ((size_t)se.kw * se.kh + se.kw + se.kh) * 4 + 64;
-    const size_t tabbytes = se.allones ? 0 : 7 * nbytes;   // running min/max tables of the span form
-    VP_TRY(vp_ws_reserve(ctx, 5 * vp_align(nbytes) + 2 * vp_align(bitbytes) + vp_align(offbytes) + vp_align(tabbytes) + 4096));
+    VP_TRY(vp_ws_reserve(ctx, 2 * vp_align(nbytes) + morph_ws_bytes(se, w, h, cn)));
     TAKE(d_src, uint8_t*, nbytes);
-    uint8_t* d_tab = tabbytes ? (uint8_t*)vp_ws_take(ctx, tabbytes) : nullptr;
-    if (tabbytes && !d_tab) return vp_fail(ctx, VP_ERR_NOMEM, "workspace");
     TAKE(d_a, uint8_t*, nbytes);
-    TAKE(d_b, uint8_t*, nbytes);
-    TAKE(d_c, uint8_t*, nbytes);
-    TAKE(d_tmp, uint8_t*, nbytes);
-    TAKE(bits_a, u64*, bitbytes);
-    TAKE(bits_b, u64*, bitbytes);
-    TAKE(d_offs, int16_t*, offbytes);
-    TAKE(d_flag, int*, 4);
     VP_TRY(h2d(ctx, d_src, src, nbytes));
-    bool binary = false;
-    if (cn == 1 && se.allones) {
-        // a 0/255 mask can take the bit-plane path; anything else is grey-level
-        VP_HIP(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
-        VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, bits_a, d_flag));
-        int flag = 1;
-        VP_TRY(d2h(ctx, &flag, d_flag, 4));
-        VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        binary = flag == 0;
-    }
-    uint8_t* result = d_a;
-    if (binary && op != VP_MORPH_GRADIENT) {
-        // whole op (incl. OPEN/CLOSE) as one fused bit-plane launch
-        std::vector<vp_bitstage> st;
-        rect_se k = {se.kw, se.kh, se.ax, se.ay};
-        if (!(se.iterations == 0 || se.kw * se.kh == 1)) stages_for_op(st, op, k);
-        VP_TRY(run_bit_stages(ctx, st, bits_a, bits_b, w, h, 1, nullptr, d_a));
-    } else if (op == VP_MORPH_ERODE || op == VP_MORPH_DILATE) {
-        VP_TRY(morph_basic_dev(ctx, op == VP_MORPH_DILATE, se, d_src, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs, d_tab));
-    } else if (op == VP_MORPH_OPEN || op == VP_MORPH_CLOSE) {
-        const int first = op == VP_MORPH_CLOSE;
-        VP_TRY(morph_basic_dev(ctx, first, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs, d_tab));
-        VP_TRY(morph_basic_dev(ctx, !first, se, d_b, w, h, cn, binary, d_a, d_tmp, bits_a, bits_b, d_offs, d_tab));
-    } else {  // GRADIENT = dilate - erode
-        VP_TRY(morph_basic_dev(ctx, 1, se, d_src, w, h, cn, binary, d_b, d_tmp, bits_a, bits_b, d_offs, d_tab));
-        VP_TRY(morph_basic_dev(ctx, 0, se, d_src, w, h, cn, binary, d_c, d_tmp, bits_a, bits_b, d_offs, d_tab));
-        VP_TRY(vpk_absdiff_sub_u8(ctx, d_b, d_c, nbytes, d_a));
-    }
-    VP_TRY(d2h(ctx, dst, result, nbytes));
+    VP_TRY(morph_core(ctx, op, se, d_src, w, h, cn, 0, d_a));
+    VP_TRY(d2h(ctx, dst, d_a, nbytes));
     return vp_synchronize(ctx);
+}
+
+// ---- device-resident forms of the per-operator entry points ---------------------------------------------------------------------
+// Same arithmetic, same argument meaning; images are device pointers (packed rows unless a stride is taken), nothing is copied
+// and nothing is synchronised: the call enqueues on the context's stream and returns.  They let the Python mirror keep the
+// intermediate images of a module's process() in HBM between operator calls (modules/red_buoy.py:21-38: the Lab image, its
+// planes, the threshold mask and both cleaned masks never need to visit the host).
+
+int vp_cvt_color_dev(vp_ctx* ctx, int code, const uint8_t* d_src, size_t src_stride, int w, int h, uint8_t* d_dst, uint8_t* const* d_planes)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!d_src || w <= 0 || h <= 0 || h > 65535) return vp_fail(ctx, VP_ERR_INVALID, "vp_cvt_color_dev arguments");
+    if (code < VP_BGR2LAB || code > VP_BGR2HLS) return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
+    const int scn = code == VP_GRAY2BGR ? 1 : 3, dcn = code == VP_BGR2GRAY ? 1 : 3;
+    if (src_stride < (size_t)w * scn) return vp_fail(ctx, VP_ERR_INVALID, "src_stride");
+    uint8_t* dp[3] = {nullptr, nullptr, nullptr};
+    if (d_planes)
+        for (int c = 0; c < dcn; c++) dp[c] = d_planes[c];
+    if (code == VP_HSV2BGR) {
+        if (d_planes || !d_dst || src_stride != (size_t)w * 3) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "HSV2BGR: packed rows, no split planes");
+        return vpk_hsv2bgr(ctx, d_src, (size_t)w * h, d_dst);
+    }
+    return vpk_cvt_color(ctx, code, d_src, src_stride, w, h, d_dst, dp[0], dp[1], dp[2]);
+}
+
+int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, int w, int h, int cn, const int32_t* lo, const int32_t* hi, uint8_t* d_dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!d_src || !d_dst || !lo || !hi || w <= 0 || h <= 0 || h > 65535 || (cn != 1 && cn != 3) || src_stride < (size_t)w * cn)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_inrange_u8_dev arguments");
+    vp_range3 q;
+    norm_range(cn, lo, hi, &q);
+    return vpk_inrange_u8(ctx, d_src, src_stride, w, h, cn, q, d_dst);
+}
+
+int vp_morph_u8_dev(vp_ctx* ctx, int op, const uint8_t* d_src, int w, int h, int cn, const uint8_t* kernel, int kw, int kh, int ax, int ay,
+                    int iterations, int binary_hint, uint8_t* d_dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!d_src || !d_dst || d_src == d_dst || w <= 0 || h <= 0 || h > 65535 || cn < 1 || cn > 4 || op < VP_MORPH_ERODE || op > VP_MORPH_GRADIENT)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_morph_u8_dev arguments");
+    norm_se se;
+    if (normalise_se(kernel, kw, kh, ax, ay, iterations, &se) != VP_OK) return vp_fail(ctx, VP_ERR_INVALID, "structuring element");
+    VP_TRY(vp_ws_reserve(ctx, morph_ws_bytes(se, w, h, cn)));
+    return morph_core(ctx, op, se, d_src, w, h, cn, binary_hint, d_dst);
 }
 
 int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, int numbering, int32_t* labels, int32_t* stats,
@@ -745,19 +814,23 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, 
     return vp_synchronize(ctx);
 }
 
-int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, int mode, int method, int32_t* points,
-                        int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours, int64_t* n_points)
+// src: host image (uploaded) or, with src_on_device, a device image read in place
+static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_device, size_t src_stride, int w, int h, int mode, int method,
+                              int32_t* points, int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours,
+                              int64_t* n_points)
 {
     VP_TRY(check_ctx(ctx));
     if (!src || w <= 0 || h <= 0 || src_stride < (size_t)w || !n_contours || !n_points || max_contours < 0 || max_points < 0)
-        return vp_fail(ctx, VP_ERR_INVALID, "vp_find_contours_u8 arguments");
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_find_contours arguments");
     const size_t npx = (size_t)w * h;
     const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
     const int mc = max_contours > 0 ? max_contours : 1;
     const long long mp = max_points > 0 ? max_points : 1;
     VP_TRY(vp_ws_reserve(ctx, vp_align(npx) + vp_align(bitbytes) + vp_contours_ws_bytes(w, h, 1, mc) + vp_align(16 + (size_t)mc * 9) +
                                   vp_align((size_t)mp * 8) + 8192));
-    TAKE(d_src, uint8_t*, npx);
+    TAKE(d_stage, uint8_t*, npx);
+    const uint8_t* d_src = d_stage;
+    size_t d_stride = (size_t)w;
     TAKE(d_bits, u64*, bitbytes);
     // result header, one block so that one copy brings it back: info[2] (16 B) | counts[mc] | offsets[mc] | is_hole[mc]
     const size_t hdr_bytes = 16 + (size_t)mc * 9;
@@ -767,8 +840,9 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int 
     int32_t* d_counts = reinterpret_cast<int32_t*>(d_hdr + 16);
     int32_t* d_offsets = d_counts + mc;
     uint8_t* d_hole = reinterpret_cast<uint8_t*>(d_offsets + mc);
-    VP_TRY(h2d_rows(ctx, d_src, (size_t)w, src, src_stride, (size_t)w, h));
-    VP_TRY(vpk_pack_bits(ctx, d_src, (size_t)w, w, h, 1, d_bits, nullptr));
+    if (src_on_device) { d_src = src; d_stride = src_stride; }
+    else VP_TRY(h2d_rows(ctx, d_stage, (size_t)w, src, src_stride, (size_t)w, h));
+    VP_TRY(vpk_pack_bits(ctx, d_src, d_stride, w, h, 1, d_bits, nullptr));
     VP_TRY(vpk_find_contours(ctx, d_bits, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info));
     // the header and the first points come back under one synchronisation; longer point lists take a second copy
     const size_t spec_pts = points ? (size_t)std::min<long long>(mp, 8192) : 0;
@@ -810,6 +884,19 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int 
         if (is_hole) is_hole[j] = hh[k];
     }
     return VP_OK;
+}
+
+int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, int mode, int method, int32_t* points,
+                        int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours, int64_t* n_points)
+{
+    return find_contours_impl(ctx, src, false, src_stride, w, h, mode, method, points, max_points, counts, is_hole, max_contours, n_contours, n_points);
+}
+
+// the mask is a device image; the contour lists come back to host memory as with vp_find_contours_u8 (synchronised on return)
+int vp_find_contours_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, int w, int h, int mode, int method, int32_t* points,
+                         int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours, int64_t* n_points)
+{
+    return find_contours_impl(ctx, d_src, true, src_stride, w, h, mode, method, points, max_points, counts, is_hole, max_contours, n_contours, n_points);
 }
 
 // ---- chain -------------------------------------------------------------------------------------------

@@ -54,7 +54,6 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
     __shared__ u64 m_nz[CL_ROWS], m_ones[CL_ROWS], m_b63[CL_ROWS];
     __shared__ u32 rowoff[CL_ROWS + 1];
     __shared__ u32 wsum[4];
-    __shared__ c2_box bgp[4];
     __shared__ u32 nroots_s, nqueue_s;
     const int ww = G.ww;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = tid & 31;
@@ -79,58 +78,72 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
     const size_t sidx = (size_t)frame * strips + strip;
     const u64 lastmask = (G.w & 63) ? ((1ull << (G.w & 63)) - 1ull) : ~0ull;
     C2_PROBE_BEGIN;
-    // ---- stage the strip, row masks, bounding box of the zero pixels (the frame's background row needs it) ----------------------
-    c2_box bb = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+    // ---- stage the strip (all loads of a thread first), row masks ---------------------------------------------------------------------
+    // a word is "full" when all its pixels are set (the last word of a row: all its valid pixels; it never hands a run on, so the
+    // run logic may take it as all ones)
     bool multi_mine = false;
-    for (int rr = 0; rr < G.rows; rr += 8) {
-        const int r = rr + (tid >> 5);
-        u64 acc_nz = 0, acc_ones = 0, acc_b63 = 0;     // used by lanes 0 and 32: masks of the row their half-wave holds
-        for (int j0 = 0; j0 < ww; j0 += 32) {
-            const int j = j0 + l32;
-            const bool valid = r < nrows && j < ww;
-            const u64 w = valid ? fb[(size_t)(y0 + r) * ww + j] : 0ull;
-            if (r < G.rows && j < ww) lbits[r * ww + j] = w;
-            multi_mine |= nstarts(w) > 1u;
-            u64 z = ~w;
-            if (j == ww - 1) z &= lastmask;
-            if (valid && z) {
-                bb.minx = min(bb.minx, 64 * j + (__ffsll((long long)z) - 1));
-                bb.maxx = max(bb.maxx, 64 * j + 63 - __clzll(z));
-                bb.miny = min(bb.miny, y0 + r);
-                bb.maxy = max(bb.maxy, y0 + r);
+    {
+        u64 wreg[4][2];                                // (rows / 8) x ceil(ww / 32) <= 4 x 2 words per thread; indices are compile-time
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; b2++) {
+                const int r = a * 8 + (tid >> 5), j = b2 * 32 + l32;
+                wreg[a][b2] = (a * 8 < G.rows && r < nrows && j < ww) ? fb[(size_t)(y0 + r) * ww + j] : 0ull;
             }
-            const u64 b_nz = __ballot(w != 0ull), b_ones = __ballot(w == ~0ull), b_63 = __ballot((w >> 63) != 0ull);
-            const int sh = (lane & 32);                // half of the ballot that belongs to this lane's row
-            acc_nz |= ((b_nz >> sh) & 0xffffffffull) << j0;
-            acc_ones |= ((b_ones >> sh) & 0xffffffffull) << j0;
-            acc_b63 |= ((b_63 >> sh) & 0xffffffffull) << j0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if (a * 8 >= G.rows) break;                // block-uniform
+            const int r = a * 8 + (tid >> 5);
+            u64 acc_nz = 0, acc_full = 0, acc_b63 = 0; // used by lanes 0 and 32: masks of the row their half-wave holds
+#pragma unroll
+            for (int b2 = 0; b2 < 2; b2++) {
+                if (b2 * 32 >= ww) break;
+                const int j = b2 * 32 + l32;
+                const u64 w = wreg[a][b2];
+                if (j < ww) lbits[r * ww + j] = w;
+                multi_mine |= nstarts(w) > 1u;
+                const u64 b_nz = __ballot(w != 0ull), b_full = __ballot(w == (j == ww - 1 ? lastmask : ~0ull)), b_63 = __ballot((w >> 63) != 0ull);
+                const int sh = (lane & 32);            // half of the ballot that belongs to this lane's row
+                acc_nz |= ((b_nz >> sh) & 0xffffffffull) << (b2 * 32);
+                acc_full |= ((b_full >> sh) & 0xffffffffull) << (b2 * 32);
+                acc_b63 |= ((b_63 >> sh) & 0xffffffffull) << (b2 * 32);
+            }
+            if (l32 == 0) { m_nz[r] = acc_nz; m_ones[r] = acc_full; m_b63[r] = acc_b63; }
         }
-        if (l32 == 0 && r < G.rows) { m_nz[r] = acc_nz; m_ones[r] = acc_ones; m_b63[r] = acc_b63; }
     }
     if (tid == 0) { nroots_s = 0; nqueue_s = 0; }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        bb.minx = min(bb.minx, __shfl_xor(bb.minx, d));
-        bb.maxx = max(bb.maxx, __shfl_xor(bb.maxx, d));
-        bb.miny = min(bb.miny, __shfl_xor(bb.miny, d));
-        bb.maxy = max(bb.maxy, __shfl_xor(bb.maxy, d));
-    }
-    if (lane == 0) bgp[wv] = bb;
     const bool any_multi = __syncthreads_or(multi_mine);
-    if (tid == 0) {
-        for (int k = 1; k < 4; k++) {
-            bb.minx = min(bb.minx, bgp[k].minx); bb.maxx = max(bb.maxx, bgp[k].maxx);
-            bb.miny = min(bb.miny, bgp[k].miny); bb.maxy = max(bb.maxy, bgp[k].maxy);
-        }
-        bgbox[sidx] = bb;
-    }
-    // ---- list of the non-zero words, row-major -----------------------------------------------------------------------------------
+    // ---- list of the non-zero words, row-major; bounding box of the zero pixels from the masks (the frame's background row needs it:
+    // a row holds a zero pixel when one of its words is not full; the first / last such word of each row gives the x range) ----------------
     if (wv == 0) {
         const u32 c = lane < G.rows ? (u32)__popcll(m_nz[lane]) : 0u;
         u32 inc = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
         if (lane <= G.rows) rowoff[lane] = inc - c;    // lane == rows: the total (c = 0 there)
+    } else if (wv == 1) {
+        c2_box bb = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+        const u64 colmask = ww >= 64 ? ~0ull : ((1ull << ww) - 1ull);
+        if (lane < nrows) {
+            const u64 nf = ~m_ones[lane] & colmask;    // words of this row that hold a zero pixel
+            if (nf) {
+                const int jf = __ffsll((long long)nf) - 1, jl = 63 - __clzll(nf);
+                const u64 zf = ~lbits[lane * ww + jf] & (jf == ww - 1 ? lastmask : ~0ull);
+                const u64 zl = ~lbits[lane * ww + jl] & (jl == ww - 1 ? lastmask : ~0ull);
+                bb.minx = 64 * jf + (__ffsll((long long)zf) - 1);
+                bb.maxx = 64 * jl + 63 - __clzll(zl);
+                bb.miny = bb.maxy = y0 + lane;
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            bb.minx = min(bb.minx, __shfl_xor(bb.minx, d));
+            bb.maxx = max(bb.maxx, __shfl_xor(bb.maxx, d));
+            bb.miny = min(bb.miny, __shfl_xor(bb.miny, d));
+            bb.maxy = max(bb.maxy, __shfl_xor(bb.maxy, d));
+        }
+        if (lane == 0) bgbox[sidx] = bb;
     }
     __syncthreads();
     const u32 nnz = rowoff[G.rows];
@@ -139,20 +152,24 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
         if (tid == 0) ncomp[sidx] = 0u;
         return;
     }
+    // place of every non-zero word in the list; with one segment per word everywhere that place is also the segment's index
     for (int rr = 0; rr < G.rows; rr += 8) {
         const int r = rr + (tid >> 5);
         const u64 nzr = m_nz[r];
         for (int j0 = 0; j0 < ww; j0 += 32) {
             const int j = j0 + l32;
-            if (j < ww && ((nzr >> j) & 1ull)) nzlist[rowoff[r] + (u32)__popcll(nzr & ((1ull << j) - 1ull))] = (unsigned short)((r << 8) | j);
+            if (j < ww && ((nzr >> j) & 1ull)) {
+                const u32 pos = rowoff[r] + (u32)__popcll(nzr & ((1ull << j) - 1ull));
+                nzlist[pos] = (unsigned short)((r << 8) | j);
+                wbase[r * ww + j] = pos;
+            }
         }
     }
     __syncthreads();
     // ---- index of every word's first segment ------------------------------------------------------------------------------------------
     u32 S;
     if (!any_multi) {
-        S = nnz;                                       // one segment per non-zero word: the index is the place in the list
-        for (u32 t = tid; t < nnz; t += 256) { const u32 e = nzlist[t]; wbase[(e >> 8) * ww + (e & 255u)] = t; }
+        S = nnz;                                       // one segment per non-zero word: wbase is already right
     } else {
         // exclusive scan of the segment counts in list order: thread = CH consecutive entries
         const u32 CH = (nnz + 255u) / 256u;
@@ -175,12 +192,12 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
                 wbase[i] = run;
                 run += nstarts(lbits[i]);
             }
+        if (S > (u32)cap) {                            // block-uniform
+            if (tid == 0) ncomp[sidx] = C2_DENSE;
+            return;
+        }
+        __syncthreads();
     }
-    if (S > (u32)cap) {                                // block-uniform
-        if (tid == 0) ncomp[sidx] = C2_DENSE;
-        return;
-    }
-    __syncthreads();
     C2_PROBE(0, 1);   // word list, segment indices
     // does the first segment of word (r, j) continue a run that comes in from the left?
     auto continues = [&](int r, int j, u64 w) -> bool { return (w & 1ull) && j > 0 && ((m_b63[r] >> (j - 1)) & 1ull); };
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     __shared__ u64 tot_sx, tot_sy;
     __shared__ u32 tot_area;
     __shared__ c2_box bgs;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int ww = G.ww;
     const u64* fb = bits + (size_t)f * G.h * ww;
     const u32* wc = wordcomp + (size_t)f * G.h * ww;

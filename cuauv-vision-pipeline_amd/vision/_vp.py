@@ -99,6 +99,11 @@ _SIGS = {
     "vp_ccl_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vp_find_contours_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "vp_cvt_color_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vp_inrange_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vp_morph_u8_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vp_find_contours_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
     "vp_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.c_int]),
     "vp_chain_run_contours": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(ChainBuffers), C.POINTER(ContourDesc),

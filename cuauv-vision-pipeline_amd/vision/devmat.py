@@ -1,0 +1,279 @@
+"""Images that stay in HBM between operator calls.
+
+The reference's modules call one thin cv2 wrapper after another on numpy arrays (modules/red_buoy.py:21-38).  A literal
+mirror uploads and downloads every image at every call: at 1080p `bgr_to_lab` alone brings 12.4 MB back of which the module
+reads nothing.  `DeviceMat` is what the `vision.utils` mirror returns instead: an array-like whose data lives on the device and
+reaches host memory only when Python looks at it.
+
+  * the next `vision.utils` / cv2-facade call that receives it reads the device copy in place (no transfer);
+  * anything else — numpy functions, indexing, `.copy()`, `np.asarray`, `self.post(...)`, a C extension asking for the buffer —
+    materialises a host copy once (one D2H), and from then on the object behaves like the numpy array it wraps: writable, owned
+    by the caller, mutated in place by `draw_contours`-style code (modules/red_buoy.py:39);
+  * a host copy that may have been written to (handed out writable, indexed for assignment, used as `out=`) invalidates the
+    device copy, so a later operator call uploads the host data again — results never depend on which side was used.
+
+It is not an `np.ndarray` subclass (numpy offers no hook on raw buffer reads, so a subclass could not be lazy); code that
+insists on `isinstance(x, np.ndarray)` can call `np.asarray(x)`.  `VP_LAZY=0` (or `set_lazy(False)`) makes the mirror return
+plain numpy arrays, as in round 1.
+"""
+import ctypes as C
+import os
+import threading
+import weakref
+
+import numpy as np
+
+from vision import _vp
+
+_lazy = os.environ.get("VP_LAZY", "1") != "0"
+
+
+def set_lazy(on: bool):
+    global _lazy
+    _lazy = bool(on)
+
+
+def lazy_enabled() -> bool:
+    return _lazy
+
+
+class _Pool:
+    """Free lists of device buffers of one context, by size class (hipMalloc / hipFree synchronise: never on the per-frame path).
+    Everything on a context runs on its one stream, so a buffer released by the garbage collector can be handed to the next
+    operator at once: the kernels that still read it were enqueued earlier."""
+    CAP_BYTES = 2 << 30
+
+    def __init__(self, ctx):
+        self.ctx = weakref.ref(ctx)
+        self.free = {}
+        self.held = 0
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def size_class(nbytes):
+        n = max(int(nbytes), 256)
+        return (n + 65535) & ~65535 if n > 65536 else 1 << (n - 1).bit_length()
+
+    def take(self, nbytes):
+        cls = self.size_class(nbytes)
+        with self.lock:
+            lst = self.free.get(cls)
+            if lst:
+                self.held -= cls
+                return lst.pop(), cls
+        ctx = self.ctx()
+        p = C.c_void_p()
+        _vp.check(_vp.lib().vp_dev_alloc(ctx.handle, cls, C.byref(p)), ctx.handle)
+        return p.value, cls
+
+    def give(self, ptr, cls):
+        ctx = self.ctx()
+        if ctx is None or not ctx.handle:
+            return                                   # the context is gone and took its device memory with it
+        with self.lock:
+            if self.held + cls <= self.CAP_BYTES:
+                self.free.setdefault(cls, []).append(ptr)
+                self.held += cls
+                return
+        _vp.lib().vp_dev_free(ctx.handle, ptr)
+
+    def drain(self):
+        ctx = self.ctx()
+        with self.lock:
+            ptrs = [p for lst in self.free.values() for p in lst]
+            self.free.clear()
+            self.held = 0
+        if ctx is not None and ctx.handle:
+            for p in ptrs:
+                _vp.lib().vp_dev_free(ctx.handle, p)
+
+
+def pool_of(ctx):
+    p = getattr(ctx, "_pool", None)
+    if p is None:
+        p = ctx._pool = _Pool(ctx)
+    return p
+
+
+class _DevBuf:
+    """One device allocation; returns to its pool when the last DeviceMat (or view bookkeeping) drops it."""
+    __slots__ = ("ptr", "cls", "pool", "__weakref__")
+
+    def __init__(self, ctx, nbytes):
+        self.pool = pool_of(ctx)
+        self.ptr, self.cls = self.pool.take(nbytes)
+
+    def __del__(self):
+        try:
+            self.pool.give(self.ptr, self.cls)
+        except Exception:
+            pass
+
+
+class DeviceMat:
+    """(h, w) or (h, w, c) image, tightly packed, whose authoritative copy may be on the device (`_dev_ok`), on the host
+    (`_host` is not None and `_host_ok`), or both."""
+    __array_priority__ = 100.0
+    __slots__ = ("_ctx", "_buf", "_shape", "_dtype", "_host", "_dev_ok", "binary", "__weakref__")
+
+    def __init__(self, ctx, shape, dtype=np.uint8, binary=False):
+        self._ctx = ctx
+        self._shape = tuple(int(s) for s in shape)
+        self._dtype = np.dtype(dtype)
+        self._buf = _DevBuf(ctx, int(np.prod(self._shape)) * self._dtype.itemsize)
+        self._host = None
+        self._dev_ok = True
+        self.binary = bool(binary)          # known to hold only 0 / 255 (a mask made by this library)
+
+    # ---- what the operator wrappers use ------------------------------------------------------------------------------------
+    @property
+    def dev_ptr(self):
+        return self._buf.ptr
+
+    def device_valid_for(self, ctx):
+        return self._dev_ok and ctx is self._ctx and bool(ctx.handle)
+
+    @classmethod
+    def from_host(cls, ctx, arr, binary=False):
+        """Uploads a packed host array; the host array is NOT kept (the caller may go on mutating it)."""
+        arr = np.ascontiguousarray(arr)
+        m = cls(ctx, arr.shape, arr.dtype, binary)
+        _vp.check(_vp.lib().vp_memcpy_h2d(ctx.handle, m._buf.ptr, arr.ctypes.data, arr.nbytes), ctx.handle)
+        return m
+
+    def host(self, writable=True):
+        """The host copy (one D2H the first time).  Handing it out writable makes it the authoritative copy."""
+        if self._host is None:
+            out = np.empty(self._shape, self._dtype)
+            ctx = self._ctx
+            if not ctx.handle:
+                raise _vp.VpError("the context that owns this image was closed before the image was read")
+            _vp.check(_vp.lib().vp_memcpy_d2h(ctx.handle, out.ctypes.data, self._buf.ptr, out.nbytes), ctx.handle)
+            self._host = out
+        if writable:
+            self._dev_ok = False
+            self.binary = False
+            return self._host
+        v = self._host.view()
+        v.flags.writeable = False
+        return v
+
+    def refresh_device(self, ctx):
+        """Device copy of the current contents on `ctx` (re-uploads after host-side writes or a change of context)."""
+        if self.device_valid_for(ctx):
+            return self._buf.ptr
+        h = self.host(writable=False)
+        if ctx is not self._ctx:
+            self._ctx = ctx
+            self._buf = _DevBuf(ctx, h.nbytes)
+        _vp.check(_vp.lib().vp_memcpy_h2d(ctx.handle, self._buf.ptr, h.ctypes.data, h.nbytes), ctx.handle)
+        self._dev_ok = True
+        return self._buf.ptr
+
+    # ---- array protocol -----------------------------------------------------------------------------------------------------------
+    shape = property(lambda self: self._shape)
+    dtype = property(lambda self: self._dtype)
+    ndim = property(lambda self: len(self._shape))
+    size = property(lambda self: int(np.prod(self._shape)))
+    nbytes = property(lambda self: int(np.prod(self._shape)) * self._dtype.itemsize)
+    itemsize = property(lambda self: self._dtype.itemsize)
+
+    def __len__(self):
+        return self._shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        h = self.host(writable=True)
+        if dtype is not None and np.dtype(dtype) != h.dtype:
+            return h.astype(dtype)
+        return h.copy() if copy else h
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        def conv(x, w):
+            return x.host(writable=w) if isinstance(x, DeviceMat) else x
+        ins = tuple(conv(x, False) for x in inputs)
+        if "out" in kwargs:
+            kwargs["out"] = tuple(conv(x, True) for x in kwargs["out"])
+        return getattr(ufunc, method)(*ins, **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        def conv(x):
+            if isinstance(x, DeviceMat):
+                return x.host(writable=True)
+            if isinstance(x, (list, tuple)):
+                return type(x)(conv(y) for y in x)
+            if isinstance(x, dict):
+                return {k: conv(v) for k, v in x.items()}
+            return x
+        return func(*conv(args), **conv(kwargs))
+
+    def __getitem__(self, key):
+        return self.host(writable=True)[key]         # views of the host copy can be written through
+
+    def __setitem__(self, key, value):
+        if isinstance(value, DeviceMat):
+            value = value.host(writable=False)
+        self.host(writable=True)[key] = value
+
+    def __iter__(self):
+        return iter(self.host(writable=True))
+
+    def __getattr__(self, name):                     # everything else an ndarray has: .copy(), .astype(), .sum(), .T, .ctypes, .flags ...
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.host(writable=True), name)
+
+    def __repr__(self):
+        where = "device" if self._host is None else ("host+device" if self._dev_ok else "host")
+        return f"DeviceMat(shape={self._shape}, dtype={self._dtype}, on={where})"
+
+    def __bool__(self):
+        return bool(self.host(writable=False))
+
+    def __eq__(self, other):
+        return np.equal(self, other)
+
+    def __ne__(self, other):
+        return np.not_equal(self, other)
+
+    __hash__ = None
+
+
+def _binop(name, ufunc, swap=False):
+    def f(self, other):
+        return ufunc(other, self) if swap else ufunc(self, other)
+    f.__name__ = name
+    return f
+
+
+def _iop(name, ufunc):
+    def f(self, other):
+        h = self.host(writable=True)
+        ufunc(h, other.host(writable=False) if isinstance(other, DeviceMat) else other, out=h)
+        return self
+    f.__name__ = name
+    return f
+
+
+for _n, _u in (("add", np.add), ("sub", np.subtract), ("mul", np.multiply), ("truediv", np.true_divide), ("floordiv", np.floor_divide),
+               ("mod", np.remainder), ("pow", np.power), ("and", np.bitwise_and), ("or", np.bitwise_or), ("xor", np.bitwise_xor),
+               ("lshift", np.left_shift), ("rshift", np.right_shift), ("matmul", np.matmul)):
+    setattr(DeviceMat, f"__{_n}__", _binop(f"__{_n}__", _u))
+    setattr(DeviceMat, f"__r{_n}__", _binop(f"__r{_n}__", _u, swap=True))
+    if _n != "matmul":
+        setattr(DeviceMat, f"__i{_n}__", _iop(f"__i{_n}__", _u))
+for _n, _u in (("lt", np.less), ("le", np.less_equal), ("gt", np.greater), ("ge", np.greater_equal)):
+    setattr(DeviceMat, f"__{_n}__", _binop(f"__{_n}__", _u))
+DeviceMat.__neg__ = lambda self: np.negative(self)
+DeviceMat.__pos__ = lambda self: np.positive(self)
+DeviceMat.__abs__ = lambda self: np.absolute(self)
+DeviceMat.__invert__ = lambda self: np.invert(self)
+
+
+def to_host(x):
+    """np.ndarray for either kind (the caller may write to it)."""
+    return x.host(writable=True) if isinstance(x, DeviceMat) else x
+
+
+def to_host_readonly(x):
+    """Host data for reading only: does not give up the device copy (self.post, drawing sources, comparisons)."""
+    return x.host(writable=False) if isinstance(x, DeviceMat) else x

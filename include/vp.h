@@ -153,6 +153,24 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride,
                         int32_t* points_host, int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours,
                         int32_t* n_contours, int64_t* n_points);
 
+/* ---- device-resident forms of the per-operator entry points ----------------------------- *
+ * Same arithmetic and argument meaning as vp_cvt_color_u8 / vp_inrange_u8 / vp_morph_u8 / vp_find_contours_u8; images are
+ * device pointers.  Nothing is copied; the first three enqueue on the context's stream and return without synchronising, so a
+ * module's process() (modules/red_buoy.py:21-38: bgr_to_lab -> range_threshold -> morph_remove_noise -> morph_close_holes ->
+ * outer_contours) uploads its frame once and downloads only what Python reads (the Python mirror hands these images around as
+ * lazily materialised arrays, vision/devmat.py).  vp_morph_u8_dev: dst must not overlap src; binary_hint 1 = the image is known
+ * to hold only 0 / 255 (a mask this library produced), 0 = unknown (one flag is then read back, synchronising).
+ * vp_find_contours_dev returns the lists in host memory and synchronises, like its host form. */
+int vp_cvt_color_dev(vp_ctx* ctx, int code, const uint8_t* src_dev, size_t src_stride, int w, int h, uint8_t* dst_interleaved_dev,
+                     uint8_t* const* dst_planes_dev);
+int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, int w, int h, int cn, const int32_t* lo, const int32_t* hi,
+                      uint8_t* dst_dev);
+int vp_morph_u8_dev(vp_ctx* ctx, int op, const uint8_t* src_dev, int w, int h, int cn, const uint8_t* kernel, int kw, int kh,
+                    int anchor_x, int anchor_y, int iterations, int binary_hint, uint8_t* dst_dev);
+int vp_find_contours_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, int w, int h, int mode, int method,
+                         int32_t* points_host, int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours,
+                         int32_t* n_contours, int64_t* n_points);
+
 /* ---- fused, batched, device-resident chain -------------------------------------------- */
 
 #define VP_CHAIN_MAX_MORPH 8
