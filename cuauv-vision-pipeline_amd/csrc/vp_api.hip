@@ -739,6 +739,111 @@ int vp_morph_u8(vp_ctx* ctx, int op, const uint8_t* src, int w, int h, int cn, c
     return vp_synchronize(ctx);
 }
 
+// ---- debug overlays (host only, no device work) -----------------------------------------------------------------------------
+// utils/draw.py:283-327 draw_contours / draw_polylines modify the caller's host image in place on every frame
+// (modules/red_buoy.py:39).  The Python mirror's rasteriser (Bresenham steps, square brush of the requested thickness) is the
+// same statement sequence here in C, because at 1080p a dozen contours of a few hundred points are 10^4 brush stamps per frame.
+// utils/feature.py:240-265 contour_centroid / contour_area (cv2.moments, cv2.contourArea on an integer contour): the three Green sums
+// a00 = sum(x[i-1] y[i] - x[i] y[i-1]), a10 = sum(d (x[i-1] + x[i])), a01 = sum(d (y[i-1] + y[i])) as exact integers (host code).
+int vp_polygon_sums_i32(const int32_t* pts, int npts, int64_t* out3)
+{
+    if (!pts || !out3 || npts < 0) return VP_ERR_INVALID;
+    long long a00 = 0, a10 = 0, a01 = 0;
+    if (npts > 0) {
+        long long xp = pts[2 * (npts - 1)], yp = pts[2 * (npts - 1) + 1];
+        for (int i = 0; i < npts; i++) {
+            const long long x = pts[2 * i], y = pts[2 * i + 1];
+            const long long d = xp * y - x * yp;
+            a00 += d; a10 += d * (xp + x); a01 += d * (yp + y);
+            xp = x; yp = y;
+        }
+    }
+    out3[0] = a00; out3[1] = a10; out3[2] = a01;
+    return VP_OK;
+}
+
+// counts[k] points per polyline, back to back in pts; one call draws them all (a frame's contours)
+int vp_draw_polylines_u8(uint8_t* img, size_t stride, int w, int h, int cn, const int32_t* pts, const int32_t* counts, int npolys, int closed,
+                         const uint8_t* color, int thickness)
+{
+    if (!img || !pts || !counts || !color || w <= 0 || h <= 0 || cn < 1 || cn > 4 || npolys < 0 || stride < (size_t)w * cn) return VP_ERR_INVALID;
+    if (thickness < 1) thickness = 1;
+    const int r0 = (thickness - 1) / 2, r1 = thickness / 2;
+    // one brush row of colour, for memcpy
+    std::vector<uint8_t> pat((size_t)(thickness + 1) * cn);
+    for (int i = 0; i <= thickness; i++)
+        for (int c = 0; c < cn; c++) pat[(size_t)i * cn + c] = color[c];
+    auto fill = [&](int xa, int xb, int ya, int yb) {      // [xa, xb) x [ya, yb), clipped
+        xa = std::max(xa, 0); xb = std::min(xb, w); ya = std::max(ya, 0); yb = std::min(yb, h);
+        if (xa >= xb || ya >= yb) return;
+        uint8_t* row = img + (size_t)ya * stride + (size_t)xa * cn;
+        const size_t nb = (size_t)(xb - xa) * cn;
+        if (xb - xa == 1 && cn == 3) {                     // the column a horizontal step adds
+            for (int yy = ya; yy < yb; yy++, row += stride) { row[0] = color[0]; row[1] = color[1]; row[2] = color[2]; }
+        } else if (nb <= pat.size()) {
+            for (int yy = ya; yy < yb; yy++, row += stride) memcpy(row, pat.data(), nb);
+        } else {
+            for (int yy = ya; yy < yb; yy++, row += stride)
+                for (size_t o = 0; o < nb; o += cn) memcpy(row + o, color, (size_t)cn);
+        }
+    };
+    // The brush is a square stamped at every Bresenham step.  A step moves by at most one pixel per axis, so the square at the new
+    // position adds one column and / or one row to what the previous stamp covered: only that strip is written (the union of the
+    // stamps, i.e. the image, is the same as with full stamps).
+    bool have = false;
+    int lx = 0, ly = 0;
+    auto stamp = [&](int x, int y) {
+        if (have && x == lx && y == ly) return;
+        if (have && abs(x - lx) <= 1 && abs(y - ly) <= 1) {
+            if (x != lx) { const int cx = x > lx ? x + r1 : x - r0; fill(cx, cx + 1, y - r0, y + r1 + 1); }
+            if (y != ly) { const int cy = y > ly ? y + r1 : y - r0; fill(x - r0, x + r1 + 1, cy, cy + 1); }
+        } else {
+            fill(x - r0, x + r1 + 1, y - r0, y + r1 + 1);
+        }
+        have = true; lx = x; ly = y;
+    };
+    auto line = [&](int x0, int y0, int x1, int y1) {
+        if (abs(x1 - x0) <= 1 && abs(y1 - y0) <= 1) {       // neighbouring pixels (most steps of a traced contour): no stepping needed
+            stamp(x0, y0);
+            if (x1 != x0 || y1 != y0) stamp(x1, y1);
+            return;
+        }
+        const int dx = abs(x1 - x0), dy = -abs(y1 - y0);
+        const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+        long long err = (long long)dx + dy;
+        for (;;) {
+            stamp(x0, y0);
+            if (x0 == x1 && y0 == y1) break;
+            const long long e2 = 2 * err;
+            if (e2 >= dy) { err += dy; x0 += sx; }
+            if (e2 <= dx) { err += dx; y0 += sy; }
+        }
+    };
+    size_t o = 0;
+    for (int k = 0; k < npolys; k++) {
+        const int npts = counts[k];
+        if (npts < 0) return VP_ERR_INVALID;
+        const int32_t* p = pts + 2 * o;
+        o += (size_t)npts;
+        have = false;
+        if (npts == 0) continue;
+        if (npts == 1) { line(p[0], p[1], p[0], p[1]); continue; }
+        const int last = closed ? npts : npts - 1;
+        for (int i = 0; i < last; i++) {
+            const int j = i + 1 < npts ? i + 1 : 0;
+            line(p[2 * i], p[2 * i + 1], p[2 * j], p[2 * j + 1]);
+        }
+    }
+    return VP_OK;
+}
+
+int vp_draw_polyline_u8(uint8_t* img, size_t stride, int w, int h, int cn, const int32_t* pts, int npts, int closed, const uint8_t* color,
+                        int thickness)
+{
+    const int32_t cnt = npts;
+    return vp_draw_polylines_u8(img, stride, w, h, cn, pts, &cnt, 1, closed, color, thickness);
+}
+
 // ---- device-resident forms of the per-operator entry points ---------------------------------------------------------------------
 // Same arithmetic, same argument meaning; images are device pointers (packed rows unless a stride is taken), nothing is copied
 // and nothing is synchronised: the call enqueues on the context's stream and returns.  They let the Python mirror keep the

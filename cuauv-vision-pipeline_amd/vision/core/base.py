@@ -24,6 +24,7 @@ import numpy as np
 
 from vision.core.bindings.camera_message_framework import BLOCK_STUB, BlockAccessor, ReadStatus
 from vision.core.tuners import BoolTuner, DoubleTuner, IntTuner, TunerBase
+from vision.core.frames import copy_frame
 from vision.utils.helpers import as_mat
 
 try:  # the CUAUV logging daemon client, when the monorepo is around
@@ -476,7 +477,7 @@ class ModuleBase:
                 source, image, acq_time = message.source, message.data, message.acquisition_time
                 if message.status == ReadStatus.SUCCESS and image is not None:
                     # the arrays view the library's read buffer: hand module code its own writable copies
-                    image = tuple(np.array(p, copy=True) for p in image) if isinstance(image, tuple) else np.array(image, copy=True)
+                    image = tuple(copy_frame(p) for p in image) if isinstance(image, tuple) else copy_frame(image)
                     self._update_metadata_for_direction(source.name, image, acq_time)
                     self._current_direction = source.name
                     if isinstance(image, tuple):

@@ -141,6 +141,16 @@ class DeviceMat:
         _vp.check(_vp.lib().vp_memcpy_h2d(ctx.handle, m._buf.ptr, arr.ctypes.data, arr.nbytes), ctx.handle)
         return m
 
+    def reshaped(self, shape):
+        """Same data under another shape (e.g. (h, w, 1) -> (h, w)); shares the device buffer, copies nothing."""
+        m = object.__new__(DeviceMat)
+        m._ctx, m._buf, m._dtype, m._dev_ok, m.binary = self._ctx, self._buf, self._dtype, self._dev_ok, self.binary
+        m._shape = tuple(int(x) for x in shape)
+        m._host = None if self._host is None else self._host.reshape(m._shape)
+        if not self._dev_ok and m._host is None:
+            raise RuntimeError("image has neither a valid device nor a host copy")
+        return m
+
     def host(self, writable=True):
         """The host copy (one D2H the first time).  Handing it out writable makes it the authoritative copy."""
         if self._host is None:

@@ -11,11 +11,12 @@ from typing import Callable, List, Tuple
 import numpy as np
 
 from vision import _vp
-from vision.utils.helpers import as_mat
+from vision.devmat import DeviceMat, lazy_enabled, to_host
+from vision.utils.helpers import as_mat, device_image
 
 
 def _u8_image(mat, channels):
-    mat = as_mat(mat)
+    mat = to_host(as_mat(mat))
     if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
         raise TypeError("expected a uint8 numpy image")
     if channels == 3 and not (mat.ndim == 3 and mat.shape[2] == 3):
@@ -39,7 +40,28 @@ def _convert_colorspace(code: int) -> Callable[[np.ndarray], Tuple[np.ndarray, T
     dcn = 1 if code == _vp.BGR2GRAY else 3
     want_planes = code != _vp.HSV2BGR
 
+    def _inner_device(mat):
+        """The image stays in HBM: results are DeviceMat (vision/devmat.py), nothing is downloaded here."""
+        ctx = _vp.default_context()
+        src = device_image(ctx, mat, scn)
+        h, w = src.shape[:2]
+        conv = DeviceMat(ctx, (h, w) if dcn == 1 else (h, w, 3))
+        planes = [DeviceMat(ctx, (h, w)) for _ in range(dcn)] if (dcn == 3 and want_planes) else []
+        arr = (_vp.C.c_void_p * 3)(*[p.dev_ptr for p in planes], *([None] * (3 - len(planes))))
+        _vp.check(_vp.lib().vp_cvt_color_dev(ctx.handle, code, src.dev_ptr, w * scn, w, h, conv.dev_ptr, arr if planes else None), ctx.handle)
+        if not want_planes:                           # HSV2BGR (colour-balance helper): channel copies are host views
+            hc = conv.host(writable=False)
+            return conv, tuple(np.ascontiguousarray(hc[:, :, c]) for c in range(3))
+        if planes:
+            return conv, tuple(planes)
+        second = DeviceMat(ctx, (h, w))               # cv2.split of a single-channel image: a 1-tuple holding a copy
+        _vp.check(_vp.lib().vp_cvt_color_dev(ctx.handle, code, src.dev_ptr, w * scn, w, h, second.dev_ptr, None), ctx.handle)
+        return conv, (second,)
+
     def _inner(mat: np.ndarray):
+        mat = as_mat(mat)
+        if lazy_enabled() or isinstance(mat, DeviceMat):
+            return _inner_device(mat)
         mat = _u8_image(mat, scn)
         h, w = mat.shape[:2]
         conv = np.empty((h, w) if dcn == 1 else (h, w, 3), np.uint8)
@@ -124,6 +146,8 @@ def range_threshold(mat: np.ndarray, min, max) -> np.ndarray:
     conversion), or float32 single-channel input (the `dists` image of thresh_color_distance)."""
     mat = as_mat(mat)
     ctx = _vp.default_context()
+    if isinstance(mat, DeviceMat) and mat.dtype != np.uint8:
+        mat = mat.host()
     if isinstance(mat, np.ndarray) and mat.dtype == np.float32:
         if mat.ndim == 3 and mat.shape[2] == 1:
             mat = mat[:, :, 0]
@@ -137,8 +161,9 @@ def range_threshold(mat: np.ndarray, min, max) -> np.ndarray:
         hi = float(np.float32(np.ravel(max)[0] if np.ndim(max) else max))
         _vp.check(_vp.lib().vp_inrange_f32(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, lo, hi, _vp.ptr(out)), ctx.handle)
         return out
-    cn = 3 if (isinstance(mat, np.ndarray) and mat.ndim == 3 and mat.shape[2] == 3) else 1
-    mat = _u8_image(mat, cn)
+    cn = 3 if (isinstance(mat, (np.ndarray, DeviceMat)) and mat.ndim == 3 and mat.shape[2] == 3) else 1
+    on_device = lazy_enabled() or isinstance(mat, DeviceMat)
+    mat = device_image(ctx, mat, cn) if on_device else _u8_image(mat, cn)
     h, w = mat.shape[:2]
 
     def bounds(b):
@@ -149,6 +174,10 @@ def range_threshold(mat: np.ndarray, min, max) -> np.ndarray:
             raise ValueError("bounds need one value per channel")
         return np.ascontiguousarray(np.clip(np.rint(b[:cn]), -2**31, 2**31 - 1).astype(np.int32))
     lo, hi = bounds(min), bounds(max)
+    if on_device:
+        out = DeviceMat(ctx, (h, w), binary=True)
+        _vp.check(_vp.lib().vp_inrange_u8_dev(ctx.handle, mat.dev_ptr, w * cn, w, h, cn, _vp.ptr(lo), _vp.ptr(hi), out.dev_ptr), ctx.handle)
+        return out
     out = np.empty((h, w), np.uint8)
     _vp.check(_vp.lib().vp_inrange_u8(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, cn, _vp.ptr(lo), _vp.ptr(hi), _vp.ptr(out)), ctx.handle)
     return out
@@ -207,7 +236,7 @@ def _outside_path(name):
 
 def _threshold(mat: np.ndarray, thresh: float, maxval: float, kind: int) -> np.ndarray:
     """cv2.threshold(mat, thresh, maxval, kind)[1] on uint8 images (libvp vp_threshold_u8)."""
-    mat = as_mat(mat)
+    mat = to_host(as_mat(mat))
     if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8 or mat.size == 0:
         raise TypeError("expected a non-empty uint8 numpy image")
     mat = np.ascontiguousarray(mat)

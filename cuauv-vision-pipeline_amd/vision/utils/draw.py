@@ -54,10 +54,42 @@ def _fill(mat, pts, color):
                 mat[y, xa:xb + 1] = color
 
 
+def _native_polylines(mat, polys, closed, color, thickness):
+    """The same rasteriser in C (libvp vp_draw_polylines_u8, host code), all polylines in one call: returns False when the image
+    cannot be handed over as is."""
+    if not (isinstance(mat, np.ndarray) and mat.dtype == np.uint8 and mat.ndim in (2, 3) and mat.flags.writeable):
+        return False
+    cn = 1 if mat.ndim == 2 else mat.shape[2]
+    if cn > 4 or mat.strides[-1] != 1 or (mat.ndim == 3 and mat.strides[1] != cn) or mat.strides[0] < mat.shape[1] * cn:
+        return False
+    try:
+        from vision import _vp
+        lib = _vp.lib()
+    except Exception:
+        return False
+    polys = [np.asarray(p).reshape(-1, 2) for p in polys]
+    if not polys:
+        return True
+    counts = np.fromiter((len(p) for p in polys), np.int32, len(polys))
+    p32 = np.ascontiguousarray(np.concatenate(polys) if len(polys) > 1 else polys[0], np.int32)
+    col = np.zeros(4, np.uint8)
+    col[:cn] = np.asarray(color, np.uint8).ravel()[:cn] if np.ndim(color) else np.uint8(color)
+    return lib.vp_draw_polylines_u8(mat.ctypes.data, mat.strides[0], mat.shape[1], mat.shape[0], cn, p32.ctypes.data, counts.ctypes.data,
+                                    len(polys), int(bool(closed)), col.ctypes.data, int(thickness)) == 0
+
+
+def _native_polyline(mat, pts, closed, color, thickness):
+    return _native_polylines(mat, [pts], closed, color, thickness)
+
+
 def draw_polylines(mat: np.ndarray, points, isClosed: bool = False, color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
     """utils/draw.py:304-327; modifies `mat` in place."""
+    from vision.devmat import to_host
+    mat = to_host(mat)
     pts = np.asarray(points, np.int64).reshape(-1, 2)
     if len(pts) == 0:
+        return
+    if thickness >= 0 and _native_polyline(mat, pts, isClosed, color, max(thickness, 1)):
         return
     color = np.asarray(color, mat.dtype)[: (mat.shape[2] if mat.ndim == 3 else 1)]
     if mat.ndim == 2:
@@ -74,6 +106,10 @@ def draw_polylines(mat: np.ndarray, points, isClosed: bool = False, color: Tuple
 
 def draw_contours(mat: np.ndarray, contours: List[np.ndarray], color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
     """utils/draw.py:283-301 (cv2.drawContours(mat, contours, -1, color, thickness)); modifies `mat` in place."""
+    from vision.devmat import to_host
+    mat = to_host(mat)
+    if thickness >= 0 and _native_polylines(mat, contours, True, color, max(thickness, 1)):
+        return
     for c in contours:
         draw_polylines(mat, c, True, color, thickness)
 

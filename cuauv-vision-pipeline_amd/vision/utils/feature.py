@@ -10,14 +10,15 @@ from typing import List, Tuple
 import numpy as np
 
 from vision import _vp
-from vision.utils.helpers import as_mat
+from vision.devmat import DeviceMat, to_host_readonly
+from vision.utils.helpers import as_mat, device_image
 
 
 def connected_components(mat: np.ndarray, numbering: int = _vp.CCL_BLOCK2X2, max_labels: int = 4096,
                          want_labels: bool = True):
     """Returns (nlabels, labels int32 (h,w) or None, stats int32 (k,5), centroids float64 (k,2)),
     k = min(nlabels, max_labels); row 0 is the background, like cv2."""
-    mat = as_mat(mat)
+    mat = to_host_readonly(as_mat(mat))
     if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
         raise TypeError("expected a uint8 mask")
     if mat.ndim == 3 and mat.shape[2] == 1:
@@ -38,13 +39,36 @@ def connected_components(mat: np.ndarray, numbering: int = _vp.CCL_BLOCK2X2, max
     return n.value, labels, stats[:k].copy(), cent[:k].copy()
 
 
+def _green_sums(pts):
+    """(a00, a10, a01) of an integer contour as Python ints: one native pass (libvp vp_polygon_sums_i32, host code)."""
+    p32 = pts if (pts.dtype == np.int32 and pts.flags.c_contiguous) else np.ascontiguousarray(pts, np.int32)
+    out = np.empty(3, np.int64)
+    _vp.check(_vp.lib().vp_polygon_sums_i32(p32.ctypes.data, len(p32), out.ctypes.data))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def _polygon_moments(contour: np.ndarray):
     """cv2.moments on an (N,1,2) int contour (imgproc/src/moments.cpp contourMoments): Green's theorem,
-    float64; m00 made non-negative together with the first moments."""
-    pts = np.asarray(contour).reshape(-1, 2).astype(np.float64)
+    float64; m00 made non-negative together with the first moments.  The sums run over integers (coordinates below 2^15, so every
+    partial sum stays below 2^53): summed in int64 here, they equal the sequential float64 loop of the C++ code bit for bit."""
+    pts = np.asarray(contour).reshape(-1, 2)
     n = len(pts)
     if n == 0:
         return 0.0, 0.0, 0.0
+    if not np.issubdtype(pts.dtype, np.integer):
+        return _polygon_moments_float(pts.astype(np.float64))
+    a00, a10, a01 = (float(v) for v in _green_sums(pts))
+    if abs(a00) > 1.1920929e-07:
+        if a00 > 0:
+            db1_2, db1_6 = 0.5, 1.0 / 6
+        else:
+            db1_2, db1_6 = -0.5, -1.0 / 6
+        return a00 * db1_2, a10 * db1_6, a01 * db1_6
+    return 0.0, 0.0, 0.0
+
+
+def _polygon_moments_float(pts):
+    n = len(pts)
     a00 = a10 = a01 = 0.0
     xi_1, yi_1 = pts[n - 1]
     for i in range(n):
@@ -72,10 +96,13 @@ def contour_centroid(contour: np.ndarray) -> Tuple[int, int]:
 
 def contour_area(contour: np.ndarray) -> float:
     """utils/feature.py:255-265 (cv2.contourArea, oriented=False): |shoelace| / 2."""
-    pts = np.asarray(contour).reshape(-1, 2).astype(np.float64)
+    pts = np.asarray(contour).reshape(-1, 2)
     n = len(pts)
     if n == 0:
         return 0.0
+    if np.issubdtype(pts.dtype, np.integer):         # integer sums: exact, equal to the sequential float64 loop (see _polygon_moments)
+        return abs(float(_green_sums(pts)[0]) * 0.5)
+    pts = pts.astype(np.float64)
     a00 = 0.0
     prev = pts[n - 1]
     for i in range(n):
@@ -138,24 +165,35 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
     """cv2.findContours(mat, mode, method)[0] on the GPU (libvp vp_find_contours_u8): tuple of (N,1,2) int32 arrays of
     (x, y) points, newest contour first like cv2."""
     mat = as_mat(mat)
-    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
-        raise TypeError("expected a uint8 mask")
-    if mat.ndim == 3 and mat.shape[2] == 1:
-        mat = mat[:, :, 0]
-    if mat.ndim != 2 or mat.size == 0:
-        raise ValueError("expected a non-empty (h, w) mask")
-    if mat.strides[1] != 1:
-        mat = np.ascontiguousarray(mat)
-    h, w = mat.shape
     ctx = _vp.default_context()
+    dev = None
+    if isinstance(mat, DeviceMat):                     # the mask is already in HBM (range_threshold / morphology result): read it there
+        if mat.dtype != np.uint8:
+            raise TypeError("expected a uint8 mask")
+        dev = device_image(ctx, mat, 1)
+        h, w = dev.shape
+    else:
+        if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
+            raise TypeError("expected a uint8 mask")
+        if mat.ndim == 3 and mat.shape[2] == 1:
+            mat = mat[:, :, 0]
+        if mat.ndim != 2 or mat.size == 0:
+            raise ValueError("expected a non-empty (h, w) mask")
+        if mat.strides[1] != 1:
+            mat = np.ascontiguousarray(mat)
+        h, w = mat.shape
     max_c, max_p = 256, 1 << 14
     while True:
         pts = np.empty((max_p, 2), np.int32)
         counts = np.empty(max_c, np.int32)
         holes = np.empty(max_c, np.uint8)
         nc, npts = _vp.C.c_int32(0), _vp.C.c_int64(0)
-        _vp.check(_vp.lib().vp_find_contours_u8(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, int(mode), int(method), _vp.ptr(pts), max_p,
-                                                _vp.ptr(counts), _vp.ptr(holes), max_c, _vp.C.byref(nc), _vp.C.byref(npts)), ctx.handle)
+        if dev is not None:
+            _vp.check(_vp.lib().vp_find_contours_dev(ctx.handle, dev.dev_ptr, w, w, h, int(mode), int(method), _vp.ptr(pts), max_p,
+                                                     _vp.ptr(counts), _vp.ptr(holes), max_c, _vp.C.byref(nc), _vp.C.byref(npts)), ctx.handle)
+        else:
+            _vp.check(_vp.lib().vp_find_contours_u8(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, int(mode), int(method), _vp.ptr(pts), max_p,
+                                                    _vp.ptr(counts), _vp.ptr(holes), max_c, _vp.C.byref(nc), _vp.C.byref(npts)), ctx.handle)
         if nc.value <= max_c and npts.value <= max_p:
             break
         max_c = max(max_c, 2 * nc.value)

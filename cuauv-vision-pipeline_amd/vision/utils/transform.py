@@ -9,7 +9,8 @@ from typing import Optional
 import numpy as np
 
 from vision import _vp
-from vision.utils.helpers import as_mat
+from vision.devmat import DeviceMat, lazy_enabled
+from vision.utils.helpers import as_mat, device_image
 
 
 def _structuring_element(shape, x, y):
@@ -38,11 +39,8 @@ def rect_kernel(x: int, y: Optional[int] = None) -> np.ndarray:
 
 def _morph(op, mat, kernel, iterations, anchor=(-1, -1)):
     mat = as_mat(mat)
-    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8 or mat.ndim not in (2, 3):
+    if not isinstance(mat, (np.ndarray, DeviceMat)) or mat.dtype != np.uint8 or mat.ndim not in (2, 3):
         raise TypeError("expected a uint8 (h, w) or (h, w, c) image")
-    src = np.ascontiguousarray(mat)
-    h, w = src.shape[:2]
-    cn = 1 if src.ndim == 2 else src.shape[2]
     if kernel is None or np.size(kernel) == 0:
         kp, kw, kh = None, 0, 0
     else:
@@ -51,8 +49,20 @@ def _morph(op, mat, kernel, iterations, anchor=(-1, -1)):
             raise ValueError("kernel must be 2-D")
         kh, kw = kernel.shape
         kp = _vp.ptr(kernel)
-    out = np.empty_like(src)
     ctx = _vp.default_context()
+    if (lazy_enabled() or isinstance(mat, DeviceMat)) and mat.size and (mat.ndim == 2 or mat.shape[2] <= 4):
+        # device-resident: the result stays in HBM; a mask known to be 0/255 takes the bit-plane path without a flag read-back
+        src = device_image(ctx, mat, 0)
+        h, w = src.shape[:2]
+        cn = 1 if src.ndim == 2 else src.shape[2]
+        out = DeviceMat(ctx, src.shape, binary=src.binary)
+        _vp.check(_vp.lib().vp_morph_u8_dev(ctx.handle, op, src.dev_ptr, w, h, cn, kp, kw, kh, int(anchor[0]), int(anchor[1]), int(iterations),
+                                            1 if src.binary else 0, out.dev_ptr), ctx.handle)
+        return out
+    src = np.ascontiguousarray(mat)
+    h, w = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    out = np.empty_like(src)
     _vp.check(_vp.lib().vp_morph_u8(ctx.handle, op, _vp.ptr(src), w, h, cn, kp, kw, kh, int(anchor[0]), int(anchor[1]),
                                     int(iterations), _vp.ptr(out)), ctx.handle)
     return out

@@ -153,6 +153,20 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride,
                         int32_t* points_host, int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours,
                         int32_t* n_contours, int64_t* n_points);
 
+/* utils/feature.py:240-265 `contour_centroid` / `contour_area` (cv2.moments / cv2.contourArea of an integer contour): the Green sums
+ * out3 = {sum d, sum d (x' + x), sum d (y' + y)}, d = x' y - x y' over consecutive points (x', y') -> (x, y), as exact integers;
+ * host code, no context.  The Python mirror applies cv2's factors 1/2 and 1/6 in float64. */
+int vp_polygon_sums_i32(const int32_t* pts_xy, int npts, int64_t* out3);
+
+/* utils/draw.py:283-327 `draw_contours` / `draw_polylines` (modules/red_buoy.py:39): in-place polyline on a HOST image (no device
+ * work, no context): Bresenham steps with a square brush of `thickness` pixels - the Python mirror's rasteriser in C.  pts = npts
+ * (x, y) int32 pairs; color has cn entries.  Debug overlay only: agreement with cv2's line drawing is not claimed. */
+int vp_draw_polyline_u8(uint8_t* img_host, size_t stride, int w, int h, int cn, const int32_t* pts, int npts, int closed,
+                        const uint8_t* color, int thickness);
+/* several polylines in one call: counts[k] points each, back to back in pts (cv2.drawContours(img, contours, -1, ...)) */
+int vp_draw_polylines_u8(uint8_t* img_host, size_t stride, int w, int h, int cn, const int32_t* pts, const int32_t* counts, int npolys,
+                         int closed, const uint8_t* color, int thickness);
+
 /* ---- device-resident forms of the per-operator entry points ----------------------------- *
  * Same arithmetic and argument meaning as vp_cvt_color_u8 / vp_inrange_u8 / vp_morph_u8 / vp_find_contours_u8; images are
  * device pointers.  Nothing is copied; the first three enqueue on the context's stream and return without synchronising, so a

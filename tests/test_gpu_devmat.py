@@ -1,0 +1,160 @@
+"""Images that stay in HBM between operator calls (vision/devmat.py): what the `vision.utils` mirror returns must behave like the
+caller-owned, writable numpy arrays of the reference (utils/color.py:11-32 ... modules/red_buoy.py:39) whichever side holds the data,
+and must not move it before Python looks."""
+import threading
+
+import numpy as np
+import pytest
+
+import frames as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain(image):
+    from vision.utils.color import bgr_to_lab, range_threshold
+    from vision.utils.feature import outer_contours
+    from vision.utils.transform import morph_close_holes, morph_remove_noise, rect_kernel
+    lab, (l_, a_, b_) = bgr_to_lab(image)
+    th = range_threshold(a_, 150, 255)
+    k = rect_kernel(5)
+    cl = morph_close_holes(morph_remove_noise(th, k), k)
+    return lab, a_, th, cl, outer_contours(th)
+
+
+def test_chain_stays_on_the_device_and_matches_the_oracle(vp, oracle):
+    from vision.devmat import DeviceMat
+    img = F.s1_buoy(3, 640, 360)
+    lab, a_, th, cl, cs = _chain(img)
+    for m in (lab, a_, th, cl):
+        assert isinstance(m, DeviceMat) and m._host is None, "an intermediate image was downloaded although nothing read it"
+    assert th.binary and cl.binary
+    olab = oracle.bgr2lab(img)
+    oth = oracle.inrange(np.ascontiguousarray(olab[:, :, 1]), 150, 255)
+    k5 = np.ones((5, 5), np.uint8)
+    ocl = oracle.morph(oracle.CLOSE, oracle.morph(oracle.OPEN, oth, k5), k5)
+    exp = oracle.find_contours(oth, 0, 2)
+    assert len(cs) == len(exp) and all(isinstance(c, np.ndarray) and np.array_equal(c, e) for c, e in zip(cs, exp))
+    assert np.array_equal(lab, olab) and np.array_equal(a_, olab[:, :, 1]) and np.array_equal(th, oth) and np.array_equal(cl, ocl)
+    assert lab.shape == (360, 640, 3) and th.shape == (360, 640) and th.dtype == np.uint8 and th.ndim == 2 and len(th) == 360
+
+
+def test_host_side_writes_are_seen_by_the_next_operator(vp, oracle):
+    from vision.utils.color import range_threshold
+    from vision.utils.transform import dilate, rect_kernel
+    g = np.ascontiguousarray(F.s1_buoy(1, 320, 200)[:, :, 2])
+    k3 = np.ones((3, 3), np.uint8)
+    ref = oracle.inrange(g, 150, 255)
+    # __setitem__ on the result
+    th = range_threshold(g, 150, 255)
+    th[10:20, 30:60] = 255
+    ref1 = ref.copy(); ref1[10:20, 30:60] = 255
+    assert np.array_equal(dilate(th, rect_kernel(3)), oracle.morph(oracle.DILATE, ref1, k3))
+    # a writable numpy view handed out by np.asarray, mutated behind the object's back
+    th = range_threshold(g, 150, 255)
+    view = np.asarray(th)
+    assert isinstance(view, np.ndarray) and view.flags.writeable
+    view[100:110, :] = 255
+    ref2 = ref.copy(); ref2[100:110, :] = 255
+    assert np.array_equal(dilate(th, rect_kernel(3)), oracle.morph(oracle.DILATE, ref2, k3))
+    # in-place operators and out=
+    th = range_threshold(g, 150, 255)
+    th |= 1
+    np.bitwise_and(th, 0xF0, out=th)
+    assert np.array_equal(th, (ref | 1) & 0xF0)
+    assert np.array_equal(dilate(th, rect_kernel(3)), oracle.morph(oracle.DILATE, (ref | 1) & 0xF0, k3))   # a grey image now: generic path
+
+
+def test_behaves_like_an_array(vp, oracle):
+    from vision.utils.color import bgr_to_gray, range_threshold
+    img = F.s2_bins(0, 200, 120)
+    g, (g1,) = bgr_to_gray(img)
+    og = oracle.bgr2gray(img)
+    assert np.array_equal(g1, og) and g1 is not g
+    th = range_threshold(g, 20, 255)
+    oth = oracle.inrange(og, 20, 255)
+    assert int((th > 0).sum()) == int((oth > 0).sum()) and int(np.count_nonzero(th)) == int(np.count_nonzero(oth))
+    assert np.array_equal(th[5:9, 7], oth[5:9, 7]) and th[3, 4] == oth[3, 4]
+    assert np.array_equal(th.copy(), oth) and np.array_equal(th.astype(np.float32), oth.astype(np.float32))
+    assert np.array_equal(~th, ~oth) and np.array_equal(th & g, oth & og) and np.array_equal(255 - th, 255 - oth)
+    assert th.T.shape == (200, 120) and th.flags.c_contiguous and th.mean() == oth.mean()
+    assert np.array_equal(np.dstack([th, th, th]), np.dstack([oth, oth, oth]))
+    assert np.array_equal(np.where(th)[0], np.where(oth)[0])
+    rows = [r for r in th]
+    assert len(rows) == 120 and np.array_equal(rows[7], oth[7])
+    assert "DeviceMat" in repr(range_threshold(g, 20, 255))
+
+
+def test_plain_numpy_mode(vp, oracle):
+    from vision import devmat
+    from vision.utils.color import bgr_to_lab, range_threshold
+    img = F.s1_buoy(0, 160, 90)
+    devmat.set_lazy(False)
+    try:
+        lab, planes = bgr_to_lab(img)
+        th = range_threshold(planes[1], 150, 255)
+        assert type(lab) is np.ndarray and all(type(p) is np.ndarray for p in planes) and type(th) is np.ndarray
+        assert np.array_equal(lab, oracle.bgr2lab(img))
+        # a DeviceMat made earlier is still accepted
+        devmat.set_lazy(True)
+        d = range_threshold(planes[1], 150, 255)
+        devmat.set_lazy(False)
+        from vision.utils.transform import erode, rect_kernel
+        assert np.array_equal(erode(d, rect_kernel(3)), oracle.morph(oracle.ERODE, th, np.ones((3, 3), np.uint8)))
+    finally:
+        devmat.set_lazy(True)
+
+
+def test_image_made_on_another_thread(vp, oracle):
+    """Contexts are per thread (ModuleBase runs process() on its own thread): an image produced under one context is usable under
+    another (it travels through the host)."""
+    from vision.utils.color import range_threshold
+    from vision.utils.transform import dilate, rect_kernel
+    g = np.ascontiguousarray(F.s1_buoy(5, 200, 100)[:, :, 2])
+    box = {}
+    t = threading.Thread(target=lambda: box.update(th=range_threshold(g, 150, 255)))
+    t.start(); t.join()
+    out = dilate(box["th"], rect_kernel(3))
+    assert np.array_equal(out, oracle.morph(oracle.DILATE, oracle.inrange(g, 150, 255), np.ones((3, 3), np.uint8)))
+
+
+def test_facade_and_drawing_take_device_images(vp, oracle):
+    from vision import cv2_facade as cv2
+    from vision.utils.draw import draw_contours
+    img = F.s2_bins(1, 320, 180)
+    hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV)
+    mask = cv2.inRange(hsv, np.array([10, 20, 60]), np.array([30, 100, 255]))
+    opened = cv2.morphologyEx(mask, cv2.MORPH_OPEN, cv2.getStructuringElement(cv2.MORPH_RECT, (5, 5)))
+    cs, _ = cv2.findContours(opened, cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)
+    ohsv = oracle.bgr2hsv(img)
+    omask = oracle.inrange(ohsv, (10, 20, 60), (30, 100, 255))
+    oopen = oracle.morph(oracle.OPEN, omask, np.ones((5, 5), np.uint8))
+    exp = oracle.find_contours(oopen, 0, 2)
+    assert len(cs) == len(exp) and all(np.array_equal(a, b) for a, b in zip(cs, exp))
+    vis = cv2.cvtColor(mask, cv2.COLOR_GRAY2BGR)
+    over = cv2.addWeighted(img, 0.7, vis, 0.3, 0)
+    assert over.shape == img.shape
+    n, lab, st, ce = cv2.connectedComponentsWithStats(opened, 8, cv2.CV_32S)
+    on, olab, ost, oce = oracle.ccl(oopen, 2)
+    assert n == on and np.array_equal(lab, olab) and np.array_equal(st, ost)
+    # drawing into a device image materialises it and draws on the host copy
+    a = img.copy(); b = img.copy()
+    draw_contours(a, cs, thickness=3)
+    from vision.utils import draw as D
+    for c in cs:                                   # the pure-Python rasteriser of the same statements
+        pts = np.asarray(c, np.int64).reshape(-1, 2)
+        for i in range(len(pts)):
+            D._line(b, pts[i], pts[(i + 1) % len(pts)], np.asarray((0, 0, 255), np.uint8), 3)
+    assert np.array_equal(a, b)
+    draw_contours(vis, cs, thickness=2)
+    assert isinstance(np.asarray(vis), np.ndarray)
+
+
+def test_polygon_sums_equal_the_sequential_loop(vp):
+    from vision.utils import feature
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 17, 500):
+        c = rng.integers(0, 1920, (n, 1, 2)).astype(np.int32)
+        assert feature._polygon_moments(c) == feature._polygon_moments_float(c.reshape(-1, 2).astype(np.float64))
+    sq = np.array([[[10, 10]], [[10, 30]], [[50, 30]], [[50, 10]]], np.int32)
+    assert feature.contour_area(sq) == 800.0 and feature.contour_centroid(sq) == (30, 20)
