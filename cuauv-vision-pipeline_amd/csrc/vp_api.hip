@@ -497,6 +497,19 @@ int vp_color_balance_u8(vp_ctx* ctx, const uint8_t* src, int w, int h, int flags
     return vp_synchronize(ctx);
 }
 
+int vp_color_balance_last_folds(vp_ctx* ctx, int32_t* tiles_folded)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!tiles_folded) return vp_fail(ctx, VP_ERR_INVALID, "vp_color_balance_last_folds arguments");
+    *tiles_folded = 0;
+    if (!ctx->cb_folds_dev) return VP_OK;
+    uint32_t v = 0;
+    VP_HIP(ctx, hipMemcpyAsync(&v, ctx->cb_folds_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *tiles_folded = (int32_t)v;
+    return VP_OK;
+}
+
 int vp_color_balance_dev(vp_ctx* ctx, const uint8_t* src, uint8_t* dst, int w, int h, int n, int flags, int hblocks, int vblocks)
 {
     VP_TRY(check_ctx(ctx));
@@ -1147,9 +1160,12 @@ static int chain_split(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffe
         ctx->stream = ctx->aux[s];
         rc = chain_core(ctx, d, &sb, cnt);
         ctx->stream = user;
+        // join whatever was queued on the side stream, also after an error: it must not still run when the next call reuses the workspace
+        const hipError_t e1 = hipEventRecord(ctx->ev_join[s], ctx->aux[s]);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(user, ctx->ev_join[s], 0) : e1;
         if (rc != VP_OK) break;
-        if ((e = hipEventRecord(ctx->ev_join[s], ctx->aux[s])) != hipSuccess) { rc = vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", e); break; }
-        if ((e = hipStreamWaitEvent(user, ctx->ev_join[s], 0)) != hipSuccess) { rc = vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", e); break; }
+        if (e1 != hipSuccess) { rc = vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", e1); break; }
+        if (e2 != hipSuccess) { rc = vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", e2); break; }
         f0 += cnt;
     }
     ctx->stream = user;

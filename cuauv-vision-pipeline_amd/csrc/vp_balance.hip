@@ -13,10 +13,15 @@
 //   k_cb_apply     table lookup -> BGR2HSV -> S/V tables -> HSV2BGR (OpenCV's float form) -> store (third pass)
 // 12 B/px of algorithmic traffic with the HSV stage (3 reads + 1 write of the frame), 9 B/px without it.
 //
-// The reference's running mean (avg += (x - avg) / count, cpp:452-467) is replaced by the exact sum / count: it differs by
-// rounding noise of ~1e-13 relative, which can only matter where gain * value lands within that distance of an integer
-// (never observed).
+// The reference's tile means are a sequential fold (avg += (x - avg) / count, cpp:452-467), not a sum / count.  k_cb_plan1 gets the
+// same tables without walking the tile: from the exact mean M and a rigorous bound e >= |fold - M| (derived at cb_fold_bound) it
+// checks that every statement that reads the means - the 1/6 test of cpp:474, the choice of the cast, every entry of the gain
+// tables - comes out the same for all values in [M - e, M + e]; then the fold's value, whatever it is, gives these tables.  When
+// one of them could differ (a comparison within e of its boundary, a product gain * v within e of an integer: about one frame in
+// 10^5) three threads run the fold itself, in the reference's order, and the tables are built from its result.
 #include "vp_internal.h"
+#include <cmath>
+#include <cstdlib>
 
 #define CB_MAX_TILES 1024
 #define CB_COPIES 8
@@ -85,7 +90,7 @@ __device__ __forceinline__ int cb_tile_of(const cb_params& P, size_t pix_in_fram
 // ---- pass 1: histograms -------------------------------------------------------------------------------------------------
 // grid (blocks, n); a block walks groups of 4 pixels (12 bytes = 3 dwords) of its frame.  hist: [n][tiles][3][256]
 template <bool TILED>
-__global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src, cb_params P, u32* __restrict__ hist)
+__global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src, cb_params P, u32* __restrict__ hist, u32* __restrict__ neq)
 {
     // natural images concentrate on few bins: 16 interleaved copies (bin * 16 + lane % 16) cut same-address atomics of a wave
     // from 64 lanes to 4 and keep the copies of one bin in different banks
@@ -98,6 +103,10 @@ __global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src
         for (int i = tid; i < 768 * CB_COPIES; i += 256) (&lh[0][0])[i] = 0;
         __syncthreads();
     }
+    // neq[tile][0..2] become non-zero when some pixel of the tile has B != G, G != R, B != R: channels that agree everywhere
+    // have the same sequence of values, hence bitwise equal running means (k_cb_plan1 needs to know)
+    u32* fneq = neq + (size_t)f * P.hb * P.vb * 4;
+    u32 nq = 0;
     const size_t ngroups = npx / 4;
     const u32* s32 = reinterpret_cast<const u32*>(fs);
     for (size_t gidx = (size_t)blockIdx.x * 256 + tid; gidx < ngroups; gidx += (size_t)gridDim.x * 256) {
@@ -106,10 +115,16 @@ __global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src
                               {(b >> 16) & 255, b >> 24, c & 255}, {(c >> 8) & 255, (c >> 16) & 255, c >> 24}};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            const u32 q = (px[k][0] != px[k][1] ? 1u : 0u) | (px[k][1] != px[k][2] ? 2u : 0u) | (px[k][0] != px[k][2] ? 4u : 0u);
             if (TILED) {
-                u32* th = fh + (size_t)cb_tile_of(P, 4 * gidx + k) * 768;
+                const size_t tl = (size_t)cb_tile_of(P, 4 * gidx + k);
+                u32* th = fh + tl * 768;
                 atomicAdd(th + px[k][0], 1u); atomicAdd(th + 256 + px[k][1], 1u); atomicAdd(th + 512 + px[k][2], 1u);
+                if (q & 1u) fneq[tl * 4] = 1u;
+                if (q & 2u) fneq[tl * 4 + 1] = 1u;
+                if (q & 4u) fneq[tl * 4 + 2] = 1u;
             } else {
+                nq |= q;
                 atomicAdd(&lh[0][px[k][0] * CB_COPIES + cp], 1u); atomicAdd(&lh[1][px[k][1] * CB_COPIES + cp], 1u);
                 atomicAdd(&lh[2][px[k][2] * CB_COPIES + cp], 1u);
             }
@@ -117,10 +132,16 @@ __global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src
     }
     if (blockIdx.x == 0 && tid < (int)(npx & 3)) {   // tail pixels of the frame
         const size_t p = (npx & ~(size_t)3) + tid;
+        const u32 q = (fs[3 * p] != fs[3 * p + 1] ? 1u : 0u) | (fs[3 * p + 1] != fs[3 * p + 2] ? 2u : 0u) | (fs[3 * p] != fs[3 * p + 2] ? 4u : 0u);
         if (TILED) {
-            u32* th = fh + (size_t)cb_tile_of(P, p) * 768;
+            const size_t tl = (size_t)cb_tile_of(P, p);
+            u32* th = fh + tl * 768;
             atomicAdd(th + fs[3 * p], 1u); atomicAdd(th + 256 + fs[3 * p + 1], 1u); atomicAdd(th + 512 + fs[3 * p + 2], 1u);
+            if (q & 1u) fneq[tl * 4] = 1u;
+            if (q & 2u) fneq[tl * 4 + 1] = 1u;
+            if (q & 4u) fneq[tl * 4 + 2] = 1u;
         } else {
+            nq |= q;
             atomicAdd(&lh[0][fs[3 * p] * CB_COPIES + cp], 1u); atomicAdd(&lh[1][fs[3 * p + 1] * CB_COPIES + cp], 1u);
             atomicAdd(&lh[2][fs[3 * p + 2] * CB_COPIES + cp], 1u);
         }
@@ -133,6 +154,9 @@ __global__ __launch_bounds__(256) void k_cb_hist(const uint8_t* __restrict__ src
             for (int k = 0; k < CB_COPIES; k++) v += (&lh[0][0])[i * CB_COPIES + k];
             if (v) atomicAdd(fh + i, v);
         }
+        if (nq & 1u) fneq[0] = 1u;
+        if (nq & 2u) fneq[1] = 1u;
+        if (nq & 4u) fneq[2] = 1u;
     }
 }
 
@@ -167,12 +191,52 @@ struct cb_plan {      // per frame, device
     int s_lo, s_hi, v_lo, v_hi;   // cpp:619-629
 };
 
-// one block per frame.  lut: [n][tiles][3][256] u8 (B, G, R)
-__global__ __launch_bounds__(256) void k_cb_plan1(cb_params P, const u32* __restrict__ hist, cb_plan* __restrict__ plans, uint8_t* __restrict__ lut)
+// |fold - exact mean| after n steps of avg += (x - avg) / count over values in [0, 255] (cpp:466-468), every operation rounded to
+// nearest (u = 2^-53): one step adds at most d_k = u (2 * 255 / k + 255) (1 + 2u) of error (the subtraction and the division each
+// within u of (x - avg) / k <= 255 / k, the addition within u of a value <= 255), and e_n = e_{n-1} (1 - 1/n) + d_n gives
+// n e_n = sum k d_k <= u (510 n + 255 n (n + 1) / 2).  A further factor 1.001 swallows the (1 + 2u) terms.
+__device__ __forceinline__ double cb_fold_bound(double n) { return (510.0 + 127.5 * (n + 1.0)) * 0x1p-53 * 1.001; }
+
+// The statements of cpp:474-541 for table index v = tid: the three table entries (B, G, R) the tile means l[] (B, G, R) lead to.
+__device__ __forceinline__ void cb_tile_entries(const cb_params& P, const cb_plan& pl, const double* l, const double* ratio, const int* cmin,
+                                                const double* __restrict__ powtab, int tid, int* out)
+{
+    const double b_avg = pl.avg[0], g_avg = pl.avg[1], r_avg = pl.avg[2];
+    double lb = l[0], lg = l[1], lr = l[2];
+    double gain[3] = {1, 1, 1};
+    if (P.flags & VP_CB_EQUALIZE_RGB) {
+        if (fabs(lr - r_avg) > r_avg / 6 || fabs(lb - b_avg) > b_avg / 6 || fabs(lg - g_avg) > g_avg / 6) { lr = r_avg; lb = b_avg; lg = g_avg; }
+        if (lr > lg && lr > lb) { gain[1] = lr / lg; gain[0] = lr / lb; }           // red cast: lift G and B
+        else if (lg > lr && lg > lb) { gain[2] = lg / lr; gain[0] = lg / lb; }      // green cast: lift R and B
+        else { gain[2] = lb / lr; gain[1] = lb / lg; }                              // blue cast (and ties): lift R and G
+    }
+    const bool red = lr > lg && lr > lb, green = !red && (lg > lr && lg > lb);
+    for (int c = 0; c < 3; c++) {
+        int v = min(max(tid, pl.lo[c]), pl.hi[c]);   // clip (no-op without extrema clipping: the value lies inside)
+        if (P.flags & VP_CB_EQUALIZE_RGB) {
+            const bool lifted = red ? (c != 2) : (green ? (c != 1) : (c != 0));
+            if (lifted) {
+                if (P.flags & VP_CB_ADAPTIVE_CAST) v = cb_constrain(v * (powtab[v] * (gain[c] - 1.) + 1.));   // powtab[v] = pow((255. - v) / 255., 0.25) from the host's libm
+                else v = cb_constrain(v * gain[c]);
+            }
+        }
+        if (P.flags & VP_CB_RGB_CONTRAST) v = cb_cast_u8((v - cmin[c]) * ratio[c]);
+        out[c] = v;
+    }
+}
+
+// one block per frame.  lut: [n][tiles][3][256] u8 (B, G, R); src: the frames (read only when a tile's fold has to be run);
+// neq: [n][tiles][4] flags of k_cb_hist; folds (nullable): number of tiles whose fold was run, for the tests
+__global__ __launch_bounds__(256) void k_cb_plan1(cb_params P, const u32* __restrict__ hist, const u32* __restrict__ neq,
+                                                  const uint8_t* __restrict__ src, cb_plan* __restrict__ plans, uint8_t* __restrict__ lut,
+                                                  u32* __restrict__ folds, int force_fold, const double* __restrict__ powtab)
 {
     __shared__ u32 gh[3][256];
     __shared__ cb_plan pl;
     __shared__ double tsum[3];
+    __shared__ double tcnt;
+    __shared__ int certain_s;
+    __shared__ double pert[2][3];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int tiles = P.hb * P.vb;
     const size_t npx = (size_t)P.w * P.h;
@@ -217,37 +281,89 @@ __global__ __launch_bounds__(256) void k_cb_plan1(cb_params P, const u32* __rest
         cmin[0] = pl.lo[0]; cmin[1] = pl.lo[1]; cmin[2] = pl.lo[2];
     }
     for (int t = 0; t < tiles; t++) {
-        // tile means of the clipped channels (cpp:452-467, exact form)
+        // exact tile means of the clipped channels
         __syncthreads();
         if (tid < 3) {
             const u32* th = fh + (size_t)t * 768 + tid * 256;
             unsigned long long s = 0, c = 0;
             for (int i = 0; i < 256; i++) { s += (unsigned long long)min(max(i, pl.lo[tid]), pl.hi[tid]) * th[i]; c += th[i]; }
             tsum[tid] = c ? (double)s / (double)c : 0.0;
+            if (tid == 0) tcnt = (double)c;
         }
         __syncthreads();
-        double lb = tsum[0], lg = tsum[1], lr = tsum[2];
-        double gain[3] = {1, 1, 1};
-        if (P.flags & VP_CB_EQUALIZE_RGB) {
-            if (fabs(lr - r_avg) > r_avg / 6 || fabs(lb - b_avg) > b_avg / 6 || fabs(lg - g_avg) > g_avg / 6) { lr = r_avg; lb = b_avg; lg = g_avg; }
-            if (lr > lg && lr > lb) { gain[1] = lr / lg; gain[0] = lr / lb; }           // red cast: lift G and B
-            else if (lg > lr && lg > lb) { gain[2] = lg / lr; gain[0] = lg / lb; }      // green cast: lift R and B
-            else { gain[2] = lb / lr; gain[1] = lb / lg; }                              // blue cast (and ties): lift R and G
-        }
-        const bool red = lr > lg && lr > lb, green = !red && (lg > lr && lg > lb);
         uint8_t* tl = lut + ((size_t)f * tiles + t) * 768;
-        for (int c = 0; c < 3; c++) {
-            int v = min(max(tid, pl.lo[c]), pl.hi[c]);   // clip (no-op without extrema clipping: the value lies inside)
-            if (P.flags & VP_CB_EQUALIZE_RGB) {
-                const bool lifted = red ? (c != 2) : (green ? (c != 1) : (c != 0));
-                if (lifted) {
-                    if (P.flags & VP_CB_ADAPTIVE_CAST) v = cb_constrain(v * (pow((255. - v) / 255., 0.25) * (gain[c] - 1.) + 1.));
-                    else v = cb_constrain(v * gain[c]);
-                }
-            }
-            if (P.flags & VP_CB_RGB_CONTRAST) v = cb_cast_u8((v - cmin[c]) * ratio[c]);
-            tl[c * 256 + tid] = (uint8_t)v;
+        int v[3];
+        if (!(P.flags & VP_CB_EQUALIZE_RGB)) {       // the means are not read at all
+            const double l[3] = {tsum[0], tsum[1], tsum[2]};
+            cb_tile_entries(P, pl, l, ratio, cmin, powtab, tid, v);
+            for (int c = 0; c < 3; c++) tl[c * 256 + tid] = (uint8_t)v[c];
+            continue;
         }
+        // ---- can the fold's value matter? ----
+        if (tid == 0) {
+            const double e = cb_fold_bound(tcnt), M[3] = {tsum[0], tsum[1], tsum[2]};
+            const u32* q = neq + ((size_t)f * tiles + t) * 4;
+            const bool same01 = q[0] == 0u && pl.lo[0] == pl.lo[1] && pl.hi[0] == pl.hi[1];   // B and G: one sequence of values, one fold
+            const bool same12 = q[1] == 0u && pl.lo[1] == pl.lo[2] && pl.hi[1] == pl.hi[2];
+            const bool same02 = q[2] == 0u && pl.lo[0] == pl.lo[2] && pl.hi[0] == pl.hi[2];
+            const int grp[3] = {0, same01 ? 0 : 1, same02 ? 0 : (same12 ? (same01 ? 0 : 1) : 2)};
+            bool certain = !force_fold && tcnt > 0;
+            // cpp:474: certainly true for some channel, or certainly false for all (the compared values carry their own rounding:
+            // 2^-40 is far above it)
+            bool replaced = false, unsure = false;
+            for (int c = 0; c < 3; c++) {
+                const double d = fabs(M[c] - pl.avg[c]), thr = pl.avg[c] / 6, m = e + 0x1p-40;
+                if (d > thr + m) replaced = true;
+                else if (d >= thr - m) unsure = true;
+            }
+            if (!replaced && unsure) certain = false;
+            for (int c = 0; c < 3; c++) { pert[0][c] = 0; pert[1][c] = 0; }
+            if (certain && !replaced) {
+                // which group of channels has the largest mean must be beyond doubt: the two largest DIFFERENT folds at least 2e apart
+                int top = 0;
+                for (int c = 1; c < 3; c++) if (M[c] > M[top]) top = c;
+                for (int c = 0; c < 3; c++)
+                    if (grp[c] != grp[top] && M[top] - M[c] <= 2 * e + 0x1p-40) certain = false;
+                // the two extreme cases for every gain (largest mean over another): top group down and the rest up, and the reverse
+                for (int c = 0; c < 3; c++) { const double sg = grp[c] == grp[top] ? -1.0 : 1.0; pert[0][c] = sg * e; pert[1][c] = -sg * e; }
+            }
+            certain_s = certain ? 1 : 0;
+        }
+        __syncthreads();
+        bool differ = false;
+        if (certain_s) {
+            const double la[3] = {tsum[0] + pert[0][0], tsum[1] + pert[0][1], tsum[2] + pert[0][2]};
+            const double lb2[3] = {tsum[0] + pert[1][0], tsum[1] + pert[1][1], tsum[2] + pert[1][2]};
+            int vb[3];
+            cb_tile_entries(P, pl, la, ratio, cmin, powtab, tid, v);
+            cb_tile_entries(P, pl, lb2, ratio, cmin, powtab, tid, vb);
+            differ = v[0] != vb[0] || v[1] != vb[1] || v[2] != vb[2];
+        }
+        const bool ok = !__syncthreads_or(differ || !certain_s);
+        if (!ok) {
+            // ---- the fold itself, in the reference's order (cpp:459-469): one thread per channel ----
+            if (tid < 3) {
+                const int by = t / P.hb, bx = t - by * P.hb;
+                const uint8_t* fs = src + (size_t)f * npx * 3;
+                const int lo = pl.lo[tid], hi = pl.hi[tid];
+                double avg = 0;
+                int count = 0;
+                for (int j = 0; j < P.bh; j++) {
+                    const uint8_t* row = fs + ((size_t)(by * P.bh + j) * P.w + (size_t)bx * P.bw) * 3 + tid;
+                    for (int i = 0; i < P.bw; i++) {
+                        const int x = min(max((int)row[3 * (size_t)i], lo), hi);
+                        ++count;
+                        avg += (x - avg) / count;
+                    }
+                }
+                tsum[tid] = avg;
+                if (tid == 0 && folds) atomicAdd(folds, 1u);
+            }
+            __syncthreads();
+            const double l[3] = {tsum[0], tsum[1], tsum[2]};
+            cb_tile_entries(P, pl, l, ratio, cmin, powtab, tid, v);
+        }
+        for (int c = 0; c < 3; c++) tl[c * 256 + tid] = (uint8_t)v[c];
     }
     if (tid == 0) { pl.s_lo = 0; pl.s_hi = 255; pl.v_lo = 0; pl.v_hi = 255; plans[f] = pl; }
 }
@@ -549,8 +665,8 @@ int vpk_hsv2bgr(vp_ctx* ctx, const uint8_t* d_src, size_t npx, uint8_t* d_dst)
     return VP_OK;
 }
 
-size_t vp_balance_ws_bytes(int n, int tiles) { return vp_align((size_t)n * tiles * 768 * 4) + vp_align((size_t)n * 1024 * 4) + vp_align((size_t)n * tiles * 768) +
-                                                      vp_align((size_t)n * 512) + vp_align(sizeof(cb_plan) * (size_t)n) + vp_align(sizeof(hsi_state) * (size_t)n) + 4096; }
+size_t vp_balance_ws_bytes(int n, int tiles) { return vp_align((size_t)n * tiles * 772 * 4 + 64) + vp_align((size_t)n * 1024 * 4) + vp_align((size_t)n * tiles * 768) +
+                                                      vp_align((size_t)n * 512) + vp_align(sizeof(cb_plan) * (size_t)n) + vp_align(sizeof(hsi_state) * (size_t)n) + 4096 + 2048; }
 
 // d_src / d_dst: (n, h, w, 3) packed; d_dst may equal d_src.  Frames must start 4-byte aligned (w*h*3 % 4 == 0 or n == 1).
 int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int flags, int hblocks, int vblocks)
@@ -564,7 +680,9 @@ int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, 
     const size_t npx = (size_t)w * h;
     if (n > 1 && (npx * 3) % 4) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "colour balance: batched frames must be 4-byte aligned");
     cb_params P = {w, h, n, flags, hblocks, vblocks, w / hblocks, h / vblocks};
-    u32* hist = (u32*)vp_ws_take(ctx, (size_t)n * tiles * 768 * 4);
+    u32* hist = (u32*)vp_ws_take(ctx, (size_t)n * tiles * 772 * 4 + 64);   // histograms | per-tile channel-equality flags | fold counter
+    u32* neq = hist ? hist + (size_t)n * tiles * 768 : nullptr;
+    u32* folds = neq ? neq + (size_t)n * tiles * 4 : nullptr;
     u32* svhist = (u32*)vp_ws_take(ctx, (size_t)n * 1024 * 4);   // S/V histograms; reused as the four radix histograms of the HSI stage
     uint8_t* lut = (uint8_t*)vp_ws_take(ctx, (size_t)n * tiles * 768);
     uint8_t* svlut = (uint8_t*)vp_ws_take(ctx, (size_t)n * 512);
@@ -577,10 +695,24 @@ int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, 
     const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((npx / 4 + 255) / 256, std::max<size_t>(8, (size_t)ctx->num_cu * 8 / (size_t)n)));
     const dim3 grid(bx, (unsigned)n);
     vp_prof_scope ps(ctx, VPK_OTHER);
-    VP_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)n * tiles * 768 * 4, s));
-    if (tiled) hipLaunchKernelGGL((k_cb_hist<true>), grid, dim3(256), 0, s, d_src, P, hist);
-    else hipLaunchKernelGGL((k_cb_hist<false>), grid, dim3(256), 0, s, d_src, P, hist);
-    hipLaunchKernelGGL(k_cb_plan1, dim3((unsigned)n), dim3(256), 0, s, P, hist, plans, lut);
+    VP_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)n * tiles * 772 * 4 + 64, s));
+    if (tiled) hipLaunchKernelGGL((k_cb_hist<true>), grid, dim3(256), 0, s, d_src, P, hist, neq);
+    else hipLaunchKernelGGL((k_cb_hist<false>), grid, dim3(256), 0, s, d_src, P, hist, neq);
+    static const int force_fold = getenv("VP_CB_FORCE_FOLD") ? atoi(getenv("VP_CB_FORCE_FOLD")) : 0;   // tests: run the fold for every tile
+    // adaptive_cast_correction (cpp:489-490) calls pow((255. - v) / 255., 0.25): 256 possible arguments.  The table comes from the
+    // host's libm - the library the reference itself would call on this machine - so that the device's own pow (which may round the
+    // last bit differently) never enters the result.
+    double* powtab = nullptr;
+    if (flags & VP_CB_ADAPTIVE_CAST) {
+        static double host_tab[256];
+        static bool made = false;
+        if (!made) { for (int v = 0; v < 256; v++) host_tab[v] = pow((255. - v) / 255., 0.25); made = true; }
+        powtab = (double*)vp_ws_take(ctx, sizeof host_tab);
+        if (!powtab) return vp_fail(ctx, VP_ERR_NOMEM, "colour balance workspace");
+        VP_HIP(ctx, hipMemcpyAsync(powtab, host_tab, sizeof host_tab, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_cb_plan1, dim3((unsigned)n), dim3(256), 0, s, P, hist, neq, d_src, plans, lut, folds, force_fold, (const double*)powtab);
+    ctx->cb_folds_dev = folds;
     if (hsv) {
         VP_HIP(ctx, hipMemsetAsync(svhist, 0, (size_t)n * 512 * 4, s));
         if (tiled) hipLaunchKernelGGL((k_cb_hsvhist<true>), grid, dim3(256), 0, s, d_src, P, ctx->tab, lut, svhist);

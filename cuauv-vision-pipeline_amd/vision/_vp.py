@@ -57,7 +57,6 @@ class ContourBuffers(C.Structure):
 
 _lib = None
 _lock = threading.Lock()
-_ctxs = {}
 
 _SIGS = {
     "vp_version": (C.c_int, []),
@@ -77,6 +76,7 @@ _SIGS = {
     "vp_profile_kernel_name": (C.c_char_p, [C.c_int]),
     "vp_cvt_color_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_color_balance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vp_color_balance_last_folds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "vp_color_balance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vp_threshold_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "vp_otsu_threshold_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
@@ -188,6 +188,9 @@ class Context:
 
     def close(self):
         if self.handle:
+            pool = getattr(self, "_pool", None)      # device buffers of images that stayed in HBM (vision/devmat.py)
+            if pool is not None:
+                pool.drain()
             lib().vp_destroy(self.handle)
             self.handle = None
 
@@ -238,13 +241,19 @@ class Context:
               self.handle)
 
 
+_tls = threading.local()
+
+
 def default_context(device=0):
-    """Per-(thread, device) context: ModuleBase runs process() on a non-main thread (core/base.py:701-703)."""
-    key = (threading.get_ident(), device)
-    ctx = _ctxs.get(key)
-    if ctx is None:
-        ctx = Context(device)
-        _ctxs[key] = ctx
+    """Per-(thread, device) context: ModuleBase runs process() on a non-main thread (core/base.py:701-703) and starts a new one on
+    every FRAMEWORK_DELETED retry.  The contexts hang off thread-local storage, so a thread that ends releases its contexts (streams,
+    events, device workspace, staging memory) with it, and a recycled thread id can never inherit another thread's context."""
+    ctxs = getattr(_tls, "ctxs", None)
+    if ctxs is None:
+        ctxs = _tls.ctxs = {}
+    ctx = ctxs.get(device)
+    if ctx is None or not ctx.handle:
+        ctx = ctxs[device] = Context(device)
     return ctx
 
 
@@ -257,8 +266,8 @@ def pinned_empty(ctx, shape, dtype):
     check(lib().vp_host_alloc(ctx.handle, max(nbytes, 1), C.byref(p)), ctx.handle)
     buf = (C.c_ubyte * max(nbytes, 1)).from_address(p.value)
     arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-    handle, addr = ctx.handle, p.value
-    weakref.finalize(buf, lambda: lib().vp_host_free(handle, addr))
+    addr = p.value
+    weakref.finalize(buf, lambda: lib().vp_host_free(None, addr))   # page-locked memory is not tied to a context, which may be gone by then
     return arr
 
 

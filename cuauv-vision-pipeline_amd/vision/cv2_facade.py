@@ -67,16 +67,46 @@ def getStructuringElement(shape, ksize):
     return _transform._structuring_element(int(shape), int(ksize[0]), int(ksize[1]))
 
 
-def erode(src, kernel, iterations=1, anchor=(-1, -1)):
-    return _transform._morph(_vp.MORPH_ERODE, src, kernel, iterations, anchor)
+BORDER_CONSTANT = 0
+BORDER_REPLICATE = 1
+BORDER_REFLECT_101 = 4
+BORDER_DEFAULT = 4
 
 
-def dilate(src, kernel, iterations=1, anchor=(-1, -1)):
-    return _transform._morph(_vp.MORPH_DILATE, src, kernel, iterations, anchor)
+def _into(dst, result):
+    """cv2's optional `dst` argument: the result is also written into it when it has the right shape and type (cv2 reallocates
+    otherwise, which a caller-owned numpy array cannot do: the returned array is the result either way)."""
+    if dst is not None:
+        from vision.devmat import to_host
+        d = to_host(dst)
+        r = np.asarray(result)
+        if isinstance(d, np.ndarray) and d.shape == r.shape and d.dtype == r.dtype and d.flags.writeable:
+            np.copyto(d, r)
+            return dst
+    return result
 
 
-def morphologyEx(src, op, kernel, iterations=1, anchor=(-1, -1)):
-    return _transform._morph(int(op), src, kernel, iterations, anchor)
+def _default_border_only(name, borderType, borderValue):
+    # cv2's default for morphology: BORDER_CONSTANT with morphologyDefaultBorderValue() = "outside never wins"
+    if borderType not in (None, BORDER_CONSTANT) or borderValue is not None:
+        raise error(f"{name}: only the default border (constant, morphologyDefaultBorderValue) is on the accelerated path")
+
+
+# positional order as in cv2: (src, kernel, dst, anchor, iterations, borderType, borderValue)
+def erode(src, kernel, dst=None, anchor=None, iterations=1, borderType=None, borderValue=None):
+    _default_border_only("erode", borderType, borderValue)
+    return _into(dst, _transform._morph(_vp.MORPH_ERODE, src, kernel, iterations, anchor if anchor is not None else (-1, -1)))
+
+
+def dilate(src, kernel, dst=None, anchor=None, iterations=1, borderType=None, borderValue=None):
+    _default_border_only("dilate", borderType, borderValue)
+    return _into(dst, _transform._morph(_vp.MORPH_DILATE, src, kernel, iterations, anchor if anchor is not None else (-1, -1)))
+
+
+# (src, op, kernel, dst, anchor, iterations, borderType, borderValue)
+def morphologyEx(src, op, kernel, dst=None, anchor=None, iterations=1, borderType=None, borderValue=None):
+    _default_border_only("morphologyEx", borderType, borderValue)
+    return _into(dst, _transform._morph(int(op), src, kernel, iterations, anchor if anchor is not None else (-1, -1)))
 
 
 def findContours(image, mode, method):
@@ -87,8 +117,14 @@ def findContours(image, mode, method):
 def connectedComponentsWithStats(image, connectivity=8, ltype=CV_32S):
     if connectivity != 8:
         raise error("only 8-connectivity is implemented")
-    n, labels, stats, cent = _feature.connected_components(image, max_labels=65536)
-    return n, labels, stats, cent
+    if ltype != CV_32S:
+        raise error("only CV_32S labels are implemented")
+    cap = 4096
+    while True:                                    # stats and centroids always have one row per label, as in cv2
+        n, labels, stats, cent = _feature.connected_components(image, max_labels=cap)
+        if n <= cap:
+            return n, labels, stats, cent
+        cap = n
 
 
 def moments(contour):
@@ -248,9 +284,16 @@ def getRotationMatrix2D(center, angle, scale):
     return np.array([[a, b, (1 - a) * cx - b * cy], [-b, a, b * cx + (1 - a) * cy]], np.float64)
 
 
-def GaussianBlur(src, ksize, sigmaX, sigmaY=0):
-    """cv2.GaussianBlur on uint8 images (modules/preprocessor.py:110-114): OpenCV's bit-exact fixed-point path on the GPU."""
+def GaussianBlur(src, ksize, sigmaX, dst=None, sigmaY=0, borderType=None):
+    """cv2.GaussianBlur on uint8 images (modules/preprocessor.py:110-114): OpenCV's bit-exact fixed-point path on the GPU.
+    Positional order as in cv2: (src, ksize, sigmaX, dst, sigmaY, borderType)."""
+    return _into(dst, _gaussian_blur(src, ksize, sigmaX, sigmaY, borderType))
+
+
+def _gaussian_blur(src, ksize, sigmaX, sigmaY, borderType):
     from vision import _vp
+    if borderType not in (None, BORDER_DEFAULT):
+        raise error("GaussianBlur: only BORDER_DEFAULT (reflect 101) is on the accelerated path")
     src = np.ascontiguousarray(src)
     if src.dtype != np.uint8 or src.ndim not in (2, 3) or src.size == 0:
         raise error("GaussianBlur: only non-empty uint8 images are on the accelerated path")
@@ -265,16 +308,21 @@ def GaussianBlur(src, ksize, sigmaX, sigmaY=0):
     return out
 
 
-BORDER_CONSTANT = 0
-BORDER_REPLICATE = 1
 INTER_LINEAR = 1
 WARP_INVERSE_MAP = 16
 
 
-def warpAffine(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0):
+def warpAffine(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0):
     """cv2.warpAffine with bilinear interpolation on uint8 images (modules/preprocessor.py:130-135,145-149): OpenCV's classical
-    fixed-point path on the GPU (libvp vp_warp_affine_u8)."""
+    fixed-point path on the GPU (libvp vp_warp_affine_u8).  Positional order as in cv2: (src, M, dsize, dst, flags, borderMode,
+    borderValue)."""
+    return _into(dst, _warp_affine(src, M, dsize, flags, borderMode, borderValue))
+
+
+def _warp_affine(src, M, dsize, flags, borderMode, borderValue):
     from vision import _vp
+    if flags is None:
+        flags = INTER_LINEAR
     if (flags & ~WARP_INVERSE_MAP) != INTER_LINEAR:
         raise error("warpAffine: only INTER_LINEAR is on the accelerated path")
     if borderMode not in (BORDER_CONSTANT, BORDER_REPLICATE):
@@ -297,12 +345,19 @@ def warpAffine(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, bo
     return out
 
 
-def resize(src, dsize, interpolation=INTER_LINEAR):
-    """cv2.resize(src, (width, height)) with the default bilinear interpolation, uint8 images (modules/preprocessor.py:136-144)."""
+def resize(src, dsize, dst=None, fx=None, fy=None, interpolation=INTER_LINEAR):
+    """cv2.resize(src, (width, height)) with the default bilinear interpolation, uint8 images (modules/preprocessor.py:136-144).
+    Positional order as in cv2: (src, dsize, dst, fx, fy, interpolation); dsize None or (0, 0) takes the size from fx / fy."""
     from vision import _vp
     if interpolation != INTER_LINEAR:
         raise error("resize: only INTER_LINEAR is on the accelerated path")
     src = np.ascontiguousarray(src)
+    if dsize is None or tuple(dsize) == (0, 0):
+        if not fx or not fy:
+            raise error("resize: dsize or both fx and fy are needed")
+        dsize = (int(round(src.shape[1] * fx)), int(round(src.shape[0] * fy)))   # cv2: saturate_cast<int>(cols * fx): round half to even
+    elif fx or fy:
+        pass                                       # cv2 ignores fx / fy when dsize is given
     if src.dtype != np.uint8 or src.ndim not in (2, 3) or src.size == 0:
         raise error("resize: expected a non-empty uint8 image")
     cn = 1 if src.ndim == 2 else src.shape[2]
@@ -312,7 +367,7 @@ def resize(src, dsize, interpolation=INTER_LINEAR):
     out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
     ctx = _vp.default_context()
     _vp.check(_vp.lib().vp_resize_u8(ctx.handle, _vp.ptr(src), src.shape[1], src.shape[0], cn, dw, dh, _vp.ptr(out)), ctx.handle)
-    return out
+    return _into(dst, out)
 
 
 def Canny(image, threshold1, threshold2, apertureSize=3, L2gradient=False):

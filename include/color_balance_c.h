@@ -6,8 +6,10 @@
  * (vp_color_balance_u8, include/vp.h) with one process-wide context created on first use.
  *
  * arr: (height, width, depth = 3) BGR uint8, modified in place.  Returns 0, or a negative VP_ERR_* code
- * (the reference always returns 0; it has no error path).  Not implemented: horizontal_blocks / vertical_blocks
- * that do not divide the frame — returns VP_ERR_UNSUPPORTED (-4) and leaves arr untouched.  Device selection: environment variable VP_DEVICE (default 0).
+ * (the reference always returns 0 and its binding, modules/color_balance.py:105, ignores the value: so every distinct
+ * failure is also written to stderr once).  horizontal_blocks / vertical_blocks that do not divide the frame (the
+ * reference wraps such tiles into the next row and processes pixels twice) are not implemented: the frame is then
+ * balanced with a single tile and a warning.  Device selection: environment variable VP_DEVICE (default 0).
  */
 #ifndef COLOR_BALANCE_C_H
 #define COLOR_BALANCE_C_H

@@ -102,6 +102,9 @@ enum { VP_CB_EQUALIZE_RGB = 1, VP_CB_RGB_CONTRAST = 2, VP_CB_HSV_CONTRAST = 4, V
        VP_CB_ADAPTIVE_CAST = 32, VP_CB_DEFAULT = 1 | 4 | 16 };
 int vp_color_balance_u8(vp_ctx* ctx, const uint8_t* src_host, int w, int h, int flags, int horizontal_blocks, int vertical_blocks,
                         uint8_t* dst_host);
+/* Diagnostic: in how many tiles the last colour-balance call on this context had to run the reference's sequential tile mean
+ * (cpp:452-467) because its value could have mattered (see csrc/vp_balance.hip); valid until the next call that uses the workspace. */
+int vp_color_balance_last_folds(vp_ctx* ctx, int32_t* tiles_folded);
 /* Same on device memory for a batch of n frames ((n,h,w,3), packed; dst may equal src); enqueues and returns. */
 int vp_color_balance_dev(vp_ctx* ctx, const uint8_t* src_dev, uint8_t* dst_dev, int w, int h, int n_frames, int flags,
                          int horizontal_blocks, int vertical_blocks);

@@ -98,3 +98,18 @@ def test_color_balance_library_exports_reference_entry():
         rc = lib.process_frame(arr.ctypes.data_as(C.c_void_p), C.c_size_t(4), C.c_size_t(4), C.c_size_t(3), True, False, True, False, True, False, 1, 1)
         assert rc == -2          # VP_ERR_HIP: no device, no CPU path
         assert lib.process_frame(arr.ctypes.data_as(C.c_void_p), C.c_size_t(4), C.c_size_t(4), C.c_size_t(4), True, False, True, False, True, False, 1, 1) == -1
+
+
+def test_facade_positional_order_is_cv2s():
+    """A module written against the real cv2 may pass dst / anchor / iterations positionally: the facade takes them in cv2's order
+    (cv2.erode(src, kernel, dst, anchor, iterations, borderType, borderValue), ...)."""
+    import inspect
+    from vision import cv2_facade as f
+    want = {"erode": ["src", "kernel", "dst", "anchor", "iterations", "borderType", "borderValue"],
+            "dilate": ["src", "kernel", "dst", "anchor", "iterations", "borderType", "borderValue"],
+            "morphologyEx": ["src", "op", "kernel", "dst", "anchor", "iterations", "borderType", "borderValue"],
+            "GaussianBlur": ["src", "ksize", "sigmaX", "dst", "sigmaY", "borderType"],
+            "warpAffine": ["src", "M", "dsize", "dst", "flags", "borderMode", "borderValue"],
+            "resize": ["src", "dsize", "dst", "fx", "fy", "interpolation"]}
+    for name, params in want.items():
+        assert list(inspect.signature(getattr(f, name)).parameters) == params, name

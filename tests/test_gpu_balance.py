@@ -39,11 +39,9 @@ def test_balance_vs_oracle(vp, oracle, flags):
     for i, (w, h) in enumerate([(320, 180), (257, 101), (64, 64), (5, 3)]):
         for f in (F.s1_buoy(i, w, h), F.s2_bins(i, w, h), F.s3_noise(i, w, h)):
             got = balance(f, **flags)
-            exp = oracle.color_balance(f, mean_mode=1, **flags)
+            exp = oracle.color_balance(f, mean_mode=0, **flags)     # the reference's running tile mean (cpp:452-467), literally
             assert got.shape == f.shape and got.dtype == np.uint8
             assert np.array_equal(got, exp), (flags, w, h, int((got != exp).sum()))
-            lit = oracle.color_balance(f, mean_mode=0, **flags)     # the reference's running mean, literally
-            assert np.abs(lit.astype(int) - exp.astype(int)).max() <= 1 and (lit != exp).mean() < 1e-3
 
 
 def test_balance_flat_and_degenerate_frames(vp, oracle):
@@ -51,11 +49,11 @@ def test_balance_flat_and_degenerate_frames(vp, oracle):
     from vision.modules.color_balance import balance
     for val in (0, 7, 128, 255):
         f = np.full((40, 60, 3), val, np.uint8)
-        assert np.array_equal(balance(f), oracle.color_balance(f, mean_mode=1))
+        assert np.array_equal(balance(f), oracle.color_balance(f, mean_mode=0))
     f = np.zeros((32, 32, 3), np.uint8)
     f[:, :, 2] = 200                                            # pure red: G and B means are 0 -> infinite gains
-    assert np.array_equal(balance(f), oracle.color_balance(f, mean_mode=1))
-    assert np.array_equal(balance(f, rgb_contrast_correct=True), oracle.color_balance(f, mean_mode=1, rgb_contrast_correct=True))
+    assert np.array_equal(balance(f), oracle.color_balance(f, mean_mode=0))
+    assert np.array_equal(balance(f, rgb_contrast_correct=True), oracle.color_balance(f, mean_mode=0, rgb_contrast_correct=True))
 
 
 def test_balance_tiles(vp, oracle):
@@ -65,20 +63,22 @@ def test_balance_tiles(vp, oracle):
     for hb, vb in [(2, 2), (4, 3), (1, 5), (8, 1)]:
         for extra in (dict(), dict(hsv_contrast_correct=False)):
             got = balance(f, horizontal_blocks=hb, vertical_blocks=vb, **extra)
-            exp = oracle.color_balance(f, horizontal_blocks=hb, vertical_blocks=vb, mean_mode=1, **extra)
+            exp = oracle.color_balance(f, horizontal_blocks=hb, vertical_blocks=vb, mean_mode=0, **extra)
             assert np.array_equal(got, exp), (hb, vb, extra)
     with pytest.raises(vp.VpError):
         balance(f, horizontal_blocks=3, vertical_blocks=1)      # 320 % 3 != 0: the reference wraps rows there
 
 
-def test_balance_adaptive_cast_within_one(vp, oracle):
-    """adaptive_cast_correction goes through pow(): device and host libm may round the last bit differently; tolerance 1."""
+def test_balance_adaptive_cast_exact(vp, oracle):
+    """adaptive_cast_correction (cpp:489-490) goes through pow((255. - v) / 255., 0.25): 256 possible arguments, tabulated with the
+    host's libm (the one the reference would call here), so the result is exact, not within one."""
     from vision.modules.color_balance import balance
-    f = F.s1_buoy(1, 320, 180)
-    got = balance(f, adaptive_cast_correction=True, hsv_contrast_correct=False)
-    exp = oracle.color_balance(f, adaptive_cast_correction=True, hsv_contrast_correct=False, mean_mode=1)
-    d = np.abs(got.astype(int) - exp.astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    for i, (w, h) in enumerate([(320, 180), (257, 101), (64, 64)]):
+        for f in (F.s1_buoy(i, w, h), F.s2_bins(i, w, h), F.s3_noise(i, w, h)):
+            for kw in (dict(hsv_contrast_correct=False), dict(), dict(rgb_contrast_correct=True)):
+                got = balance(f, adaptive_cast_correction=True, **kw)
+                exp = oracle.color_balance(f, adaptive_cast_correction=True, mean_mode=0, **kw)
+                assert np.array_equal(got, exp), (w, h, kw, int((got != exp).sum()))
 
 
 def test_balance_full_size_and_batch(vp, oracle):
@@ -87,7 +87,7 @@ def test_balance_full_size_and_batch(vp, oracle):
     from vision import _vp
     from vision.modules.color_balance import balance
     f = F.s1_buoy(0)
-    assert np.array_equal(balance(f), oracle.color_balance(f, mean_mode=1))
+    assert np.array_equal(balance(f), oracle.color_balance(f, mean_mode=0))
     n, h, w = 5, 72, 128
     frames = np.stack([F.s1_buoy(i, w, h) if i % 2 else F.s2_bins(i, w, h) for i in range(n)])
     ctx = _vp.default_context()
@@ -114,7 +114,7 @@ def test_balance_hsi_stage_within_one(vp, oracle, flags):
     for i, (w, h) in enumerate([(320, 180), (257, 101), (33, 7)]):
         for f in (F.s1_buoy(i, w, h), F.s2_bins(i, w, h), F.s3_noise(i, w, h)):
             got = balance(f, **flags)
-            exp = oracle.color_balance(f, mean_mode=1, **flags)
+            exp = oracle.color_balance(f, mean_mode=0, **flags)
             d = np.abs(got.astype(int) - exp.astype(int))
             assert d.max() <= 1, (flags, w, h, int(d.max()))
             assert (d > 0).mean() < 5e-3, (flags, w, h, float((d > 0).mean()))
@@ -124,3 +124,46 @@ def test_balance_hsi_stage_within_one(vp, oracle, flags):
     flat = np.full((16, 16, 3), 90, np.uint8)
     assert np.array_equal(balance(flat, hsi_contrast_correct=True, hsv_contrast_correct=False),
                           oracle.color_balance(flat, hsi_contrast_correct=True, hsv_contrast_correct=False))
+
+
+def _folds(vp):
+    import ctypes as C
+    ctx = vp.default_context()
+    n = C.c_int32(-1)
+    vp.check(vp.lib().vp_color_balance_last_folds(ctx.handle, C.byref(n)), ctx.handle)
+    return n.value
+
+
+def test_running_mean_is_reproduced_not_approximated(vp, oracle):
+    """The reference's tile mean is a sequential fold (avg += (x - avg) / count, cpp:466-468).  The kernels build the gain tables
+    from the exact mean only after checking that no value within a rigorous bound of it could change a table entry or a decision;
+    otherwise they run the fold.  Both routes must give the reference's result (oracle mean_mode=0) - here on frames made to need
+    the fold, and with the fold forced for every tile."""
+    from vision.modules.color_balance import balance
+    rng = np.random.default_rng(7)
+    # 1. ordinary frames take the certified route: no tile folded
+    f = F.s1_buoy(2, 320, 180)
+    assert np.array_equal(balance(f), oracle.color_balance(f, mean_mode=0)) and _folds(vp) == 0
+    assert np.array_equal(balance(f, horizontal_blocks=4, vertical_blocks=3), oracle.color_balance(f, horizontal_blocks=4, vertical_blocks=3, mean_mode=0))
+    assert _folds(vp) == 0
+    # 2. grey frames (B = G = R everywhere: one sequence, one fold value, gains exactly 1): certified as well
+    g = np.repeat(rng.integers(0, 256, (90, 160, 1), dtype=np.uint8), 3, axis=2)
+    assert np.array_equal(balance(g), oracle.color_balance(g, mean_mode=0)) and _folds(vp) == 0
+    # 3. two channels with the same histogram but different sequences: exact means equal, folds not -> the order of the two largest
+    #    means is in doubt -> fold
+    a = rng.integers(60, 200, (90, 160), dtype=np.uint8)
+    b = a.copy().ravel(); rng.shuffle(b); b = b.reshape(a.shape)
+    lowc = (a // 3).astype(np.uint8)
+    for order in ((0, 1, 2), (2, 0, 1), (1, 2, 0)):
+        planes = [a, b, lowc]
+        f = np.stack([planes[order[0]], planes[order[1]], planes[order[2]]], -1)
+        for kw in (dict(hsv_contrast_correct=False, rgb_extrema_clipping=False), dict()):
+            got = balance(f, **kw)
+            assert _folds(vp) == 1, (order, kw)
+            assert np.array_equal(got, oracle.color_balance(f, mean_mode=0, **kw)), (order, kw)
+    # 4. a tile mean sitting exactly on the 1/6 boundary of cpp:474: global mean 120, tile means 100 and 140
+    f = np.zeros((40, 80, 3), np.uint8)
+    f[:, :40] = (100, 50, 25); f[:, 40:] = (140, 70, 35)
+    got = balance(f, horizontal_blocks=2, vertical_blocks=1, hsv_contrast_correct=False, rgb_extrema_clipping=False)
+    assert _folds(vp) >= 1
+    assert np.array_equal(got, oracle.color_balance(f, horizontal_blocks=2, vertical_blocks=1, hsv_contrast_correct=False, rgb_extrema_clipping=False, mean_mode=0))

@@ -535,7 +535,7 @@ def test_gaussian_blur_u8(vp, oracle):
     for img in imgs:
         for (kw, kh), s1, s2 in [((3, 3), 0, 0), ((5, 5), 0, 0), ((7, 7), 0, 0), ((9, 9), 0, 0), ((11, 11), 0, 0), ((31, 31), 0, 0), ((5, 5), 1.3, 0),
                                  ((21, 3), 4.0, 0.7), ((1, 9), 0, 0), ((101, 101), 0, 0), ((201, 201), 0, 0)]:
-            got = cv2.GaussianBlur(img, (kw, kh), s1, s2)
+            got = cv2.GaussianBlur(img, (kw, kh), s1, sigmaY=s2)      # positional order is cv2's: the 4th positional is dst
             exp = oracle.gaussian_blur(img, (kw, kh), s1, s2)
             assert got.shape == img.shape and np.array_equal(got, exp), (img.shape, kw, kh, s1, s2)
     assert np.array_equal(T.simple_gaussian_blur(imgs[1], 7, 2.0), oracle.gaussian_blur(imgs[1], (7, 7), 2.0))

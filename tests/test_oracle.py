@@ -424,3 +424,19 @@ def test_adaptive_threshold_mean_restatement(oracle):
     flat = np.full((9, 9), 90, np.uint8)
     assert not oracle.adaptive_threshold_mean(flat, 255, False, 3, 0).any() and oracle.adaptive_threshold_mean(flat, 255, False, 3, 1).all()
     assert not oracle.adaptive_threshold_mean(flat, -1, True, 3, 0).any()
+
+
+def test_fold_bound_holds(oracle):
+    """|running mean - exact mean| stays below the bound the kernels rely on (cb_fold_bound in csrc/vp_balance.hip), on long
+    sequences of every kind: the bound is a proof, this is a check that it was typed correctly."""
+    rng = np.random.default_rng(1)
+    for n, gen in ((2_073_600, lambda n: rng.integers(0, 256, n)), (2_073_600, lambda n: np.full(n, 255)), (500_000, lambda n: np.arange(n) % 256),
+                   (300_000, lambda n: np.r_[np.zeros(n // 2), np.full(n - n // 2, 255)]), (7, lambda n: rng.integers(0, 256, n))):
+        x = gen(n).astype(np.float64)
+        avg = 0.0
+        k = np.arange(1, n + 1, dtype=np.float64)
+        for i in range(n):                          # the fold, literally (float64 scalar arithmetic = the C doubles)
+            avg += (x[i] - avg) / k[i]
+        exact = float(np.float64(int(x.sum())) / np.float64(n))
+        bound = (510.0 + 127.5 * (n + 1.0)) * 2.0 ** -53 * 1.001
+        assert abs(avg - exact) <= bound, (n, abs(avg - exact), bound)
