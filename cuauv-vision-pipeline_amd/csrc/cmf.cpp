@@ -54,6 +54,7 @@ struct ShmHeader {
 };
 static_assert(sizeof(ShmPlane) == 72, "plane layout");
 static_assert(sizeof(ShmSlot) == 360, "slot layout");
+constexpr size_t kSlotMetaOffset = offsetof(ShmSlot, acquisition_time);   // metadata = everything after the two sequence numbers
 static_assert(offsetof(ShmHeader, slots) == 24, "slots offset");
 static_assert(offsetof(ShmHeader, cond) == 1104, "cond offset");
 static_assert(offsetof(ShmHeader, mutex) == 1152, "mutex offset");
@@ -81,6 +82,37 @@ struct GlobalLock {
 
 inline uint64_t load_acq(const uint64_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 inline void store_rel(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+
+// Slot contents (metadata and payload) are read while the writer may be overwriting them; the sequence numbers decide afterwards
+// whether the copy is kept.  That is the seqlock's design, and to the C++ memory model (and to ThreadSanitizer) it is a data race
+// unless the racing accesses are atomic.  Normal builds copy with memcpy (what the hardware does is fine and a 6 MB frame must move
+// at memory speed); a build with -fsanitize=thread copies with relaxed atomic accesses instead, so that the sanitizer checks
+// everything else - sequence numbers, publication order, mutex / condition variable - without drowning in the intended race
+// (tests/native/cmf_tsan_main.cpp, run by tests/test_cmf.py).
+#if defined(__SANITIZE_THREAD__)
+#define CMF_TSAN 1
+#elif defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define CMF_TSAN 1
+#endif
+#endif
+#ifdef CMF_TSAN
+inline void racy_read(void* dst, const void* src, size_t n)
+{
+    unsigned char* d = static_cast<unsigned char*>(dst);
+    const unsigned char* s = static_cast<const unsigned char*>(src);
+    for (size_t i = 0; i < n; i++) d[i] = __atomic_load_n(s + i, __ATOMIC_RELAXED);
+}
+inline void racy_write(void* dst, const void* src, size_t n)
+{
+    unsigned char* d = static_cast<unsigned char*>(dst);
+    const unsigned char* s = static_cast<const unsigned char*>(src);
+    for (size_t i = 0; i < n; i++) __atomic_store_n(d + i, s[i], __ATOMIC_RELAXED);
+}
+#else
+inline void racy_read(void* dst, const void* src, size_t n) { memcpy(dst, src, n); }
+inline void racy_write(void* dst, const void* src, size_t n) { memcpy(dst, src, n); }
+#endif
 
 struct PrivFrame {   // what create_frame really allocates: the public Frame first, bookkeeping after
     Frame pub;
@@ -272,21 +304,24 @@ int write_frame_planes(Block* block, uint64_t acquisition_time, const FramePlane
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     unsigned char* dst = h->payload + idx * h->max_entry_size_bytes;
     size_t cursor = 0;
+    ShmSlot meta;                                       // the slot's metadata, built here and copied over in one go
+    memset(&meta, 0, sizeof meta);
     for (size_t i = 0; i < plane_count; i++) {
         const FramePlaneWrite& p = planes[i];
         const size_t bytes = p.width * p.height * p.depth * p.type_size;
-        memcpy(dst + cursor, p.data, bytes);
-        ShmPlane& m = s.planes[i];
+        racy_write(dst + cursor, p.data, bytes);
+        ShmPlane& m = meta.planes[i];
         m.width = p.width; m.height = p.height; m.depth = p.depth; m.type_size = p.type_size; m.offset = cursor;
-        memset(m.name, 0, sizeof m.name);
         if (p.name) strncpy(m.name, p.name, CMF_PLANE_NAME_MAX_LEN - 1);
         cursor += bytes;
     }
-    for (size_t i = plane_count; i < CMF_MAX_PLANE_CNT; i++) memset(&s.planes[i], 0, sizeof(ShmPlane));
-    s.acquisition_time = acquisition_time;
-    s.total_size = entry;
-    s.plane_count = plane_count;
-    s.width = planes[0].width; s.height = planes[0].height; s.depth = planes[0].depth; s.type_size = planes[0].type_size;
+    meta.acquisition_time = acquisition_time;
+    meta.total_size = entry;
+    meta.plane_count = plane_count;
+    meta.width = planes[0].width; meta.height = planes[0].height; meta.depth = planes[0].depth; meta.type_size = planes[0].type_size;
+    // everything after the two sequence numbers (they lead the slot and are written with release stores of their own)
+    racy_write(reinterpret_cast<unsigned char*>(&s) + kSlotMetaOffset, reinterpret_cast<const unsigned char*>(&meta) + kSlotMetaOffset,
+               sizeof(ShmSlot) - kSlotMetaOffset);
     store_rel(&s.seq_end, seq);                         // frame complete
     __atomic_fetch_add(&h->uid, 1, __ATOMIC_ACQ_REL);   // publish: slot uid % 3 is the newest
     pthread_cond_broadcast(&h->cond);
@@ -334,21 +369,24 @@ int read_frame(Block* block, Frame* frame, bool block_thread)
         const uint64_t uid = load_acq(&h->uid);
         const ShmSlot& s = h->slots[uid % CMF_BUFFER_CNT];
         const uint64_t end = load_acq(&s.seq_end);
-        frame->width = s.width; frame->height = s.height; frame->depth = s.depth; frame->type_size = s.type_size;
-        frame->acquisition_time = s.acquisition_time;
+        ShmSlot meta;
+        racy_read(reinterpret_cast<unsigned char*>(&meta) + kSlotMetaOffset, reinterpret_cast<const unsigned char*>(&s) + kSlotMetaOffset,
+                  sizeof(ShmSlot) - kSlotMetaOffset);
+        frame->width = meta.width; frame->height = meta.height; frame->depth = meta.depth; frame->type_size = meta.type_size;
+        frame->acquisition_time = meta.acquisition_time;
         frame->uid = uid;
-        size_t total = s.total_size;
+        size_t total = meta.total_size;
         if (total > h->max_entry_size_bytes) total = h->max_entry_size_bytes;   // torn metadata: retry below
         frame->total_size = total;
-        frame->plane_count = (size_t)s.plane_count <= CMF_MAX_PLANE_CNT ? (size_t)s.plane_count : 0;
+        frame->plane_count = (size_t)meta.plane_count <= CMF_MAX_PLANE_CNT ? (size_t)meta.plane_count : 0;
         for (size_t i = 0; i < CMF_MAX_PLANE_CNT; i++) {
-            const ShmPlane& m = s.planes[i];
+            const ShmPlane& m = meta.planes[i];
             FramePlane& o = frame->planes[i];
             o.width = m.width; o.height = m.height; o.depth = m.depth; o.type_size = m.type_size; o.offset = m.offset;
             memcpy(o.name, m.name, CMF_PLANE_NAME_MAX_LEN);
             o.name[CMF_PLANE_NAME_MAX_LEN - 1] = '\0';
         }
-        memcpy(frame->data, h->payload + (uid % CMF_BUFFER_CNT) * h->max_entry_size_bytes, total);
+        racy_read(frame->data, h->payload + (uid % CMF_BUFFER_CNT) * h->max_entry_size_bytes, total);
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
         const uint64_t begin = load_acq(&s.seq_begin);
         if (begin == end) return SUCCESS;

@@ -165,3 +165,23 @@ def test_blocking_read_wakes_on_write():
             st, data, t = r.read_frame()
         assert st == ReadStatus.SUCCESS and t == 9 and 0.05 < waited < 1.5
         assert r.unblock_thread().read_frame()[0] == ReadStatus.NO_NEW_FRAME
+
+
+def test_seqlock_under_thread_sanitizer(tmp_path):
+    """csrc/cmf.cpp built with -fsanitize=thread: one writer and two readers (polling and blocking) on one mapping
+    of a block; ThreadSanitizer must stay silent and no reader may accept a torn frame (tests/native/cmf_tsan_main.cpp)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is needed for the sanitizer build"
+    exe = str(tmp_path / "cmf_tsan")
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-Wno-tsan", "-I" + os.path.join(root, "include"),
+                            os.path.join(root, "cuauv-vision-pipeline_amd", "csrc", "cmf.cpp"), os.path.join(root, "tests", "native", "cmf_tsan_main.cpp"),
+                            "-o", exe, "-lpthread", "-lrt"], capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stderr[-2000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 report_signal_unsafe=0")
+    run = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300, env=env)
+    assert "ThreadSanitizer" not in run.stderr, run.stderr[-4000:]
+    assert run.returncode == 0, (run.returncode, run.stdout[-500:], run.stderr[-2000:])
+    assert "bad 0" in run.stdout
