@@ -2,6 +2,7 @@
 // batched device-resident chain.  No CPU arithmetic path exists here: every operator stages its
 // operands into HBM and launches the HIP kernels of vp_color / vp_morph / vp_ccl (+ contours) / vp_balance / vp_filter / vp_yolo.
 #include "vp_internal.h"
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,24 @@ const char* vp_last_error(const vp_ctx* ctx) { return ctx ? ctx->err : g_err; }
 int vp_get_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* hdiv180, int32_t* lab_coeffs)
 {
     vp_host_tables(gamma, cbrt_tab, sdiv, hdiv180, lab_coeffs);
+    return VP_OK;
+}
+
+int vp_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// "0000:05:00.0"-style PCI address of a device: /sys/bus/pci/devices/<address>/numa_node tells which host memory and cores sit next
+// to it (the multi-device dispatcher binds each feeder thread there)
+int vp_device_pci_bus_id(int device, char* out, int len)
+{
+    if (!out || len < 16) return VP_ERR_INVALID;
+    out[0] = 0;
+    hipError_t e = hipDeviceGetPCIBusId(out, len, device);
+    if (e != hipSuccess) return vp_fail(nullptr, VP_ERR_HIP, "hipDeviceGetPCIBusId", e);
+    for (char* c = out; *c; c++) *c = (char)tolower(*c);
     return VP_OK;
 }
 

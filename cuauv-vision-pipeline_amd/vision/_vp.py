@@ -61,6 +61,8 @@ _lock = threading.Lock()
 _SIGS = {
     "vp_version": (C.c_int, []),
     "vp_strerror": (C.c_char_p, [C.c_int]),
+    "vp_device_count": (C.c_int, []),
+    "vp_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "vp_create": (C.c_void_p, [C.c_int]),
     "vp_destroy": (C.c_int, [C.c_void_p]),
     "vp_last_error": (C.c_char_p, [C.c_void_p]),

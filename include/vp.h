@@ -48,6 +48,10 @@ int vp_version(void);
 const char* vp_strerror(int code);
 /* Creates a context on HIP device `device` with its own non-blocking stream. NULL on failure
  * (vp_last_error(NULL) tells why). */
+/* Devices visible to the process, and the PCI address ("0000:05:00.0") of one: /sys/bus/pci/devices/<address>/numa_node names the
+ * host NUMA node next to it (vision/dispatch.py binds each device's feeder threads there).  No context needed. */
+int vp_device_count(void);
+int vp_device_pci_bus_id(int device, char* out, int len);
 vp_ctx* vp_create(int device);
 int vp_destroy(vp_ctx* ctx);
 const char* vp_last_error(const vp_ctx* ctx);

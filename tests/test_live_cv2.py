@@ -95,3 +95,126 @@ def test_filters_and_warps(oracle):
     if (major, minor) <= (4, 10):
         assert d.max() == 0
 
+
+
+# ---- the checks that settle every open point of SURVEY Appendix A in one run wherever a real cv2 exists -----------
+
+def test_lab_all_2_pow_24_colours(oracle):
+    """A1: the complete sRGB cube through COLOR_BGR2LAB, in slabs; settles the LabCbrtTab_b rounding question (indices 49, 324, 628)."""
+    b, g = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    bad = 0
+    for r in range(256):
+        full = np.dstack([b, g, np.full_like(b, r)])
+        bad += int(np.any(oracle.bgr2lab(full) != cv2.cvtColor(full, cv2.COLOR_BGR2LAB), axis=2).sum())
+    assert bad == 0, f"{bad} of 2^24 colours differ in Lab"
+    bad = 0
+    for r in range(256):
+        full = np.dstack([b, g, np.full_like(b, r)])
+        bad += int(np.any(oracle.bgr2hsv(full) != cv2.cvtColor(full, cv2.COLOR_BGR2HSV), axis=2).sum())
+    assert bad == 0, f"{bad} of 2^24 colours differ in HSV"
+
+
+def _cv2_chain(frame, mode, lo, hi, ops):
+    if mode == "lab":
+        th = cv2.inRange(cv2.split(cv2.cvtColor(frame, cv2.COLOR_BGR2LAB))[1], lo, hi)          # modules/red_buoy.py:21-28
+    elif mode == "hsv":
+        th = cv2.inRange(cv2.cvtColor(frame, cv2.COLOR_BGR2HSV), np.array(lo), np.array(hi))       # modules/bins.py:13-16
+    else:
+        th = cv2.inRange(cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY), lo, hi)
+    k5 = cv2.getStructuringElement(cv2.MORPH_RECT, (5, 5))
+    cl = th
+    for op in ops:
+        cl = cv2.morphologyEx(cl, op, k5)                                                        # utils/transform.py:129,146
+    return th, cl
+
+
+def test_chain_end_to_end_on_the_bench_frames(oracle):
+    """The whole hot path as bench.py runs it (S1 red_buoy chain, S2 bins chain, S3 noise with and without morphology): masks, labels,
+    statistics, centroids and contours of the oracle against the literal cv2 call sequence of the reference's modules."""
+    cases = [("S1", F.s1_buoy, "lab", 150, 255, (cv2.MORPH_OPEN, cv2.MORPH_CLOSE)),
+             ("S2", F.s2_bins, "hsv", (10, 20, 60), (30, 100, 255), (cv2.MORPH_OPEN,)),
+             ("S3", F.s3_noise, "lab", 150, 255, (cv2.MORPH_OPEN, cv2.MORPH_CLOSE)),
+             ("S3 raw", F.s3_noise, "gray", 128, 255, ())]
+    for name, gen, mode, lo, hi, ops in cases:
+        for i in range(2):
+            frame = gen(i, 640, 360)
+            th, cl = _cv2_chain(frame, mode, lo, hi, ops)
+            if mode == "lab":
+                oth = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(frame)[:, :, 1]), lo, hi)
+            elif mode == "hsv":
+                oth = oracle.inrange(oracle.bgr2hsv(frame), lo, hi)
+            else:
+                oth = oracle.inrange(oracle.bgr2gray(frame), lo, hi)
+            ocl = oth
+            for op in ops:
+                ocl = oracle.morph({cv2.MORPH_OPEN: oracle.OPEN, cv2.MORPH_CLOSE: oracle.CLOSE}[op], ocl, np.ones((5, 5), np.uint8))
+            assert np.array_equal(oth, th), (name, i, "threshold mask")
+            assert np.array_equal(ocl, cl), (name, i, "cleaned mask")
+            n, lab, st, ce = cv2.connectedComponentsWithStats(cl, connectivity=8, ltype=cv2.CV_32S)
+            on, olab, ost, oce = oracle.ccl(cl, 2)
+            assert n == on and np.array_equal(lab, olab), (name, i, "labels: numbering follows the block scan (A8)")
+            assert np.array_equal(st, ost) and np.array_equal(ce.view(np.uint64), oce.view(np.uint64)), (name, i, "statistics")
+            for cvmode, omode in ((cv2.RETR_EXTERNAL, 0), (cv2.RETR_LIST, 1)):
+                cs = cv2.findContours(th, cvmode, cv2.CHAIN_APPROX_SIMPLE)[0]
+                exp = oracle.find_contours(th, omode, 2)
+                assert len(cs) == len(exp) and all(np.array_equal(a, b) for a, b in zip(cs, exp)), (name, i, "contours")
+
+
+def test_label_numbering_block_order_vs_pixel_order(oracle):
+    """A8: A first appears at (row 1, col 0), B at (row 0, col 10).  Pixel-raster order says B = 1; the block-based scan of
+    connectedComponentsWithStats (8-way, default algorithm) says A = 1.  Also the explicit algorithms, where this cv2 has them."""
+    m = np.zeros((4, 16), np.uint8)
+    m[1, 0] = 255
+    m[0, 10] = 255
+    n, lab, st, ce = cv2.connectedComponentsWithStats(m, connectivity=8, ltype=cv2.CV_32S)
+    on, olab, ost, oce = oracle.ccl(m, 2)
+    assert n == on == 3 and np.array_equal(lab, olab) and lab[1, 0] == 1 and lab[0, 10] == 2
+    if hasattr(cv2, "connectedComponentsWithStatsWithAlgorithm"):
+        for alg, block in ((getattr(cv2, "CCL_WU", None), 1), (getattr(cv2, "CCL_GRANA", None), 2), (getattr(cv2, "CCL_BOLELLI", None), 2),
+                           (getattr(cv2, "CCL_SPAGHETTI", None), 2), (getattr(cv2, "CCL_SAUF", None), 1), (getattr(cv2, "CCL_BBDT", None), 2)):
+            if alg is None:
+                continue
+            rng = np.random.default_rng(5)
+            for mask in (m, F.random_mask(rng, 41, 67, 0.35), F.random_mask(rng, 40, 66, 0.55)):
+                n2, lab2, st2, ce2 = cv2.connectedComponentsWithStatsWithAlgorithm(mask, 8, cv2.CV_32S, alg)
+                on2, olab2, ost2, _ = oracle.ccl(mask, block)
+                assert n2 == on2 and np.array_equal(lab2, olab2) and np.array_equal(st2, ost2), (alg, block)
+
+
+def test_contour_order_orientation_and_nesting(oracle):
+    """A6: list order (newest first), orientation of outer and hole borders, start points, RETR_EXTERNAL under nesting - on nested
+    rings, a ring inside a hole of a ring, shapes touching the frame, one-pixel walls."""
+    m = np.zeros((80, 120), np.uint8)
+    cv2.rectangle(m, (5, 5), (70, 70), 255, -1)
+    cv2.rectangle(m, (15, 15), (60, 60), 0, -1)          # ring
+    cv2.rectangle(m, (25, 25), (50, 50), 255, -1)
+    cv2.rectangle(m, (32, 32), (43, 43), 0, -1)          # ring inside the hole
+    cv2.rectangle(m, (36, 36), (39, 39), 255, -1)        # island inside the inner hole
+    cv2.circle(m, (100, 40), 15, 255, 1)                 # one-pixel-wide closed curve
+    m[0, 90:120] = 255                                   # touches the frame
+    m[79, 0] = 255
+    for cvmode, omode in ((cv2.RETR_EXTERNAL, 0), (cv2.RETR_LIST, 1)):
+        for method, ometh in ((cv2.CHAIN_APPROX_NONE, 1), (cv2.CHAIN_APPROX_SIMPLE, 2)):
+            cs = cv2.findContours(m, cvmode, method)[0]
+            exp = oracle.find_contours(m, omode, ometh)
+            assert len(cs) == len(exp), (cvmode, method, len(cs), len(exp))
+            for k, (a, b) in enumerate(zip(cs, exp)):
+                assert np.array_equal(a, b), (cvmode, method, k)
+    sq = np.zeros((20, 20), np.uint8)
+    sq[5:10, 4:12] = 255
+    c = cv2.findContours(sq, cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)[0][0].reshape(-1, 2).tolist()
+    assert c == oracle.find_contours(sq, 0, 2)[0].reshape(-1, 2).tolist() == [[4, 5], [4, 9], [11, 9], [11, 5]]   # TL, BL, BR, TR
+
+
+def test_polygon_helpers_and_balance_building_blocks(oracle):
+    rng = np.random.default_rng(9)
+    from vision.utils import feature
+    for n in (3, 4, 17, 200):
+        c = rng.integers(0, 1000, (n, 1, 2)).astype(np.int32)
+        mo = cv2.moments(c)
+        m00, m10, m01 = feature._polygon_moments(c)
+        assert (mo["m00"], mo["m10"], mo["m01"]) == (m00, m10, m01)
+        assert cv2.contourArea(c) == feature.contour_area(c)
+    hsv = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    hsv[:, :, 0] %= 180
+    assert np.array_equal(oracle.hsv2bgr(hsv, 0), cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR))
