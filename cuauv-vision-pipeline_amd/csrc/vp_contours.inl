@@ -660,20 +660,40 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     u64* selmap = maps3 + 2 * mstride;
     hipStream_t s = ctx->stream;
     ct_frame_out* info = reinterpret_cast<ct_frame_out*>(d_info);
-    int rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
-    if (rc != VP_OK) return rc;
-    rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags);
-    if (rc != VP_OK) return rc;
-    VP_HIP(ctx, hipMemsetAsync(outside, 0, nids / 8 * n, s));
-    VP_HIP(ctx, hipMemsetAsync(maps3, 0, 3 * mstride * 8, s));
+    // Two independent halves up to the seeds: background regions (4-connected union-find, then which of them reach the frame) on the
+    // context's side stream, foreground components and the head bitmaps on its own stream.  Each half is a chain of short,
+    // latency-bound launches, so side by side they take the time of one (one 1080p frame: 0.19 -> 0.15 ms per call).
     vp_prof_scope ps(ctx, VPK_OTHER);
     const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
     // heads per frame are not known on the host: a fixed number of blocks per frame walks the head list (a real mask has a few
     // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
     const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
-    hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum);
-    hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
-    hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gb, bg_parent, outside);
+    hipStream_t side = ctx->fb_stream;
+    VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s));
+    VP_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fb_fork, 0));
+    ctx->stream = side;
+    int rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags);
+    ctx->stream = s;
+    if (rc == VP_OK) {
+        hipError_t e = hipMemsetAsync(outside, 0, nids / 8 * n, side);
+        if (e != hipSuccess) rc = vp_fail(ctx, VP_ERR_HIP, "hipMemsetAsync", e);
+        else hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, side, d_bits, Gb, bg_parent, outside);
+    }
+    // join whatever was queued on the side stream, also after an error
+    const hipError_t j1 = hipEventRecord(ctx->ev_fb_join, side);
+    if (rc == VP_OK) rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
+    if (rc == VP_OK) {
+        hipError_t e = hipMemsetAsync(maps3, 0, 3 * mstride * 8, s);
+        if (e != hipSuccess) rc = vp_fail(ctx, VP_ERR_HIP, "hipMemsetAsync", e);
+    }
+    if (rc == VP_OK) {
+        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum);
+        hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
+    }
+    const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_fb_join, 0) : j1;
+    if (rc != VP_OK) return rc;
+    if (j1 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", j1);
+    if (j2 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", j2);
     hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
                        outside, mode, startmap, holemap, selmap);
     hipLaunchKernelGGL(k_ct_partsum, wgrid, dim3(256), 0, s, selmap, nwords, partsum2);
