@@ -6,7 +6,8 @@ from page-locked memory the 6.2 MB of a 1080p frame cross PCIe about twice as fa
 copy is made into a pinned buffer.  The result is an ordinary writable numpy array; its buffer returns to a small pool when the last
 reference to the array (or a view of it) is dropped, because hipHostMalloc / hipHostFree are far too slow to run per frame.
 
-Without a device (the plumbing tests on a CPU box) or with VP_PINNED_FRAMES=0 the copy is a plain numpy copy.
+Without a device context on the calling thread (a CPU box; a module that never calls an accelerated operator; the first frame) or with
+VP_PINNED_FRAMES=0 the copy is a plain numpy copy.
 """
 import ctypes as C
 import os
@@ -59,12 +60,18 @@ def pinned_like(shape, dtype):
     if addr is None:
         try:
             from vision import _vp
-            ctx = _vp.default_context()
+            # Never the first to touch the device: loading the HIP runtime and creating a context take a second or two when cold, and
+            # this runs inside the runtime's frame loop.  Frames become page-locked once the thread has a context, i.e. from the
+            # second frame of a module that uses the accelerated operators; a module that never does gets plain copies for ever.
+            ctxs = getattr(_vp._tls, "ctxs", None) if _vp._lib is not None else None
+            ctx = next((c for c in (ctxs or {}).values() if c.handle), None)
+            if ctx is None:
+                return None
             p = C.c_void_p()
             _vp.check(_vp.lib().vp_host_alloc(ctx.handle, cls, C.byref(p)), ctx.handle)
             addr = p.value
         except Exception:
-            _broken = True                           # no device / no library: plain copies from now on
+            _broken = True                           # allocation failed: plain copies from now on
             return None
     buf = (C.c_ubyte * cls).from_address(addr)
     weakref.finalize(buf, _release, addr, cls)

@@ -71,6 +71,8 @@ class Self:
         return len(contours), (x, y), area
 
 
+from vision import _vp as _vp0
+_vp0.default_context()      # the runtime's frame copies become page-locked once the thread has a context (from a module's second frame on)
 base = [F.s1_buoy(i, W, H) for i in range(4)]
 normal = np.zeros((H, W, 3), np.float32)
 for posts in (False, True):
