@@ -214,7 +214,7 @@ def main():
         # bench chain and once straight into the labelling (grey >= 128, no morphology: about half the pixels set, tens of thousands
         # of components per frame, max_labels sized for them)
         def side_run(tag, gen, mode, lo, hi, mops, ml, what):
-            nb = min(B, 32)
+            nb = B if ml <= 4096 else min(B, 32)      # the noise-labelling case needs 36 B of tables per label and frame
             fr = [gen(rank * 1000 + i, W, H) for i in range(4)]
             d_in = torch.from_numpy(np.stack([fr[i % 4] for i in range(nb)])).cuda()
             st = torch.zeros((nb, ml, 5), dtype=torch.int32, device="cuda")

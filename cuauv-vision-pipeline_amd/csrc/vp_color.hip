@@ -45,15 +45,25 @@ __device__ __forceinline__ void hsv_px(const HsvLds& t, int b, int g, int r, int
     int hh = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
     hh = (hh * t.hdiv[diff] + 2048) >> 12;
     hh += hh < 0 ? 180 : 0;
-    H = clamp255(hh);
+    H = hh;            // in [0, 180): the three branches give [-30, 30], [30, 90], [90, 150] before the wrap, so no clamp is needed
     V = v;
 }
 
 __device__ __forceinline__ int gray_px(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14; }
 
+// lo <= c <= hi per channel as one unsigned comparison each: (unsigned)(c - lo) <= (unsigned)(hi - lo).  For an empty range (lo > hi) the
+// span is taken as 0 and lo as INT_MAX, so that c - lo wraps to something large and the test fails for every c.
 __device__ __forceinline__ bool in3(const vp_range3& q, int c0, int c1, int c2)
 {
-    return (c0 >= q.lo[0]) & (c0 <= q.hi[0]) & (c1 >= q.lo[1]) & (c1 <= q.hi[1]) & (c2 >= q.lo[2]) & (c2 <= q.hi[2]);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int c = k == 0 ? c0 : (k == 1 ? c1 : c2);
+        const bool empty = q.lo[k] > q.hi[k];                              // wave-uniform (kernel arguments)
+        const u32 lo = empty ? 0x7fffffffu : (u32)q.lo[k], span = empty ? 0u : (u32)(q.hi[k] - q.lo[k]);
+        ok = ok & ((u32)c - lo <= span);
+    }
+    return ok;
 }
 
 template <int MODE>
