@@ -1,7 +1,7 @@
 """The labelling has two forms behind one entry point: the two-level path (strip components merged by one block per frame) and the
 one-level kernels, which also finish every frame the two-level path hands over as crowded.  All of them must produce cv2's result:
 every mask here goes through (a) the default, (b) the one-level kernels only, (c) the two-level path with the merge capacity at 0,
-so that every frame with foreground takes the hand-over to the side stream, (d) a small capacity, so that a batch mixes both kinds.
+so that every frame with foreground is handed over to the one-level kernels, (d) a small capacity, so that a batch mixes both kinds.
 Checked against the oracle (labels, stats, centroids bitwise, both numberings)."""
 import numpy as np
 import pytest
@@ -82,12 +82,30 @@ def test_shapes(ccl_ctx, oracle, numbering):
             raise AssertionError(f"{name}: {e}") from None
 
 
-@pytest.mark.parametrize("h,w", [(1, 1), (7, 3), (33, 65), (64, 64), (97, 257), (130, 1), (1, 130), (200, 420)])
+# (40, 2500) and (70, 4096): more than 32 words per row - the row masks of the strip-local pass come from two ballots, strips are 16 rows
+@pytest.mark.parametrize("h,w", [(1, 1), (7, 3), (33, 65), (64, 64), (97, 257), (130, 1), (1, 130), (200, 420), (40, 2500), (70, 4096), (35, 2049)])
 def test_random(ccl_ctx, oracle, h, w):
     rng = np.random.default_rng(h * 31 + w)
     for p in (0.02, 0.2, 0.5, 0.62, 0.97):
         for numbering in (2, 1):
             _check(oracle, F.random_mask(rng, h, w, p), numbering)
+
+
+def test_wide_frames_with_blobs(ccl_ctx, oracle):
+    """Blobs that cross word 32 of a row and several strips, full rows, runs that span all 64 words."""
+    yy, xx = np.mgrid[0:90, 0:4096]
+    m = np.zeros((90, 4096), np.uint8)
+    rng = np.random.default_rng(21)
+    for _ in range(30):
+        cx, cy, rx, ry = rng.uniform(0, 4096), rng.uniform(0, 90), rng.uniform(5, 400), rng.uniform(3, 30)
+        m[((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1] = 255
+    m[40, :] = 255                                       # one run through all 64 words
+    m[60:62, 1000:3100] = 255
+    for numbering in (2, 1):
+        _check(oracle, m, numbering)
+    m2 = np.full((48, 3840), 255, np.uint8)
+    m2[10:20, 2040:2060] = 0
+    _check(oracle, m2, 2)
 
 
 def test_truncated_tables(ccl_ctx, oracle):

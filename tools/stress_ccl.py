@@ -18,7 +18,9 @@ t = {"thr": torch.empty((B, H, W), dtype=torch.uint8, device="cuda"), "cln": tor
      "ce": torch.zeros((B, 64, 2), dtype=torch.float64, device="cuda"), "nl": torch.zeros((B,), dtype=torch.int32, device="cuda")}
 b = _vp.ChainBuffers(); b.bgr = big.data_ptr()
 b.threshed, b.cleaned, b.labels, b.stats, b.centroids, b.nlabels = (t[k].data_ptr() for k in ("thr", "cln", "lab", "st", "ce", "nl"))
-desc = _vp.make_chain_desc(W, H, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), [(_vp.MORPH_OPEN, 5, 5), (_vp.MORPH_CLOSE, 5, 5)], ccl=1, max_labels=64)
+LO = int(os.environ.get("LO", "150"))            # 118: background speckle (hundreds of components, real unions in the strip-local pass)
+MORPH = [] if os.environ.get("NOMORPH") else [(_vp.MORPH_OPEN, 5, 5), (_vp.MORPH_CLOSE, 5, 5)]
+desc = _vp.make_chain_desc(W, H, _vp.BGR2LAB, (0, LO, 0), (255, 255, 255), MORPH, ccl=1, max_labels=64)
 bad_total = 0
 if os.environ.get("REFSMALL"):   # the same frames as a batch of D in a call of its own: the big batch must reproduce it
     ts = {"thr": torch.empty((D, H, W), dtype=torch.uint8, device="cuda"), "cln": torch.empty((D, H, W), dtype=torch.uint8, device="cuda"),
