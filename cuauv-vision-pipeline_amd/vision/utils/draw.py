@@ -2,9 +2,49 @@
 Only what the in-scope modules call: `draw_contours` (modules/red_buoy.py:39) and `draw_polylines`, as plain numpy
 rasterisation (lines between consecutive contour points, square brush of the requested thickness; -1 fills by even-odd
 scanline).  Pixel-exact agreement with cv2's anti-alias-free line drawing is not claimed."""
+from enum import Enum
 from typing import List, Tuple
 
 import numpy as np
+
+
+class Color(Enum):
+    """Named BGR colours of the reference's utils/draw.py:9-37 (values are its palette; `Color.LIME()` gives the tuple)."""
+    RED = (75, 25, 230)
+    GREEN = (75, 180, 60)
+    YELLOW = (0, 225, 255)
+    BLUE = (200, 130, 0)
+    ORANGE = (48, 130, 245)
+    PURPLE = (180, 30, 145)
+    CYAN = (240, 240, 70)
+    MAGENTA = (230, 50, 240)
+    LIME = (60, 245, 210)
+    PINK = (212, 190, 250)
+    TEAL = (128, 128, 0)
+    LAVENDER = (255, 190, 220)
+    BROWN = (40, 110, 170)
+    BEIGE = (200, 250, 255)
+    MAROON = (0, 0, 128)
+    MINT = (195, 255, 170)
+    OLIVE = (0, 128, 128)
+    APRICOT = (180, 215, 255)
+    NAVY = (128, 0, 0)
+    GREY = (128, 128, 128)
+    WHITE = (255, 255, 255)
+    BLACK = (0, 0, 0)
+    HOTPINK = (180, 105, 255)
+    DEEPPINK = (147, 20, 255)
+    FUCHSIA = (255, 0, 255)
+
+    def __call__(self):
+        return self.value
+
+
+def get_color(color_name: str):
+    try:
+        return Color[color_name.upper()].value
+    except KeyError:
+        raise ValueError(f"{color_name} is not a valid color name")
 
 
 def _stamp(mat, x, y, color, r0, r1):

@@ -4,4 +4,4 @@ the handlers read (`OBBData`: handlers/torpedoes.py:76-82 uses name, confidence,
 The reference imports `vision.yolo.data` (modules/yolo.py:15) but that package is not in its tree, and the steps themselves live
 inside ultralytics; see include/vp.h for what these functions follow."""
 from vision.yolo.ops import letterbox, nms, nms_rotated, order_points, scale_boxes  # noqa: F401
-from vision.yolo.data import OBBData, YOLOData  # noqa: F401
+from vision.yolo.data import MAP_FN, OBBData, PoseData, YOLOData  # noqa: F401
