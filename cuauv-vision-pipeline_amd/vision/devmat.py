@@ -12,6 +12,11 @@ reaches host memory only when Python looks at it.
   * a host copy that may have been written to (handed out writable, indexed for assignment, used as `out=`) invalidates the
     device copy, so a later operator call uploads the host data again — results never depend on which side was used.
 
+  * an operator whose input is such an image and whose result is one (morphology) does not even launch until the result is needed
+    (`DeviceMat.deferred`): by the next operator, by the host, or - before the input changes - by a host-side write to the input.
+    A module that computes a cleaned mask only to post it (modules/red_buoy.py:26-31) then pays nothing for it when posts are off
+    (`--enable-performance`, core/base.py:846-876).  `VP_DEFER=0` launches every operator at its call.
+
 It is not an `np.ndarray` subclass (numpy offers no hook on raw buffer reads, so a subclass could not be lazy); code that
 insists on `isinstance(x, np.ndarray)` can call `np.asarray(x)`.  `VP_LAZY=0` (or `set_lazy(False)`) makes the mirror return
 plain numpy arrays, as in round 1.
@@ -26,6 +31,16 @@ import numpy as np
 from vision import _vp
 
 _lazy = os.environ.get("VP_LAZY", "1") != "0"
+_defer = os.environ.get("VP_DEFER", "1") != "0"
+
+
+def set_defer(on: bool):
+    global _defer
+    _defer = bool(on)
+
+
+def defer_enabled() -> bool:
+    return _defer and _lazy
 
 
 def set_lazy(on: bool):
@@ -114,7 +129,7 @@ class DeviceMat:
     """(h, w) or (h, w, c) image, tightly packed, whose authoritative copy may be on the device (`_dev_ok`), on the host
     (`_host` is not None and `_host_ok`), or both."""
     __array_priority__ = 100.0
-    __slots__ = ("_ctx", "_buf", "_shape", "_dtype", "_host", "_dev_ok", "binary", "__weakref__")
+    __slots__ = ("_ctx", "_buf", "_shape", "_dtype", "_host", "_dev_ok", "binary", "_pending", "_consumers", "__weakref__")
 
     def __init__(self, ctx, shape, dtype=np.uint8, binary=False):
         self._ctx = ctx
@@ -124,10 +139,50 @@ class DeviceMat:
         self._host = None
         self._dev_ok = True
         self.binary = bool(binary)          # known to hold only 0 / 255 (a mask made by this library)
+        self._pending = None
+        self._consumers = None
+
+    @classmethod
+    def deferred(cls, ctx, shape, dtype, binary, inputs, run):
+        """Result of an operator between device images that has not been launched yet: `run(out)` launches it into `out.dev_ptr`
+        (the inputs' `dev_ptr` are valid then).  It runs when the result is first needed, at the latest just before one of `inputs` is
+        handed to the host for writing - so the result is always the one an immediate launch would have given."""
+        m = object.__new__(cls)
+        m._ctx, m._shape, m._dtype = ctx, tuple(int(s) for s in shape), np.dtype(dtype)
+        m._buf, m._host, m._dev_ok, m.binary, m._consumers = None, None, True, bool(binary), None
+        m._pending = run
+        for x in inputs:
+            if x._consumers is None:
+                x._consumers = []
+            elif len(x._consumers) > 8:
+                x._consumers = [r for r in x._consumers if (c := r()) is not None and c._pending is not None]
+            x._consumers.append(weakref.ref(m))
+        return m
+
+    def _force(self):
+        run = self._pending
+        if run is not None:
+            self._pending = None
+            if not self._ctx.handle:
+                raise _vp.VpError("the context that owns this image was closed before the image was computed")
+            self._buf = _DevBuf(self._ctx, int(np.prod(self._shape)) * self._dtype.itemsize)
+            run(self)
+
+    def _before_host_write(self):
+        """Pending operators that read this image run before its contents can change."""
+        cs = self._consumers
+        if cs:
+            self._consumers = None
+            for r in cs:
+                c = r()
+                if c is not None:
+                    c._force()
 
     # ---- what the operator wrappers use ------------------------------------------------------------------------------------
     @property
     def dev_ptr(self):
+        if self._pending is not None:
+            self._force()
         return self._buf.ptr
 
     def device_valid_for(self, ctx):
@@ -143,8 +198,10 @@ class DeviceMat:
 
     def reshaped(self, shape):
         """Same data under another shape (e.g. (h, w, 1) -> (h, w)); shares the device buffer, copies nothing."""
+        self._force()
         m = object.__new__(DeviceMat)
         m._ctx, m._buf, m._dtype, m._dev_ok, m.binary = self._ctx, self._buf, self._dtype, self._dev_ok, self.binary
+        m._pending, m._consumers = None, self._consumers
         m._shape = tuple(int(x) for x in shape)
         m._host = None if self._host is None else self._host.reshape(m._shape)
         if not self._dev_ok and m._host is None:
@@ -153,6 +210,10 @@ class DeviceMat:
 
     def host(self, writable=True):
         """The host copy (one D2H the first time).  Handing it out writable makes it the authoritative copy."""
+        if self._pending is not None:
+            self._force()
+        if writable:
+            self._before_host_write()
         if self._host is None:
             out = np.empty(self._shape, self._dtype)
             ctx = self._ctx
@@ -170,6 +231,10 @@ class DeviceMat:
 
     def refresh_device(self, ctx):
         """Device copy of the current contents on `ctx` (re-uploads after host-side writes or a change of context)."""
+        if self._pending is not None:
+            if ctx is self._ctx:
+                return None                      # not launched yet: `dev_ptr` launches it, on this very context
+            self._force()
         if self.device_valid_for(ctx):
             return self._buf.ptr
         h = self.host(writable=False)
@@ -233,7 +298,7 @@ class DeviceMat:
         return getattr(self.host(writable=True), name)
 
     def __repr__(self):
-        where = "device" if self._host is None else ("host+device" if self._dev_ok else "host")
+        where = "not computed yet" if self._pending is not None else "device" if self._host is None else ("host+device" if self._dev_ok else "host")
         return f"DeviceMat(shape={self._shape}, dtype={self._dtype}, on={where})"
 
     def __bool__(self):

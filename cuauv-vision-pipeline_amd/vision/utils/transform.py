@@ -9,7 +9,7 @@ from typing import Optional
 import numpy as np
 
 from vision import _vp
-from vision.devmat import DeviceMat, lazy_enabled
+from vision.devmat import DeviceMat, defer_enabled, lazy_enabled
 from vision.utils.helpers import as_mat, device_image
 
 
@@ -55,9 +55,17 @@ def _morph(op, mat, kernel, iterations, anchor=(-1, -1)):
         src = device_image(ctx, mat, 0)
         h, w = src.shape[:2]
         cn = 1 if src.ndim == 2 else src.shape[2]
-        out = DeviceMat(ctx, src.shape, binary=src.binary)
-        _vp.check(_vp.lib().vp_morph_u8_dev(ctx.handle, op, src.dev_ptr, w, h, cn, kp, kw, kh, int(anchor[0]), int(anchor[1]), int(iterations),
-                                            1 if src.binary else 0, out.dev_ptr), ctx.handle)
+        binary = src.binary
+        ax, ay, it = int(anchor[0]), int(anchor[1]), int(iterations)
+
+        def run(out, src=src, kernel=kernel):          # (keeps the source image and the kernel array alive until it has run)
+            _vp.check(_vp.lib().vp_morph_u8_dev(ctx.handle, op, src.dev_ptr, w, h, cn, kp, kw, kh, ax, ay, it, 1 if binary else 0, out.dev_ptr), ctx.handle)
+        if defer_enabled():
+            if it < 0 or (kp is not None and (ax >= kw or ay >= kh)):
+                raise _vp.VpError("libvp: invalid argument: structuring element")   # what the launch would report, reported at the call
+            return DeviceMat.deferred(ctx, src.shape, np.uint8, binary, (src,), run)
+        out = DeviceMat(ctx, src.shape, binary=binary)
+        run(out)
         return out
     src = np.ascontiguousarray(mat)
     h, w = src.shape[:2]

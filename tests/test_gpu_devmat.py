@@ -158,3 +158,56 @@ def test_polygon_sums_equal_the_sequential_loop(vp):
         assert feature._polygon_moments(c) == feature._polygon_moments_float(c.reshape(-1, 2).astype(np.float64))
     sq = np.array([[[10, 10]], [[10, 30]], [[50, 30]], [[50, 10]]], np.int32)
     assert feature.contour_area(sq) == 800.0 and feature.contour_centroid(sq) == (30, 20)
+
+
+def test_operators_between_device_images_run_when_needed(vp, oracle):
+    """Morphology on a device image is launched when its result is needed (or just before its input changes), never earlier; the
+    result is what an immediate launch gives."""
+    from vision import devmat
+    from vision.utils.color import range_threshold
+    from vision.utils.transform import dilate, erode, morph_close_holes, morph_remove_noise, rect_kernel
+    g = np.ascontiguousarray(F.s1_buoy(4, 320, 200)[:, :, 2])
+    k5, k3 = np.ones((5, 5), np.uint8), np.ones((3, 3), np.uint8)
+    oth = oracle.inrange(g, 150, 255)
+    th = range_threshold(g, 150, 255)
+    a = morph_remove_noise(th, rect_kernel(5))
+    b = morph_close_holes(a, rect_kernel(5))                 # a pending result as the input of the next
+    assert a._pending is not None and b._pending is not None and a.binary and b.binary and a.shape == th.shape
+    assert "not computed" in repr(b)
+    ob = oracle.morph(oracle.CLOSE, oracle.morph(oracle.OPEN, oth, k5), k5)
+    assert np.array_equal(b, ob) and a._pending is None and b._pending is None
+    assert np.array_equal(a, oracle.morph(oracle.OPEN, oth, k5))
+    # the input is written to on the host after the call: the result is that of the contents at the call
+    th = range_threshold(g, 150, 255)
+    d = dilate(th, rect_kernel(3))
+    e = erode(d, rect_kernel(3))
+    th[20:60, 30:90] = 255
+    assert d._pending is None and e._pending is not None      # d had to run before th changed; e reads d, which did not change
+    assert np.array_equal(d, oracle.morph(oracle.DILATE, oth, k3))
+    assert np.array_equal(e, oracle.morph(oracle.ERODE, oracle.morph(oracle.DILATE, oth, k3), k3))
+    oth2 = oth.copy(); oth2[20:60, 30:90] = 255
+    assert np.array_equal(dilate(th, rect_kernel(3)), oracle.morph(oracle.DILATE, oth2, k3))
+    # same through a numpy view handed out earlier (the view is the authoritative copy from then on)
+    th = range_threshold(g, 150, 255)
+    view = np.asarray(th)
+    d = dilate(th, rect_kernel(3))                            # uploads the host copy at the call
+    view[:] = 0
+    assert np.array_equal(d, oracle.morph(oracle.DILATE, oth, k3))
+    # a result nobody looks at costs no launch, and dropping it is fine
+    th = range_threshold(g, 150, 255)
+    ctx = vp.default_context()
+    ctx.profile_begin(64)
+    x = morph_remove_noise(th, rect_kernel(5))
+    del x
+    prof = ctx.profile_end()
+    assert not prof or sum(v[1] for v in prof.values()) == 0, prof
+    # arguments are checked at the call, not at first use
+    with pytest.raises(vp.VpError):
+        erode(th, rect_kernel(3), iterations=-1)
+    # switch off: launched at the call
+    devmat.set_defer(False)
+    try:
+        y = erode(th, rect_kernel(3))
+        assert y._pending is None and np.array_equal(y, oracle.morph(oracle.ERODE, oth, k3))
+    finally:
+        devmat.set_defer(True)
