@@ -90,6 +90,7 @@ vp_ctx* vp_create(int device)
     if (hipStreamCreateWithFlags(&ctx->fb_stream, hipStreamNonBlocking) != hipSuccess) { vp_fail(nullptr, VP_ERR_HIP, "side stream"); delete ctx; return nullptr; }
     hipEventCreateWithFlags(&ctx->ev_fb_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_fb_join, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming);
     ctx->ccl_levels = 2;
     ctx->ccl_mcap = -1;
     if (const char* env = getenv("VP_CCL_LEVELS")) { const int v = atoi(env); if (v == 1 || v == 2) ctx->ccl_levels = v; }
@@ -130,6 +131,7 @@ int vp_destroy(vp_ctx* ctx)
     hipStreamDestroy(ctx->fb_stream);
     hipEventDestroy(ctx->ev_fb_fork);
     hipEventDestroy(ctx->ev_fb_join);
+    hipEventDestroy(ctx->ev_upload);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VP_OK;
@@ -250,6 +252,21 @@ int vp_memcpy_h2d(vp_ctx* ctx, void* dst, const void* src, size_t bytes)
     if (!ctx) return VP_ERR_INVALID;
     VP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VP_OK;
+}
+// Enqueues the copy and marks its end on the stream; vp_wait_uploads returns once every copy enqueued so far has read its source
+// (kernels enqueued behind the copies are not waited for).
+int vp_memcpy_h2d_async(vp_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VP_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+    return VP_OK;
+}
+int vp_wait_uploads(vp_ctx* ctx)
+{
+    if (!ctx) return VP_ERR_INVALID;
+    VP_HIP(ctx, hipEventSynchronize(ctx->ev_upload));
     return VP_OK;
 }
 int vp_memcpy_d2h(vp_ctx* ctx, void* dst, const void* src, size_t bytes)

@@ -189,11 +189,18 @@ class DeviceMat:
         return self._dev_ok and ctx is self._ctx and bool(ctx.handle)
 
     @classmethod
-    def from_host(cls, ctx, arr, binary=False):
-        """Uploads a packed host array; the host array is NOT kept (the caller may go on mutating it)."""
+    def from_host(cls, ctx, arr, binary=False, pending=None):
+        """Uploads a packed host array; the host array is NOT kept (the caller may go on mutating it).
+        pending: a list - the copy is only enqueued and the packed array appended to the list; the caller must `finish_uploads(ctx,
+        pending)` before it hands control back to code that could change `arr` (an operator sets up its results and launches in
+        between, while the copy crosses PCIe)."""
         arr = np.ascontiguousarray(arr)
         m = cls(ctx, arr.shape, arr.dtype, binary)
-        _vp.check(_vp.lib().vp_memcpy_h2d(ctx.handle, m._buf.ptr, arr.ctypes.data, arr.nbytes), ctx.handle)
+        if pending is None:
+            _vp.check(_vp.lib().vp_memcpy_h2d(ctx.handle, m._buf.ptr, arr.ctypes.data, arr.nbytes), ctx.handle)
+        else:
+            _vp.check(_vp.lib().vp_memcpy_h2d_async(ctx.handle, m._buf.ptr, arr.ctypes.data, arr.nbytes), ctx.handle)
+            pending.append(arr)                      # (a packed temporary must outlive the copy)
         return m
 
     def reshaped(self, shape):
@@ -342,6 +349,15 @@ DeviceMat.__neg__ = lambda self: np.negative(self)
 DeviceMat.__pos__ = lambda self: np.positive(self)
 DeviceMat.__abs__ = lambda self: np.absolute(self)
 DeviceMat.__invert__ = lambda self: np.invert(self)
+
+
+def finish_uploads(ctx, pending):
+    """Returns once the copies enqueued with from_host(..., pending=pending) have read their host arrays."""
+    if pending:
+        try:
+            _vp.check(_vp.lib().vp_wait_uploads(ctx.handle), ctx.handle)
+        finally:
+            del pending[:]
 
 
 def to_host(x):

@@ -11,7 +11,7 @@ from typing import Callable, List, Tuple
 import numpy as np
 
 from vision import _vp
-from vision.devmat import DeviceMat, lazy_enabled, to_host
+from vision.devmat import DeviceMat, finish_uploads, lazy_enabled, to_host
 from vision.utils.helpers import as_mat, device_image
 
 
@@ -43,20 +43,24 @@ def _convert_colorspace(code: int) -> Callable[[np.ndarray], Tuple[np.ndarray, T
     def _inner_device(mat):
         """The image stays in HBM: results are DeviceMat (vision/devmat.py), nothing is downloaded here."""
         ctx = _vp.default_context()
-        src = device_image(ctx, mat, scn)
-        h, w = src.shape[:2]
-        conv = DeviceMat(ctx, (h, w) if dcn == 1 else (h, w, 3))
-        planes = [DeviceMat(ctx, (h, w)) for _ in range(dcn)] if (dcn == 3 and want_planes) else []
-        arr = (_vp.C.c_void_p * 3)(*[p.dev_ptr for p in planes], *([None] * (3 - len(planes))))
-        _vp.check(_vp.lib().vp_cvt_color_dev(ctx.handle, code, src.dev_ptr, w * scn, w, h, conv.dev_ptr, arr if planes else None), ctx.handle)
-        if not want_planes:                           # HSV2BGR (colour-balance helper): channel copies are host views
-            hc = conv.host(writable=False)
-            return conv, tuple(np.ascontiguousarray(hc[:, :, c]) for c in range(3))
-        if planes:
-            return conv, tuple(planes)
-        second = DeviceMat(ctx, (h, w))               # cv2.split of a single-channel image: a 1-tuple holding a copy
-        _vp.check(_vp.lib().vp_cvt_color_dev(ctx.handle, code, src.dev_ptr, w * scn, w, h, second.dev_ptr, None), ctx.handle)
-        return conv, (second,)
+        up = []                                       # a host image is copied while the results are set up and the kernel is enqueued
+        src = device_image(ctx, mat, scn, pending=up)
+        try:
+            h, w = src.shape[:2]
+            conv = DeviceMat(ctx, (h, w) if dcn == 1 else (h, w, 3))
+            planes = [DeviceMat(ctx, (h, w)) for _ in range(dcn)] if (dcn == 3 and want_planes) else []
+            arr = (_vp.C.c_void_p * 3)(*[p.dev_ptr for p in planes], *([None] * (3 - len(planes))))
+            _vp.check(_vp.lib().vp_cvt_color_dev(ctx.handle, code, src.dev_ptr, w * scn, w, h, conv.dev_ptr, arr if planes else None), ctx.handle)
+            if not want_planes:                           # HSV2BGR (colour-balance helper): channel copies are host views
+                hc = conv.host(writable=False)
+                return conv, tuple(np.ascontiguousarray(hc[:, :, c]) for c in range(3))
+            if planes:
+                return conv, tuple(planes)
+            second = DeviceMat(ctx, (h, w))               # cv2.split of a single-channel image: a 1-tuple holding a copy
+            _vp.check(_vp.lib().vp_cvt_color_dev(ctx.handle, code, src.dev_ptr, w * scn, w, h, second.dev_ptr, None), ctx.handle)
+            return conv, (second,)
+        finally:
+            finish_uploads(ctx, up)                   # the caller's array may change from here on
 
     def _inner(mat: np.ndarray):
         mat = as_mat(mat)
@@ -163,21 +167,34 @@ def range_threshold(mat: np.ndarray, min, max) -> np.ndarray:
         return out
     cn = 3 if (isinstance(mat, (np.ndarray, DeviceMat)) and mat.ndim == 3 and mat.shape[2] == 3) else 1
     on_device = lazy_enabled() or isinstance(mat, DeviceMat)
-    mat = device_image(ctx, mat, cn) if on_device else _u8_image(mat, cn)
+    up = []
+    mat = device_image(ctx, mat, cn, pending=up) if on_device else _u8_image(mat, cn)
     h, w = mat.shape[:2]
 
     def bounds(b):
+        if cn == 1 and type(b) in (int, float):          # the common call: Python numbers for one plane
+            v = float(b)
+            if -1e18 < v < 1e18:                         # (NaN and infinities take the general path below)
+                r = round(v)                             # half to even, like np.rint (`min` / `max` are this function's parameters)
+                return np.array([-2**31 if r < -2**31 else 2**31 - 1 if r > 2**31 - 1 else r], np.int32)
         b = np.atleast_1d(np.asarray(b, dtype=np.float64)).ravel()
         if b.size == 1 and cn == 3:
             b = np.array([b[0], 0.0, 0.0])  # cv2 scalar -> (v, 0, 0, 0)
         if b.size < cn:
             raise ValueError("bounds need one value per channel")
         return np.ascontiguousarray(np.clip(np.rint(b[:cn]), -2**31, 2**31 - 1).astype(np.int32))
-    lo, hi = bounds(min), bounds(max)
+    try:
+        lo, hi = bounds(min), bounds(max)
+    except BaseException:
+        finish_uploads(ctx, up)
+        raise
     if on_device:
-        out = DeviceMat(ctx, (h, w), binary=True)
-        _vp.check(_vp.lib().vp_inrange_u8_dev(ctx.handle, mat.dev_ptr, w * cn, w, h, cn, _vp.ptr(lo), _vp.ptr(hi), out.dev_ptr), ctx.handle)
-        return out
+        try:
+            out = DeviceMat(ctx, (h, w), binary=True)
+            _vp.check(_vp.lib().vp_inrange_u8_dev(ctx.handle, mat.dev_ptr, w * cn, w, h, cn, _vp.ptr(lo), _vp.ptr(hi), out.dev_ptr), ctx.handle)
+            return out
+        finally:
+            finish_uploads(ctx, up)
     out = np.empty((h, w), np.uint8)
     _vp.check(_vp.lib().vp_inrange_u8(ctx.handle, _vp.ptr(mat), mat.strides[0], w, h, cn, _vp.ptr(lo), _vp.ptr(hi), _vp.ptr(out)), ctx.handle)
     return out

@@ -7,6 +7,8 @@ utils/feature.py:240-265) are float64 scalar arithmetic on a handful of points a
 """
 from typing import List, Tuple
 
+import threading
+
 import numpy as np
 
 from vision import _vp
@@ -39,12 +41,21 @@ def connected_components(mat: np.ndarray, numbering: int = _vp.CCL_BLOCK2X2, max
     return n.value, labels, stats[:k].copy(), cent[:k].copy()
 
 
+_sums_tls = threading.local()
+
+
 def _green_sums(pts):
     """(a00, a10, a01) of an integer contour as Python ints: one native pass (libvp vp_polygon_sums_i32, host code)."""
     p32 = pts if (pts.dtype == np.int32 and pts.flags.c_contiguous) else np.ascontiguousarray(pts, np.int32)
-    out = np.empty(3, np.int64)
-    _vp.check(_vp.lib().vp_polygon_sums_i32(p32.ctypes.data, len(p32), out.ctypes.data))
-    return int(out[0]), int(out[1]), int(out[2])
+    t = _sums_tls
+    try:
+        out, fn = t.out, t.fn
+    except AttributeError:                             # per thread: the result buffer and the resolved entry point
+        out = t.out = (_vp.C.c_int64 * 3)()
+        fn = t.fn = _vp.lib().vp_polygon_sums_i32
+    if fn(p32.__array_interface__["data"][0], len(p32), out) != 0:
+        raise _vp.VpError("vp_polygon_sums_i32: invalid argument")
+    return out[0], out[1], out[2]
 
 
 def _polygon_moments(contour: np.ndarray):
@@ -199,9 +210,10 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
         max_c = max(max_c, 2 * nc.value)
         max_p = max(max_p, 2 * npts.value)
     out, o = [], 0
-    for k in range(nc.value):
-        out.append(pts[o:o + counts[k]].reshape(-1, 1, 2).copy())
-        o += int(counts[k])
+    pts3 = pts.reshape(-1, 1, 2)
+    for c in counts[:nc.value].tolist():
+        out.append(pts3[o:o + c].copy())
+        o += c
     return (tuple(out), holes[:nc.value].copy()) if with_holes else tuple(out)
 
 

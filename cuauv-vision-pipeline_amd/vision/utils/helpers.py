@@ -10,9 +10,9 @@ def as_mat(mat):
     return get() if callable(get) else mat
 
 
-def device_image(ctx, mat, channels):
+def device_image(ctx, mat, channels, pending=None):
     """DeviceMat holding `mat` on `ctx`: the image itself when it already lives there, otherwise an upload of the (validated, packed)
-    host array.  channels: 1 -> (h, w), 3 -> (h, w, 3), 0 -> either; a trailing axis of length 1 is dropped."""
+    host array (with `pending`, a list: only enqueued - see DeviceMat.from_host).  channels: 1 -> (h, w), 3 -> (h, w, 3), 0 -> either; a trailing axis of length 1 is dropped."""
     from vision.devmat import DeviceMat
     if isinstance(mat, DeviceMat):
         if mat.dtype != np.uint8:
@@ -35,7 +35,7 @@ def device_image(ctx, mat, channels):
         raise ValueError("expected an (h, w, 3) image" if channels == 3 else "expected an (h, w) image")
     if mat.shape[0] == 0 or mat.shape[1] == 0:
         raise ValueError("empty image")
-    return DeviceMat.from_host(ctx, mat)
+    return DeviceMat.from_host(ctx, mat, pending=pending)
 
 
 def to_odd(n: int) -> int:

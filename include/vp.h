@@ -325,6 +325,11 @@ int vp_dev_free(vp_ctx* ctx, void* dev_ptr);
 int vp_host_alloc(vp_ctx* ctx, size_t bytes, void** host_ptr);
 int vp_host_free(vp_ctx* ctx, void* host_ptr);   /* ctx may be NULL */
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
+/* The same copy enqueued on the context's stream: src_host must stay unchanged until vp_wait_uploads (or vp_synchronize) returns.
+ * vp_wait_uploads waits for the copies only, not for kernels enqueued behind them: an operator enqueues the copy of its input,
+ * does its host-side work and launches, and waits just before handing control back to code that may change the input. */
+int vp_memcpy_h2d_async(vp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int vp_wait_uploads(vp_ctx* ctx);
 int vp_memcpy_d2h(vp_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
 
 #ifdef __cplusplus

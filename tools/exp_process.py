@@ -136,3 +136,29 @@ for rep in range(20):
     best = timed("max(contours, key=contour_area)", lambda: max(cs, key=contour_area))
     timed("contour_centroid + contour_area", lambda: (contour_centroid(best), contour_area(best)))
 print("per step, synchronised, ms:", {k: round(1e3 * v / 20, 3) for k, v in steps.items()})
+
+# the same statements without the extra synchronisations: host time per statement as it is inside a real call (the kernels of one
+# statement run while Python is in the next; outer_contours waits for everything enqueued before it)
+host = {}
+
+
+def stamped(name, fn):
+    t = time.perf_counter()
+    r = fn()
+    host[name] = host.get(name, 0.0) + time.perf_counter() - t
+    return r
+
+
+for rep in range(40):
+    img = copy_frame(base[rep % 4])
+    lab, (l_, a_, b_) = stamped("bgr_to_lab (incl. upload)", lambda: bgr_to_lab(img))
+    th = stamped("range_threshold", lambda: range_threshold(a_, 150, 255))
+    k = stamped("rect_kernel", lambda: rect_kernel(5))
+    c1 = stamped("morph_remove_noise", lambda: morph_remove_noise(th, k))
+    c2 = stamped("morph_close_holes", lambda: morph_close_holes(c1, k))
+    cs = stamped("outer_contours", lambda: outer_contours(th))
+    stamped("draw_contours", lambda: draw_contours(img, cs, thickness=10))
+    best = stamped("max(contours, key=contour_area)", lambda: max(cs, key=contour_area))
+    stamped("contour_centroid + contour_area", lambda: (contour_centroid(best), contour_area(best)))
+    stamped("3 x shm set", lambda: (shm.red_buoy_results.center_x.set(0.1), shm.red_buoy_results.center_x.set(0.2), shm.red_buoy_results.area.set(3.0)))
+print("per statement, host time inside a call, ms:", {k: round(1e3 * v / 40, 3) for k, v in host.items()}, "sum", round(1e3 * sum(host.values()) / 40, 3))
