@@ -108,6 +108,18 @@ def test_thresh_color_distance(vp, oracle, h, w):
         assert np.array_equal(mask, oracle.inrange(d2, 0.0, float(np.float32(70.0 ** 2))))
 
 
+def test_thresh_color_distance_equals_numpy1_vectors(vp, oracle):
+    """The HIP path against what numpy 1.26.4 itself computes for the reference's statements (tests/golden/numpy1_color_distance.npz):
+    distance image -> mask through inRange, uint8 square root, the percentile-derived threshold."""
+    from test_oracle import _numpy1_cases
+    from vision.utils import color
+    for c in _numpy1_cases():
+        mask, dist = color.thresh_color_distance(c["split"], c["color"], c["distance_arg"], auto_distance_percentile=c["percentile"],
+                                                 ignore_channels=c["ignore"], weights=c["weights"])
+        assert np.array_equal(dist, c["sq"])
+        assert np.array_equal(mask, oracle.inrange(c["dists"], 0.0, float(np.float32(c["distance"]))))
+
+
 def test_structuring_elements(vp, oracle):
     from vision.utils import transform
     for k in (1, 3, 5, 7, 9, 11, 21, 51, 101):

@@ -440,3 +440,30 @@ def test_fold_bound_holds(oracle):
         exact = float(np.float64(int(x.sum())) / np.float64(n))
         bound = (510.0 + 127.5 * (n + 1.0)) * 2.0 ** -53 * 1.001
         assert abs(avg - exact) <= bound, (n, abs(avg - exact), bound)
+
+
+def _numpy1_cases():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "numpy1_color_distance.npz"))
+    k = 0
+    while f"c{k}_split" in z:
+        a = z[f"c{k}_args"]
+        yield {"split": [np.ascontiguousarray(p) for p in z[f"c{k}_split"]], "color": tuple(a[:3]), "weights": tuple(a[3:6]),
+               "percentile": None if a[6] < 0 else float(a[6]), "distance_arg": float(a[7]), "ignore": [int(i) for i in z[f"c{k}_ignore"]],
+               "weights_cp": z[f"c{k}_weights_cp"], "dists": z[f"c{k}_dists"], "distance": float(z[f"c{k}_distance"][0]), "sq": z[f"c{k}_sq"]}
+        k += 1
+    assert k >= 6 and str(z["numpy_version"][0]).startswith("1.")
+
+
+def test_color_distance_equals_numpy1_vectors(oracle):
+    """The numpy statements of thresh_color_distance (reference utils/color.py:91-103) as numpy 1.26.4 evaluates them
+    (tests/golden/make_numpy1_vectors.py, run under the image's conda interpreter): the oracle's float32 restatement reproduces the
+    distance image and its uint8 square root bit for bit, i.e. the promotion rules were read correctly."""
+    for c in _numpy1_cases():
+        wn = np.array([0 if i in c["ignore"] else c["weights"][i] for i in range(3)], np.float64) / np.linalg.norm(c["weights"])
+        assert np.array_equal(wn, c["weights_cp"])
+        skip = sum(1 << i for i in c["ignore"])
+        d2, sq = oracle.color_distance(c["split"], c["color"], wn.astype(np.float32), skip)
+        assert np.array_equal(d2.view(np.uint32), c["dists"].view(np.uint32))
+        assert np.array_equal(sq, c["sq"])
+        if c["percentile"] is not None:                # numpy 2 on the very same float32 image gives the same threshold
+            assert min(np.percentile(c["dists"], c["percentile"]), c["distance_arg"] ** 2) == c["distance"]
