@@ -811,6 +811,41 @@ int vp_polygon_sums_i32(const int32_t* pts, int npts, int64_t* out3)
     return VP_OK;
 }
 
+// Convex hull of integer points (host code; cv2.minAreaRect of the stand-in, modules/bins.py:62): Andrew's monotone chain over the
+// sorted distinct points, collinear points dropped, counter-clockwise from the lexicographically smallest point - exact in 64-bit
+// integers.  out must hold npts points; returns the number of hull vertices in *nout.
+int vp_convex_hull_i32(const int32_t* pts, int npts, int32_t* out, int* nout)
+{
+    if (!pts || !out || !nout || npts < 0) return VP_ERR_INVALID;
+    std::vector<std::pair<int32_t, int32_t>> p((size_t)npts);
+    for (int i = 0; i < npts; i++) p[(size_t)i] = {pts[2 * i], pts[2 * i + 1]};
+    std::sort(p.begin(), p.end());
+    p.erase(std::unique(p.begin(), p.end()), p.end());
+    const int n = (int)p.size();
+    if (n <= 2) {
+        for (int i = 0; i < n; i++) { out[2 * i] = p[(size_t)i].first; out[2 * i + 1] = p[(size_t)i].second; }
+        *nout = n;
+        return VP_OK;
+    }
+    auto cross = [](const std::pair<int32_t, int32_t>& o, const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
+        return ((long long)a.first - o.first) * ((long long)b.second - o.second) - ((long long)a.second - o.second) * ((long long)b.first - o.first);
+    };
+    std::vector<std::pair<int32_t, int32_t>> lower, upper;
+    for (int i = 0; i < n; i++) {
+        while (lower.size() >= 2 && cross(lower[lower.size() - 2], lower.back(), p[(size_t)i]) <= 0) lower.pop_back();
+        lower.push_back(p[(size_t)i]);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        while (upper.size() >= 2 && cross(upper[upper.size() - 2], upper.back(), p[(size_t)i]) <= 0) upper.pop_back();
+        upper.push_back(p[(size_t)i]);
+    }
+    int k = 0;
+    for (size_t i = 0; i + 1 < lower.size(); i++, k++) { out[2 * k] = lower[i].first; out[2 * k + 1] = lower[i].second; }
+    for (size_t i = 0; i + 1 < upper.size(); i++, k++) { out[2 * k] = upper[i].first; out[2 * k + 1] = upper[i].second; }
+    *nout = k;
+    return VP_OK;
+}
+
 // counts[k] points per polyline, back to back in pts; one call draws them all (a frame's contours).
 // All stamps carry one colour, so the image is "colour wherever some stamp covers": the stamps are collected in a coverage bit plane
 // (one bit per pixel, 259 KB at 1080p, per thread, left zeroed) and the image is written once, row by row, run by run.
@@ -982,6 +1017,14 @@ int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, int 
     vp_range3 q;
     norm_range(cn, lo, hi, &q);
     return vpk_inrange_u8(ctx, d_src, src_stride, w, h, cn, q, d_dst);
+}
+
+// cv2.addWeighted on two device images of n bytes each (modules/bins.py:20: the mask overlay); d_dst may be one of the sources
+int vp_add_weighted_u8_dev(vp_ctx* ctx, const uint8_t* d_a, double alpha, const uint8_t* d_b, double beta, double gamma, size_t n, uint8_t* d_dst)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!d_a || !d_b || !d_dst || n == 0 || n > ((size_t)1 << 40)) return vp_fail(ctx, VP_ERR_INVALID, "vp_add_weighted_u8_dev arguments");
+    return vpk_add_weighted_u8(ctx, d_a, d_b, n, alpha, beta, gamma, d_dst);
 }
 
 int vp_morph_u8_dev(vp_ctx* ctx, int op, const uint8_t* d_src, int w, int h, int cn, const uint8_t* kernel, int kw, int kh, int ax, int ay,

@@ -513,6 +513,36 @@ __global__ __launch_bounds__(256) void k_sub_sat_u8(const uint8_t* __restrict__ 
     dst[i] = (uint8_t)(d < 0 ? 0 : d);
 }
 
+// dst = saturate(round-half-even(a * alpha + b * beta + gamma)), every operation a correctly rounded double (no contraction): the
+// statement the cv2 stand-in makes in numpy float64 (vision/cv2_facade.py addWeighted)
+__global__ __launch_bounds__(256) void k_add_weighted_u8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n, double alpha,
+                                                         double beta, double gamma, uint8_t* __restrict__ dst)
+{
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    auto one = [&](int x, int y) -> unsigned {
+        const double v = __dadd_rn(__dadd_rn(__dmul_rn((double)x, alpha), __dmul_rn((double)y, beta)), gamma);
+        const double r = rint(v);
+        return (unsigned)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+    };
+    if (i0 + 4 <= n && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst) & 3u) == 0) {
+        const unsigned va = *reinterpret_cast<const unsigned*>(a + i0), vb = *reinterpret_cast<const unsigned*>(b + i0);
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) out |= one((int)((va >> (8 * k)) & 255u), (int)((vb >> (8 * k)) & 255u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(dst + i0) = out;
+    } else {
+        for (size_t i = i0; i < n && i < i0 + 4; i++) dst[i] = (uint8_t)one(a[i], b[i]);
+    }
+}
+
+int vpk_add_weighted_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double alpha, double beta, double gamma, uint8_t* dst)
+{
+    hipLaunchKernelGGL(k_add_weighted_u8, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, ctx->stream, a, b, n, alpha, beta, gamma, dst);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
 int vpk_absdiff_sub_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* dst)
 {
     hipLaunchKernelGGL(k_sub_sat_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, b, n, dst);

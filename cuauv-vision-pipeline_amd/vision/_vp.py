@@ -102,6 +102,7 @@ _SIGS = {
     "vp_find_contours_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_draw_polyline_u8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "vp_convex_hull_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "vp_polygon_sums_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vp_draw_polylines_u8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "vp_cvt_color_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -121,6 +122,7 @@ _SIGS = {
     "vp_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vp_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vp_add_weighted_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_size_t, C.c_void_p]),
     "vp_memcpy_h2d_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vp_wait_uploads": (C.c_int, [C.c_void_p]),
     "vp_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -24,6 +24,7 @@ MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3,
 RETR_EXTERNAL, RETR_LIST = 0, 1
 CHAIN_APPROX_NONE, CHAIN_APPROX_SIMPLE = 1, 2
 CC_STAT_LEFT, CC_STAT_TOP, CC_STAT_WIDTH, CC_STAT_HEIGHT, CC_STAT_AREA = 0, 1, 2, 3, 4
+CV_8U = 0
 CV_32S = 4
 
 
@@ -155,7 +156,7 @@ def arcLength(curve, closed):
     return total
 
 
-def _convex_hull(pts):
+def _convex_hull_py(pts):
     pts = sorted(set(map(tuple, pts.tolist())))
     if len(pts) <= 2:
         return np.array(pts, np.float64)
@@ -174,11 +175,57 @@ def _convex_hull(pts):
     return np.array(lower[:-1] + upper[:-1], np.float64)
 
 
+def _convex_hull(points):
+    """Monotone-chain hull as float64 (k, 2): integer points (contours) through libvp's exact host routine, anything else in Python."""
+    p = np.asarray(points).reshape(-1, 2)
+    if np.issubdtype(p.dtype, np.integer) and len(p) and np.abs(p).max(initial=0) < 2**31:
+        p32 = np.ascontiguousarray(p, np.int32)
+        out = np.empty_like(p32)
+        n = _vp.C.c_int(0)
+        _vp.check(_vp.lib().vp_convex_hull_i32(p32.ctypes.data, len(p32), out.ctypes.data, _vp.C.byref(n)))
+        return out[:n.value].astype(np.float64)
+    return _convex_hull_py(p.astype(np.float64))
+
+
 def minAreaRect(points):
     """Minimum-area enclosing rectangle by rotating calipers over the convex hull: ((cx, cy), (w, h), angle in degrees).
     Angle convention of OpenCV >= 4.5.1: in (0, 90], width measured along the edge that defines the angle."""
+    hull = _convex_hull(points)
+    if len(hull) == 0:
+        return (0.0, 0.0), (0.0, 0.0), 0.0
+    if len(hull) == 1:
+        return (float(hull[0, 0]), float(hull[0, 1])), (0.0, 0.0), 90.0
+    n = len(hull)
+    # every edge at once (columns): the same products and sums as edge by edge, the first edge of minimal area wins
+    e = (np.roll(hull, -1, axis=0) - hull)[: (n if n > 2 else 1)]
+    ln = np.array([math.hypot(x, y) for x, y in e.tolist()])
+    keep = ln != 0
+    if not keep.any():
+        return (float(hull[0, 0]), float(hull[0, 1])), (0.0, 0.0), 90.0
+    e, ln = e[keep], ln[keep]
+    ux, uy = e[:, 0] / ln, e[:, 1] / ln
+    hx, hy = hull[:, 0][:, None], hull[:, 1][:, None]
+    a = hx * ux + hy * uy
+    b = -hx * uy + hy * ux
+    amax, amin, bmax, bmin = a.max(0), a.min(0), b.max(0), b.min(0)
+    wds, hts = amax - amin, bmax - bmin
+    k = int(np.argmin(wds * hts))
+    ca, cb = (amax[k] + amin[k]) / 2, (bmax[k] + bmin[k]) / 2
+    uxk, uyk = float(ux[k]), float(uy[k])
+    cx, cy, wd, ht, ang = ca * uxk - cb * uyk, ca * uyk + cb * uxk, float(wds[k]), float(hts[k]), math.degrees(math.atan2(uyk, uxk))
+    while ang <= 0:
+        ang += 90
+        wd, ht = ht, wd
+    while ang > 90:
+        ang -= 90
+        wd, ht = ht, wd
+    return (float(np.float32(cx)), float(np.float32(cy))), (float(np.float32(wd)), float(np.float32(ht))), float(np.float32(ang))
+
+
+def _min_area_rect_loop(points):
+    """The same statements edge by edge (the form the vectorised one is tested against)."""
     pts = np.asarray(points).reshape(-1, 2).astype(np.float64)
-    hull = _convex_hull(pts)
+    hull = _convex_hull_py(pts)
     if len(hull) == 0:
         return (0.0, 0.0), (0.0, 0.0), 0.0
     if len(hull) == 1:
@@ -258,10 +305,37 @@ def approxPolyDP(curve, epsilon, closed):
     return out.reshape(-1, 1, 2).copy()
 
 
-def addWeighted(src1, alpha, src2, beta, gamma):
-    """saturate_cast<uchar>(src1*alpha + src2*beta + gamma) with round-half-even (modules/bins.py:20)."""
-    acc = np.asarray(src1, np.float64) * alpha + np.asarray(src2, np.float64) * beta + gamma
-    return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+def addWeighted(src1, alpha, src2, beta, gamma, dst=None, dtype=-1):
+    """saturate_cast<uchar>(src1*alpha + src2*beta + gamma) with round-half-even (modules/bins.py:20), every step a double.  Two uint8
+    images of one shape stay on the device (libvp vp_add_weighted_u8_dev: the same doubles) and the result is computed when something
+    reads it - bins.py draws into the overlay only when it has found rectangles, and posts it only when posts are on."""
+    from vision.devmat import DeviceMat, defer_enabled, finish_uploads, lazy_enabled
+    from vision.utils.helpers import as_mat, device_image
+    a, b = as_mat(src1), as_mat(src2)
+    on_dev = (lazy_enabled() or isinstance(a, DeviceMat) or isinstance(b, DeviceMat)) and dtype in (-1, CV_8U) and \
+        all(isinstance(m, (np.ndarray, DeviceMat)) and m.dtype == np.uint8 and m.ndim in (2, 3) and m.size for m in (a, b)) and \
+        tuple(a.shape) == tuple(b.shape)
+    if not on_dev:
+        acc = np.asarray(a, np.float64) * alpha + np.asarray(b, np.float64) * beta + gamma
+        return _into(dst, np.clip(np.rint(acc), 0, 255).astype(np.uint8))
+    ctx = _vp.default_context()
+    up = []
+    try:
+        da = device_image(ctx, a, 0, pending=up)
+        db = device_image(ctx, b, 0, pending=up)
+        fa, fb, fg = float(alpha), float(beta), float(gamma)
+        n = int(np.prod(da.shape))
+
+        def run(out, da=da, db=db):
+            _vp.check(_vp.lib().vp_add_weighted_u8_dev(ctx.handle, da.dev_ptr, fa, db.dev_ptr, fb, fg, n, out.dev_ptr), ctx.handle)
+        if defer_enabled():
+            out = DeviceMat.deferred(ctx, da.shape, np.uint8, False, (da, db), run)
+        else:
+            out = DeviceMat(ctx, da.shape)
+            run(out)
+    finally:
+        finish_uploads(ctx, up)
+    return _into(dst, out)
 
 
 def add(src1, src2):

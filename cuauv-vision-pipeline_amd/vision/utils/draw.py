@@ -107,11 +107,17 @@ def _native_polylines(mat, polys, closed, color, thickness):
         lib = _vp.lib()
     except Exception:
         return False
-    polys = [np.asarray(p).reshape(-1, 2) for p in polys]
-    if not polys:
-        return True
-    counts = np.fromiter((len(p) for p in polys), np.int32, len(polys))
-    p32 = np.ascontiguousarray(np.concatenate(polys) if len(polys) > 1 else polys[0], np.int32)
+    flat = getattr(polys, "_flat", None)
+    if flat is not None:                            # the tuple find_contours returned: its arrays are views of this one block
+        if len(polys) == 0:
+            return True
+        counts, p32 = polys._counts, flat
+    else:
+        polys = [np.asarray(p).reshape(-1, 2) for p in polys]
+        if not polys:
+            return True
+        counts = np.fromiter((len(p) for p in polys), np.int32, len(polys))
+        p32 = np.ascontiguousarray(np.concatenate(polys) if len(polys) > 1 else polys[0], np.int32)
     col = np.zeros(4, np.uint8)
     col[:cn] = np.asarray(color, np.uint8).ravel()[:cn] if np.ndim(color) else np.uint8(color)
     return lib.vp_draw_polylines_u8(mat.ctypes.data, mat.strides[0], mat.shape[1], mat.shape[0], cn, p32.ctypes.data, counts.ctypes.data,

@@ -107,6 +107,8 @@ def contour_centroid(contour: np.ndarray) -> Tuple[int, int]:
 
 def contour_area(contour: np.ndarray) -> float:
     """utils/feature.py:255-265 (cv2.contourArea, oriented=False): |shoelace| / 2."""
+    if type(contour) is np.ndarray and contour.dtype == np.int32 and contour.size and contour.flags.c_contiguous:   # what find_contours hands out
+        return abs(float(_green_sums(contour.reshape(-1, 2))[0]) * 0.5)
     pts = np.asarray(contour).reshape(-1, 2)
     n = len(pts)
     if n == 0:
@@ -209,12 +211,23 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
             break
         max_c = max(max_c, 2 * nc.value)
         max_p = max(max_p, 2 * npts.value)
+    k = nc.value
+    flat = pts[:npts.value].copy()                     # one block for all contours; the arrays handed out are views of it
+    cnt = counts[:k].tolist()
+    pts3 = flat.reshape(-1, 1, 2)
     out, o = [], 0
-    pts3 = pts.reshape(-1, 1, 2)
-    for c in counts[:nc.value].tolist():
-        out.append(pts3[o:o + c].copy())
+    for c in cnt:
+        out.append(pts3[o:o + c])
         o += c
-    return (tuple(out), holes[:nc.value].copy()) if with_holes else tuple(out)
+    out = ContourList(out)
+    out._flat, out._counts = flat, counts[:k].copy()
+    return (out, holes[:k].copy()) if with_holes else out
+
+
+class ContourList(tuple):
+    """The tuple of (N, 1, 2) int32 arrays cv2.findContours returns.  The arrays are views of one point block (`_flat`, in the
+    tuple's order), which `draw_contours` hands to the rasteriser as it is; writing to a contour writes to the block, so the two
+    cannot disagree."""
 
 
 def outer_contours(mat: np.ndarray) -> List[np.ndarray]:

@@ -1,9 +1,10 @@
 """Mirror of the reference utils/helpers.py:58-68 (`as_mat`): no UMat exists here, arrays pass through."""
 import numpy as np
 
+from vision.devmat import DeviceMat
+
 
 def as_mat(mat):
-    from vision.devmat import DeviceMat
     if isinstance(mat, (np.ndarray, DeviceMat)):
         return mat
     get = getattr(mat, "get", None)
@@ -13,7 +14,6 @@ def as_mat(mat):
 def device_image(ctx, mat, channels, pending=None):
     """DeviceMat holding `mat` on `ctx`: the image itself when it already lives there, otherwise an upload of the (validated, packed)
     host array (with `pending`, a list: only enqueued - see DeviceMat.from_host).  channels: 1 -> (h, w), 3 -> (h, w, 3), 0 -> either; a trailing axis of length 1 is dropped."""
-    from vision.devmat import DeviceMat
     if isinstance(mat, DeviceMat):
         if mat.dtype != np.uint8:
             raise TypeError("expected a uint8 image")

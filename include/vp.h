@@ -164,6 +164,10 @@ int vp_find_contours_u8(vp_ctx* ctx, const uint8_t* src_host, size_t src_stride,
  * out3 = {sum d, sum d (x' + x), sum d (y' + y)}, d = x' y - x y' over consecutive points (x', y') -> (x, y), as exact integers;
  * host code, no context.  The Python mirror applies cv2's factors 1/2 and 1/6 in float64. */
 int vp_polygon_sums_i32(const int32_t* pts_xy, int npts, int64_t* out3);
+/* Convex hull of integer points by the monotone chain (host code, exact): distinct hull vertices counter-clockwise from the
+ * lexicographically smallest point, collinear points dropped; `out` holds up to npts points.  Used by the cv2.minAreaRect stand-in
+ * (modules/bins.py:62). */
+int vp_convex_hull_i32(const int32_t* pts, int npts, int32_t* out, int* nout);
 
 /* utils/draw.py:283-327 `draw_contours` / `draw_polylines` (modules/red_buoy.py:39): in-place polyline on a HOST image (no device
  * work, no context): Bresenham steps with a square brush of `thickness` pixels - the Python mirror's rasteriser in C.  pts = npts
@@ -188,6 +192,10 @@ int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, in
                       uint8_t* dst_dev);
 int vp_morph_u8_dev(vp_ctx* ctx, int op, const uint8_t* src_dev, int w, int h, int cn, const uint8_t* kernel, int kw, int kh,
                     int anchor_x, int anchor_y, int iterations, int binary_hint, uint8_t* dst_dev);
+/* cv2.addWeighted(a, alpha, b, beta, gamma) on two device images of n bytes (modules/bins.py:20, the mask overlay):
+ * saturate(round-half-even(a*alpha + b*beta + gamma)) in correctly rounded doubles; dst may be one of the sources. */
+int vp_add_weighted_u8_dev(vp_ctx* ctx, const uint8_t* a_dev, double alpha, const uint8_t* b_dev, double beta, double gamma, size_t n,
+                           uint8_t* dst_dev);
 int vp_find_contours_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, int w, int h, int mode, int method,
                          int32_t* points_host, int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours,
                          int32_t* n_contours, int64_t* n_points);

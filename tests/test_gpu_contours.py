@@ -247,3 +247,22 @@ def test_chain_runner_contours_pinned(vp, oracle):
         th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(r.input[f])[:, :, 1]), 150, 255)
         cl = oracle.morph(oracle.OPEN, th, k, fast=True)
         assert _same(out["contours"][f][0], oracle.find_contours(cl, 0, 1))
+
+
+def test_contour_tuple_shares_one_point_block(vp, oracle):
+    """The contours of one call are views of one block that the overlay rasteriser reads directly: they are ordinary writable arrays,
+    and a change made through one of them is what gets drawn."""
+    from vision.utils import feature
+    from vision.utils.draw import draw_contours
+    m = np.zeros((120, 200), np.uint8)
+    m[20:50, 30:80] = 255
+    m[70:100, 120:180] = 255
+    cs = feature.outer_contours(m)
+    assert isinstance(cs, tuple) and len(cs) == 2 and all(type(c) is np.ndarray and c.flags.writeable and c.flags.c_contiguous for c in cs)
+    assert _same(cs, oracle.find_contours(m, 0, 2))
+    cs[0][:, 0, 0] -= 100                                          # move the newest contour (the lower right box) to the left
+    a, b = np.zeros((120, 200, 3), np.uint8), np.zeros((120, 200, 3), np.uint8)
+    draw_contours(a, cs, thickness=3)
+    draw_contours(b, [c.copy() for c in cs], thickness=3)          # a plain list of copies takes the general path
+    assert np.array_equal(a, b) and a[70:100, 20:80].any() and not a[70:100, 120:181].any()
+    assert feature.contour_area(cs[0]) == 59.0 * 29.0

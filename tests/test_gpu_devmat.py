@@ -211,3 +211,42 @@ def test_operators_between_device_images_run_when_needed(vp, oracle):
         assert y._pending is None and np.array_equal(y, oracle.morph(oracle.ERODE, oth, k3))
     finally:
         devmat.set_defer(True)
+
+
+def test_add_weighted_on_the_device(vp):
+    """cv2.addWeighted stand-in (modules/bins.py:20): the device kernel makes the statement of the numpy float64 expression, on host
+    arrays, device images and mixtures; ties round to even; the result saturates."""
+    from vision import cv2_facade as cv2
+    from vision import devmat
+    from vision.utils.color import gray_to_bgr, range_threshold
+    rng = np.random.default_rng(9)
+
+    def ref(a, al, b, be, g):
+        return np.clip(np.rint(np.asarray(a, np.float64) * al + np.asarray(b, np.float64) * be + g), 0, 255).astype(np.uint8)
+    a = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    b = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    for al, be, g in ((0.7, 0.3, 0), (0.5, 0.5, 0), (1.5, 1.0, -20.25), (-1.0, 0.25, 300), (0.1, 0.2, 0.5)):
+        out = cv2.addWeighted(a, al, b, be, g)
+        assert isinstance(out, devmat.DeviceMat) and out._pending is not None
+        assert np.array_equal(out, ref(a, al, b, be, g)), (al, be, g)
+    # every pair of byte values once: 0.5 / 0.5 makes exact ties (half to even), 0.7 / 0.3 near-ties
+    x, y = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    for al, be in ((0.5, 0.5), (0.7, 0.3), (0.3, 0.7)):
+        assert np.array_equal(cv2.addWeighted(x, al, y, be, 0), ref(x, al, y, be, 0))
+    # bins.py: frame (host) + mask overlay (device); odd sizes; dst given
+    img = F.s2_bins(0, 333, 201)
+    mask = range_threshold(np.ascontiguousarray(img[:, :, 1]), 60, 200)
+    vis = cv2.cvtColor(mask, cv2.COLOR_GRAY2BGR)
+    over = cv2.addWeighted(img, 0.7, vis, 0.3, 0)
+    assert np.array_equal(over, ref(img, 0.7, np.dstack([np.asarray(mask)] * 3), 0.3, 0))
+    dst = np.zeros_like(img)
+    assert cv2.addWeighted(img, 0.25, img, 0.25, 1, dst) is dst and np.array_equal(dst, ref(img, 0.25, img, 0.25, 1))
+    # shapes that differ, other types: the numpy statement as before
+    f = cv2.addWeighted(a.astype(np.float32), 0.5, b.astype(np.float32), 0.5, 0)
+    assert isinstance(f, np.ndarray) and np.array_equal(f, ref(a, 0.5, b, 0.5, 0))
+    devmat.set_lazy(False)
+    try:
+        h = cv2.addWeighted(a, 0.7, b, 0.3, 0)
+        assert type(h) is np.ndarray and np.array_equal(h, ref(a, 0.7, b, 0.3, 0))
+    finally:
+        devmat.set_lazy(True)

@@ -162,3 +162,85 @@ for rep in range(40):
     stamped("contour_centroid + contour_area", lambda: (contour_centroid(best), contour_area(best)))
     stamped("3 x shm set", lambda: (shm.red_buoy_results.center_x.set(0.1), shm.red_buoy_results.center_x.set(0.2), shm.red_buoy_results.area.set(3.0)))
 print("per statement, host time inside a call, ms:", {k: round(1e3 * v / 40, 3) for k, v in host.items()}, "sum", round(1e3 * sum(host.values()) / 40, 3))
+
+
+# ---- the other in-scope module body: modules/bins.py:11-81 as it stands (np.int0 spelled np.intp: removed in numpy 2), through the
+# cv2 stand-in and the vision.utils mirror; S2 frames (beige 2:1 rectangles) ------------------------------------------------------
+from vision import cv2_facade as cv2
+from vision.utils.feature import outer_contours as _outer
+from vision.utils.transform import morph_remove_noise as _mrn
+
+
+class Bins:
+    def __init__(self, posts):
+        self.posts, self.posted = posts, {}
+
+    def post(self, name, image, color_space="BGR"):
+        if self.posts:
+            self.posted[name] = np.array(as_mat(image), np.uint8, copy=True, order="C", ndmin=1)
+
+    def process(self, direction, img):
+        hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV)
+        lower_beige = np.array([10, 20, 60])
+        upper_beige = np.array([30, 100, 255])
+        mask = cv2.inRange(hsv, lower_beige, upper_beige)
+        mask_vis = cv2.cvtColor(mask, cv2.COLOR_GRAY2BGR)
+        overlayed = cv2.addWeighted(img, 0.7, mask_vis, 0.3, 0)
+        kernel = rect_kernel(5)
+        cleaned = _mrn(mask, kernel)
+        contours = _outer(cleaned)
+        valid_rects = []
+        for contour in contours:
+            rect = cv2.minAreaRect(contour)
+            (center, (w, h), angle) = rect
+            if w * h < 500:
+                continue
+            aspect_ratio = max(w, h) / min(w, h)
+            if 1.0 <= aspect_ratio <= 3.0:
+                valid_rects.append(rect)
+        for rect in valid_rects:
+            box_points = cv2.boxPoints(rect)
+            box_points = np.intp(box_points)
+            cv2.drawContours(overlayed, [box_points], 0, (0, 255, 0), 4)
+            ((cx, cy), (w, h), theta) = rect
+        self.post("bins", overlayed)
+        return len(contours), len(valid_rects)
+
+
+base2 = [F.s2_bins(i, W, H) for i in range(4)]
+NB = max(20, N // 4)
+for posts in (False, True):
+    me = Bins(posts)
+    for i in range(3):
+        me.process("forward", copy_frame(base2[i]))
+    t_body = 0.0
+    for i in range(NB):
+        img = copy_frame(base2[i % 4])
+        t1 = time.perf_counter()
+        res = me.process("forward", img)
+        t_body += time.perf_counter() - t1
+    print(f"bins body, {W}x{H}, posts {'on ' if posts else 'off'}: {NB / t_body:8.1f} calls/s  ({1e3 * t_body / NB:.3f} ms per call; {res[0]} contours, {res[1]} rectangles kept)", flush=True)
+
+# host time per statement of the bins body (no extra synchronisation)
+hb = {}
+
+
+def st(name, fn):
+    t = time.perf_counter()
+    r = fn()
+    hb[name] = hb.get(name, 0.0) + time.perf_counter() - t
+    return r
+
+
+for rep in range(40):
+    img = copy_frame(base2[rep % 4])
+    hsv = st("cvtColor BGR2HSV (incl. upload)", lambda: cv2.cvtColor(img, cv2.COLOR_BGR2HSV))
+    mask = st("inRange", lambda: cv2.inRange(hsv, np.array([10, 20, 60]), np.array([30, 100, 255])))
+    vis = st("cvtColor GRAY2BGR", lambda: cv2.cvtColor(mask, cv2.COLOR_GRAY2BGR))
+    over = st("addWeighted", lambda: cv2.addWeighted(img, 0.7, vis, 0.3, 0))
+    cl = st("morph_remove_noise", lambda: _mrn(mask, rect_kernel(5)))
+    cs = st("outer_contours", lambda: _outer(cl))
+    rects = st("minAreaRect x contours", lambda: [cv2.minAreaRect(c) for c in cs])
+    boxes = st("boxPoints + np.intp", lambda: [np.intp(cv2.boxPoints(r)) for r in rects])
+    st("drawContours x rectangles (first one downloads the overlay)", lambda: [cv2.drawContours(over, [b], 0, (0, 255, 0), 4) for b in boxes])
+print("bins body, per statement, host time inside a call, ms:", {k: round(1e3 * v / 40, 3) for k, v in hb.items()}, "sum", round(1e3 * sum(hb.values()) / 40, 3))
