@@ -24,10 +24,12 @@ def _argv(monkeypatch):
 
 def _wait(cond, timeout=5.0):
     t0 = time.time()
+    n = 0
     while time.time() - t0 < timeout:
         if cond():
             return True
-        time.sleep(0.01)
+        n += 1
+        time.sleep(0.003 + 0.001 * (n % 7))      # uneven on purpose: a fixed 10 ms poll reads a 200 fps, 4-frame loop at every other frame for ever
     return False
 
 
