@@ -25,6 +25,7 @@ import numpy as np
 from vision.core.bindings.camera_message_framework import BLOCK_STUB, BlockAccessor, ReadStatus
 from vision.core.tuners import BoolTuner, DoubleTuner, IntTuner, TunerBase
 from vision.core.frames import copy_frame
+from vision.devmat import DeviceMat
 from vision.utils.helpers import as_mat
 
 try:  # the CUAUV logging daemon client, when the monorepo is around
@@ -519,7 +520,11 @@ class ModuleBase:
             return
         if "%" in name:
             raise RuntimeError("Cannot have % in name")
-        image = np.array(as_mat(image), np.uint8, copy=True, order="C", ndmin=1)
+        image = as_mat(image)
+        if isinstance(image, DeviceMat) and image.dtype == np.uint8:
+            image = image.host_copy()                # one download into an array of its own; the image stays usable on the device
+        else:
+            image = np.array(image, np.uint8, copy=True, order="C", ndmin=1)
         color_space = color_space.upper()
         self._post_queue[name] = image
         self._post_color_spaces[name] = color_space if color_space in VALID_COLOR_SPACES else "BGR"

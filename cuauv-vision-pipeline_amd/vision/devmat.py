@@ -236,6 +236,17 @@ class DeviceMat:
         v.flags.writeable = False
         return v
 
+    def host_copy(self):
+        """A fresh host array with the current contents that the caller owns (self.post): straight from the device when the device
+        copy is the valid one - nothing is cached and the device copy stays valid."""
+        if self._pending is not None:
+            self._force()
+        if self._dev_ok and self._host is None and self._ctx.handle:
+            out = np.empty(self._shape, self._dtype)
+            _vp.check(_vp.lib().vp_memcpy_d2h(self._ctx.handle, out.ctypes.data, self._buf.ptr, out.nbytes), self._ctx.handle)
+            return out
+        return self.host(writable=False).copy()
+
     def refresh_device(self, ctx):
         """Device copy of the current contents on `ctx` (re-uploads after host-side writes or a change of context)."""
         if self._pending is not None:

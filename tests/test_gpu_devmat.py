@@ -250,3 +250,22 @@ def test_add_weighted_on_the_device(vp):
         assert type(h) is np.ndarray and np.array_equal(h, ref(a, 0.7, b, 0.3, 0))
     finally:
         devmat.set_lazy(True)
+
+
+def test_post_takes_a_copy_without_giving_up_the_device_image(vp, oracle):
+    """self.post(name, image) of a device image: one download into an array of its own (later writes to the image do not reach the
+    queued post), and the image is still valid on the device for the next operator."""
+    from vision.utils.color import range_threshold
+    from vision.utils.transform import dilate, rect_kernel
+    g = np.ascontiguousarray(F.s1_buoy(1, 200, 120)[:, :, 2])
+    th = range_threshold(g, 150, 255)
+    c = th.host_copy()
+    ref = oracle.inrange(g, 150, 255)
+    assert type(c) is np.ndarray and c.flags.writeable and np.array_equal(c, ref) and th._host is None and th._dev_ok and th.binary
+    d = dilate(th, rect_kernel(3))
+    th[0:5, :] = 255                                   # after the copy: the copy keeps the old contents
+    assert np.array_equal(c, ref) and np.array_equal(d, oracle.morph(oracle.DILATE, ref, np.ones((3, 3), np.uint8)))
+    c2 = th.host_copy()                                # host copy authoritative now
+    assert c2 is not np.asarray(th) and c2[0, 0] == 255
+    e = dilate(th, rect_kernel(3))                     # pending: host_copy computes it
+    assert e._pending is not None and np.array_equal(e.host_copy(), np.asarray(e))

@@ -26,6 +26,7 @@ from vision.utils.feature import contour_area, contour_centroid, outer_contours
 from vision.utils.transform import morph_close_holes, morph_remove_noise, rect_kernel
 from vision.utils.helpers import as_mat
 from vision.core.frames import copy_frame
+from vision.devmat import DeviceMat
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
@@ -43,7 +44,8 @@ class Self:
     def post(self, name, image, color_space="BGR"):
         if not self.posts:                       # --enable-performance
             return
-        self.posted[name] = np.array(as_mat(image), np.uint8, copy=True, order="C", ndmin=1)   # core/base.py:860 of the reference
+        image = as_mat(image)                     # what vision/core/base.py post() does (core/base.py:860 of the reference: a uint8 copy)
+        self.posted[name] = image.host_copy() if isinstance(image, DeviceMat) else np.array(image, np.uint8, copy=True, order="C", ndmin=1)
 
     def normalize(self, c):
         return (c[0] - self.shape[0] / 2) / self.shape[1], (c[1] - self.shape[1] / 2) / self.shape[1]
@@ -177,7 +179,8 @@ class Bins:
 
     def post(self, name, image, color_space="BGR"):
         if self.posts:
-            self.posted[name] = np.array(as_mat(image), np.uint8, copy=True, order="C", ndmin=1)
+            image = as_mat(image)
+            self.posted[name] = image.host_copy() if isinstance(image, DeviceMat) else np.array(image, np.uint8, copy=True, order="C", ndmin=1)
 
     def process(self, direction, img):
         hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV)
