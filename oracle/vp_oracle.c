@@ -12,7 +12,9 @@
  * cv2 is not installed in the build container, so this file restates OpenCV's published
  * 8-bit algorithms and is pinned only by (a) the widely published OpenCV known answers of
  * SURVEY.md Appendix A (tests/golden/known_answers.json), (b) SciPy as an independent
- * witness where semantics coincide and (c) float64 analytic formulas at +-1 LSB.
+ * witness where semantics coincide, (c) float64 analytic formulas at +-1 LSB and (d) for the
+ * one numpy-only stretch of the path (thresh_color_distance, utils/color.py:91-103) vectors made
+ * under a real numpy 1.x (tests/golden/numpy1_color_distance.npz).
  * tests/test_live_cv2.py compares against a real cv2 whenever one is importable.
  *
  * Each function cites the reference call site it stands in for (file:line relative to
