@@ -117,6 +117,7 @@ inline void racy_write(void* dst, const void* src, size_t n) { memcpy(dst, src, 
 struct PrivFrame {   // what create_frame really allocates: the public Frame first, bookkeeping after
     Frame pub;
     size_t capacity;
+    bool foreign;      // pub.data belongs to the caller (cmf_frame_set_buffer): never reallocated, never freed here
 };
 
 }  // namespace
@@ -360,6 +361,7 @@ int read_frame(Block* block, Frame* frame, bool block_thread)
 
     PrivFrame* pf = reinterpret_cast<PrivFrame*>(frame);
     if (pf->capacity < h->max_entry_size_bytes) {
+        if (pf->foreign) { set_err("the buffer given to cmf_frame_set_buffer is smaller than the block's entry size"); return CMF_ERR_INVALID; }
         void* grown = realloc(frame->data, h->max_entry_size_bytes);
         if (!grown) { set_err("out of memory"); return CMF_ERR_INVALID; }
         frame->data = grown;
@@ -406,9 +408,28 @@ Frame* create_frame(void)
 void delete_frame(Frame* frame)
 {
     if (!frame) return;
-    free(frame->data);
+    if (!reinterpret_cast<PrivFrame*>(frame)->foreign) free(frame->data);
     free(reinterpret_cast<PrivFrame*>(frame));
 }
+
+int cmf_frame_set_buffer(Frame* frame, void* buf, uint64_t capacity)
+{
+    if (!frame) { set_err("null frame"); return CMF_ERR_INVALID; }
+    PrivFrame* pf = reinterpret_cast<PrivFrame*>(frame);
+    if (!pf->foreign) free(frame->data);
+    if (buf) {
+        frame->data = buf;
+        pf->capacity = (size_t)capacity;
+        pf->foreign = true;
+    } else {
+        frame->data = malloc(64);
+        pf->capacity = frame->data ? 64 : 0;
+        pf->foreign = false;
+    }
+    return 0;
+}
+
+uint64_t cmf_block_entry_size(Block* block) { return (block && block->shm) ? (uint64_t)block->shm->max_entry_size_bytes : 0; }
 
 uint64_t frame_size(Frame* frame) { return frame ? frame->total_size : 0; }
 

@@ -114,6 +114,7 @@ class VideoMessage:
     data: Optional[Union[np.ndarray, Tuple[np.ndarray, ...]]]
     acquisition_time: int
     plane_names: Tuple[str, ...] = tuple()
+    private: bool = False          # data already is the module's own writable copy (read straight into page-locked memory)
 
 
 class ModuleManager:
@@ -162,11 +163,11 @@ class ModuleManager:
                 self._tuner_sources[name].deserialize(frame.tobytes("C"))
         messages: List[VideoMessage] = []
         for name, accessor in self._video_accessor.items():
-            status, data, acquisition_time = accessor.read_frame()
+            status, data, acquisition_time, private = accessor.read_frame_private()
             if status == ReadStatus.FRAMEWORK_DELETED:
                 raise RuntimeError(f"{accessor.direction} was marked for deletion")
             if data is not None:
-                messages.append(VideoMessage(self._video_sources[name], status, data, acquisition_time, accessor.last_plane_names()))
+                messages.append(VideoMessage(self._video_sources[name], status, data, acquisition_time, accessor.last_plane_names(), private))
         return messages
 
     def __getitem__(self, key: str) -> Any:
@@ -477,8 +478,10 @@ class ModuleBase:
             for message in messages:
                 source, image, acq_time = message.source, message.data, message.acquisition_time
                 if message.status == ReadStatus.SUCCESS and image is not None:
-                    # the arrays view the library's read buffer: hand module code its own writable copies
-                    image = tuple(copy_frame(p) for p in image) if isinstance(image, tuple) else copy_frame(image)
+                    # module code gets writable arrays of its own: either the library already read the frame into page-locked memory
+                    # that is now ours (message.private), or the arrays view its read buffer and are copied here
+                    if not message.private:
+                        image = tuple(copy_frame(p) for p in image) if isinstance(image, tuple) else copy_frame(image)
                     self._update_metadata_for_direction(source.name, image, acq_time)
                     self._current_direction = source.name
                     if isinstance(image, tuple):

@@ -59,10 +59,15 @@ def _load():
     lib.frame_size.restype = C.c_uint64
     lib.frame_size.argtypes = [C.POINTER(_Frame)]
     lib.cmf_last_error.restype = C.c_char_p
+    lib.cmf_frame_set_buffer.restype = C.c_int
+    lib.cmf_frame_set_buffer.argtypes = [C.POINTER(_Frame), C.c_void_p, C.c_uint64]
+    lib.cmf_block_entry_size.restype = C.c_uint64
+    lib.cmf_block_entry_size.argtypes = [C.c_void_p]
     return lib
 
 
 _dllib = _load()
+_PRIVATE_READS = os.environ.get("VP_PRIVATE_READS", "1") != "0"
 
 
 def _const_int(name):
@@ -222,6 +227,56 @@ class BlockAccessor:
         self._last_plane_names = tuple(names)
         return status, self._frame_data, self._acquisition_time
 
+    def read_frame_private(self):
+        """read_frame for a consumer that wants arrays of its own: -> (ReadStatus, ndarray | tuple of ndarrays | None, acquisition
+        time, private).  With private == True the arrays are writable, belong to the caller and stay valid for as long as it keeps
+        them: the library's seqlock copy went straight into a page-locked buffer (cmf_frame_set_buffer) that is now theirs, so the
+        copy the runtime would make next (reference core/base.py:765-768) is not needed.  private == False: no page-locked memory
+        is to be had on this thread (no device context yet, a CPU box) - the arrays are read_frame's views of the library's buffer."""
+        if not self._inside_ctx_manager:
+            raise RuntimeError(f"Attempted to access block while not in a context manager: {_caller_line()}")
+        buf = self._private_buf
+        if buf is None:
+            from vision.core.frames import pinned_like
+            size = int(_dllib.cmf_block_entry_size(self._block_ptr)) if _PRIVATE_READS else 0
+            buf = pinned_like((size,), np.uint8) if size else None
+            if buf is None:
+                if self._private_installed:                     # page-locked memory ran out: back to the library's own buffer
+                    _dllib.cmf_frame_set_buffer(self._frame_ptr, None, 0)
+                    self._private_installed = False
+                return self.read_frame() + (False,)
+            if _dllib.cmf_frame_set_buffer(self._frame_ptr, buf.ctypes.data, buf.nbytes) != 0:
+                raise RuntimeError(f"cmf_frame_set_buffer on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
+            self._private_buf, self._private_installed = buf, True
+        rc = _dllib.read_frame(self._block_ptr, self._frame_ptr, self._block_thread)
+        if rc < 0:
+            raise RuntimeError(f"read_frame on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
+        status = ReadStatus(rc)
+        if status != ReadStatus.SUCCESS:
+            return status, self._frame_data, self._acquisition_time, True      # (the last frame, as read_frame reports it: callers test for None)
+        fr = self._frame_ptr.contents
+        self._acquisition_time = int(fr.acquisition_time)
+        total, count = int(fr.total_size), int(fr.plane_count)
+        if count == 0 or total == 0:
+            self._frame_data, self._last_plane_names = None, tuple()
+            return status, None, self._acquisition_time, True
+        planes, names = [], []
+        for idx in range(count):
+            m = fr.planes[idx]
+            w, h, d, item, off = int(m.width), int(m.height), int(m.depth), int(m.type_size), int(m.offset)
+            dtype = self._type_lookup.get(item)
+            if dtype is None:
+                raise RuntimeError(f"encountered unsupported type size {item} while reading plane {idx}")
+            nbytes = w * h * d * item
+            if off + nbytes > total:
+                raise RuntimeError(f"plane {idx} with size {nbytes} at offset {off} exceeds frame size {total}")
+            planes.append(buf[off:off + nbytes].view(dtype).reshape(h, w, d))
+            names.append(m.name.decode())
+        self._private_buf = None                               # handed over: the next read gets a buffer of its own
+        self._last_plane_names = tuple(names)
+        self._frame_data = planes[0] if count == 1 else tuple(planes)
+        return status, self._frame_data, self._acquisition_time, True
+
     # -- lifetime --------------------------------------------------------------------------------
     def __enter__(self):
         if self._inside_ctx_manager:
@@ -243,6 +298,7 @@ class BlockAccessor:
         self._block_ptr = ptr
         self._frame_ptr = _dllib.create_frame()
         self._acquisition_time, self._frame_data = 0, None
+        self._private_buf, self._private_installed = None, False
         self._inside_ctx_manager = True
         return self
 

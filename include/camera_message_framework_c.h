@@ -80,6 +80,14 @@ uint64_t frame_size(Frame* frame);
 /* not in the reference: text of the last failure on this thread */
 const char* cmf_last_error(void);
 
+/* not in the reference: let read_frame copy straight into memory the caller owns (page-locked memory the module runtime hands to
+ * process() as the frame's private copy - reference core/base.py:765-768 makes that copy with numpy after read_frame).
+ * cmf_frame_set_buffer(frame, buf, capacity): from now on read_frame fills `buf`; it fails (negative status, frame untouched) when
+ * capacity is below the block's entry size.  buf == NULL gives the frame a buffer of its own again.  The frame never frees `buf`.
+ * cmf_block_entry_size(block): the block's max_entry_size_bytes (what `capacity` has to reach). */
+int cmf_frame_set_buffer(Frame* frame, void* buf, uint64_t capacity);
+uint64_t cmf_block_entry_size(Block* block);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,3 +185,38 @@ def test_seqlock_under_thread_sanitizer(tmp_path):
     assert "ThreadSanitizer" not in run.stderr, run.stderr[-4000:]
     assert run.returncode == 0, (run.returncode, run.stdout[-500:], run.stderr[-2000:])
     assert "bad 0" in run.stdout
+
+
+def test_reader_supplied_buffer():
+    """cmf_frame_set_buffer (an addition to the reference's ABI): read_frame copies straight into memory the reader owns, refuses a
+    buffer below the block's entry size without touching it, and goes back to a buffer of its own on request."""
+    d = _name("ownbuf")
+    img = np.arange(6 * 8 * 3, dtype=np.uint8).reshape(6, 8, 3)
+    lib = cmf._dllib
+    entry = img.nbytes + 6 * 8 * 4
+    with BlockAccessor(d, max_entry_size_bytes=entry) as w, BlockAccessor(d) as r:
+        assert lib.cmf_block_entry_size(r._block_ptr) == entry and lib.cmf_block_entry_size(None) == 0
+        mine = np.full(entry + 16, 0xEE, np.uint8)
+        assert lib.cmf_frame_set_buffer(r._frame_ptr, mine.ctypes.data, mine.nbytes) == 0
+        w.write_frame(5, img)
+        st, data, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 5 and np.array_equal(data, img)
+        assert np.array_equal(mine[:img.nbytes], img.ravel()) and (mine[img.nbytes:] == 0xEE).all()      # it landed in the caller's memory
+        assert r._frame_ptr.contents.data == mine.ctypes.data
+        small = np.full(entry - 1, 0x77, np.uint8)
+        assert lib.cmf_frame_set_buffer(r._frame_ptr, small.ctypes.data, small.nbytes) == 0
+        w.write_frame(6, img[::-1].copy())
+        with pytest.raises(RuntimeError, match="smaller than the block"):
+            r.read_frame()
+        assert (small == 0x77).all()
+        assert lib.cmf_frame_set_buffer(r._frame_ptr, None, 0) == 0                                        # a buffer of its own again
+        st, data, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 6 and np.array_equal(data, img[::-1])
+        assert lib.cmf_frame_set_buffer(None, None, 0) < 0
+        # the binding's private read: without a device context on this thread there is no page-locked memory, the arrays are views
+        w.write_frame(7, [("forward", img), ("depth", np.ones((6, 8), np.float32))])
+        st, data, t, private = r.read_frame_private()
+        assert st == ReadStatus.SUCCESS and t == 7 and private is False and isinstance(data, tuple) and np.array_equal(data[0], img)
+        assert r.last_plane_names() == ("forward", "depth")
+        st, data2, _, _ = r.read_frame_private()
+        assert st == ReadStatus.NO_NEW_FRAME and data2 is not None

@@ -269,3 +269,37 @@ def test_post_takes_a_copy_without_giving_up_the_device_image(vp, oracle):
     assert c2 is not np.asarray(th) and c2[0, 0] == 255
     e = dilate(th, rect_kernel(3))                     # pending: host_copy computes it
     assert e._pending is not None and np.array_equal(e.host_copy(), np.asarray(e))
+
+
+def test_frames_read_straight_into_page_locked_memory(vp):
+    """With a device context on the thread the binding's private read hands out arrays of the reader's own in page-locked memory (the
+    seqlock copy is the only copy): writable, untouched by later reads, every plane with its type."""
+    import os
+    from vision.core.bindings.camera_message_framework import BlockAccessor, ReadStatus
+    vp.default_context()
+    d = f"pytpriv{os.getpid()}"
+    a = F.s1_buoy(0, 320, 200)
+    b = F.s1_buoy(1, 320, 200)
+    depth = np.arange(200 * 320, dtype=np.float32).reshape(200, 320)
+    with BlockAccessor(d, max_entry_size_bytes=a.nbytes + depth.nbytes) as w, BlockAccessor(d) as r:
+        w.write_frame(1, [("forward", a), ("depth", depth)])
+        st, data, t, private = r.read_frame_private()
+        assert st == ReadStatus.SUCCESS and private and t == 1 and r.last_plane_names() == ("forward", "depth")
+        fwd, dep = data
+        assert fwd.shape == (200, 320, 3) and fwd.dtype == np.uint8 and fwd.flags.writeable and np.array_equal(fwd, a)
+        assert dep.shape == (200, 320, 1) and dep.dtype == np.float32 and np.array_equal(dep[:, :, 0], depth)
+        w.write_frame(2, [("forward", b), ("depth", depth * 2)])
+        st, data2, t, private = r.read_frame_private()
+        assert st == ReadStatus.SUCCESS and private and t == 2 and np.array_equal(data2[0], b)
+        assert np.array_equal(fwd, a) and np.array_equal(dep[:, :, 0], depth)           # the first frame's arrays are still the first frame
+        fwd[:] = 0                                                                       # and writable without consequences for the second
+        assert np.array_equal(data2[0], b)
+        st, again, _, _ = r.read_frame_private()
+        assert st == ReadStatus.NO_NEW_FRAME
+        w.write_frame(3, a)                                                              # a single plane comes back as one array
+        st, one, t, private = r.read_frame_private()
+        assert st == ReadStatus.SUCCESS and private and isinstance(one, np.ndarray) and np.array_equal(one, a)
+        # the operators take such a frame like any other
+        from vision.utils.color import bgr_to_gray
+        g, _ = bgr_to_gray(one)
+        assert np.asarray(g).shape == (200, 320)
