@@ -9,6 +9,8 @@ cd $root
 python3 tools/exp_cases.py $out/${tag}_cases.json > $out/${tag}_cases.txt 2> $out/${tag}_cases.err
 python3 tools/exp_process.py 400 > $out/${tag}_process.txt 2>&1
 python3 tools/exp_dispatch.py > $out/${tag}_dispatch.txt 2>&1
+python3 tools/exp_runtime.py > $out/${tag}_runtime.txt 2>&1
+VP_PRIVATE_READS=0 python3 tools/exp_runtime.py >> $out/${tag}_runtime.txt 2>&1
 python3 tools/exp_configs.py > $out/${tag}_configs.txt 2>&1
 python3 tools/exp_latency.py > $out/${tag}_latency.txt 2>&1
 python3 tools/exp_hostmem.py > $out/${tag}_hostmem.txt 2>&1
