@@ -266,3 +266,22 @@ def test_contour_tuple_shares_one_point_block(vp, oracle):
     draw_contours(b, [c.copy() for c in cs], thickness=3)          # a plain list of copies takes the general path
     assert np.array_equal(a, b) and a[70:100, 20:80].any() and not a[70:100, 120:181].any()
     assert feature.contour_area(cs[0]) == 59.0 * 29.0
+
+
+@pytest.mark.parametrize("n", [2, 5, 9])
+def test_batches_at_1080p_every_strip_height(vp, oracle, n):
+    """The strip height of the union-finds inside contour extraction follows the batch (8 rows up to 3 frames of 1080p, 16 up to 7,
+    32 beyond): the same contours whichever is in use."""
+    from vision import _vp
+    from vision.utils import chain
+    frames = np.stack([F.s1_buoy(i) if i % 2 else F.s2_bins(i) for i in range(n)])
+    out = chain.run_chain(frames, _vp.BGR2LAB, (0, 140, 0), (255, 255, 255), ((_vp.MORPH_OPEN, 3, 3),), ccl=0, want=("cleaned",),
+                          contours=dict(source="cleaned", mode=1, method=2, max_contours=4096, max_points=1 << 17))
+    k = np.ones((3, 3), np.uint8)
+    for f in range(n):
+        th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(frames[f])[:, :, 1]), 140, 255)
+        cl = oracle.morph(oracle.OPEN, th, k, fast=True)
+        assert np.array_equal(out["cleaned"][f], cl)
+        exp, eh = oracle.find_contours(cl, 1, 2, with_holes=True)
+        got, gh = out["contours"][f]
+        assert _same(got, exp) and np.array_equal(gh, eh), (n, f, len(got), len(exp))
