@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void k_ccl_link(const u64* __restrict__ bits, 
 // One block per (frame, strip of CL_ROWS rows).
 // dynamic LDS: lbits[nw] u64 | wbase[nw + 2] u32 | lparent[cap] | lgid[cap] | lmin[cap] (cap <= nw + 2: lmin reuses wbase)
 __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits, ccl_geom G, u32* __restrict__ parent,
-                                                   u32* __restrict__ flags, int strips, int cap, const u32* __restrict__ only)
+                                                   u32* __restrict__ flags, int strips, int cap, const u32* __restrict__ only,
+                                                   u32* __restrict__ zero_too)   // nullable: bitmap with the layout of `flags`, cleared here
 {
     extern __shared__ __attribute__((aligned(16))) u64 cl_lds[];
     __shared__ u32 wsum[4];
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const u64* __restrict__ bits,
     CL_FOR_WORDS(r, j, i) lbits[i] = ccl_word(G, fb, (y0 + r) * ww + j, j);
     __syncthreads();
     ccl_local_strip(G, lbits, wbase, lparent, lparent + cap, cap <= nwmax + 2 ? wbase : lparent + 2 * cap, wsum, &total_s, y0, nrows, strip, strips, fb,
-                    parent + (size_t)frame * G.nids, flags + (size_t)frame * G.nw32, (u32)cap);
+                    parent + (size_t)frame * G.nids, flags + (size_t)frame * G.nw32, (u32)cap, zero_too ? zero_too + (size_t)frame * G.nw32 : nullptr);
 }
 
 // vertical unions across strip boundaries: grid (strips - 1, n), block = 64 threads over the words of the row
@@ -615,7 +616,10 @@ static size_t ccl_local_lds(const ccl_geom& G, size_t& cap)
 
 // union-find phase only: parent[] (every segment points at a smaller id of its component, roots at themselves)
 // and the exact root bitmap in flags[]; `only` (nullable): per-frame switch, frames whose entry is 0 are left alone
-static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags, const u32* only = nullptr)
+// zero_too (nullable): a bitmap laid out like `flags` that the caller wants cleared (the strip kernel clears its slice of the root
+// bitmap anyway; the contour code's "reaches the frame" bitmap rides along instead of costing a memset launch)
+static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u32* parent, u32* flags, const u32* only = nullptr,
+                     u32* zero_too = nullptr)
 {
     const int h = G.h;
     const dim3 wgrid((unsigned)((h * G.ww + 255) / 256), (unsigned)n);
@@ -624,9 +628,10 @@ static int ccl_roots(vp_ctx* ctx, const u64* d_bits, const ccl_geom& G, int n, u
     size_t cap;
     const size_t lds_local = ccl_local_lds(G, cap);
     if (lds_local <= 64 * 1024) {
-        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips, (int)cap, only); }
+        { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds_local, s, d_bits, G, parent, flags, strips, (int)cap, only, zero_too); }
         if (strips > 1) { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_boundary, dim3((unsigned)(strips - 1), (unsigned)n), dim3(64), 0, s, d_bits, G, parent, flags, only); }
     } else {
+        if (zero_too) { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(zero_too, 0, (size_t)G.nw32 * 4 * n, s)); }
         { vp_prof_scope ps(ctx, VPK_MEMSET); VP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)G.nw32 * 4 * n, s)); }
         { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY); hipLaunchKernelGGL(k_ccl_init, wgrid, dim3(256), 0, s, d_bits, G, parent, flags); }
         { vp_prof_scope ps(ctx, VPK_CCL_LOCAL); hipLaunchKernelGGL(k_ccl_link, wgrid, dim3(256), 0, s, d_bits, G, parent, flags); }

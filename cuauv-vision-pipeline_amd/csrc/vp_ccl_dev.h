@@ -274,7 +274,8 @@ __device__ __forceinline__ u32 ccl_local_unions(const ccl_geom& G, const u64* lb
 // rows of this strip).
 __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lbits, u32* wbase, u32* lparent, u32* lgid, u32* lmin,
                                                 u32* wsum, u32* total_s, int y0, int nrows, int strip, int strips,
-                                                const u64* __restrict__ fb, u32* __restrict__ gp, u32* __restrict__ gf, u32 cap = CL_CAP)
+                                                const u64* __restrict__ fb, u32* __restrict__ gp, u32* __restrict__ gf, u32 cap = CL_CAP,
+                                                u32* __restrict__ gz = nullptr)   // gz: a second bitmap of the same layout, cleared along with gf
 {
     const int ww = G.ww;
     const int tid = threadIdx.x;
@@ -286,7 +287,7 @@ __device__ __forceinline__ void ccl_local_strip(const ccl_geom& G, const u64* lb
         const u32 w0 = lo >> 5;
         const u32 w1 = (strip == strips - 1) ? G.nw32 : ((G.numbering == VP_CCL_BLOCK2X2) ? ((u32)((y0 + G.rows) >> 1) * rows_ids) >> 5
                                                                                          : ((u32)(y0 + G.rows) * rows_ids) >> 5);
-        for (u32 i = w0 + tid; i < w1; i += 256) gf[i] = 0u;
+        for (u32 i = w0 + tid; i < w1; i += 256) { gf[i] = 0u; if (gz) gz[i] = 0u; }
     }
     u32 my_first;
     const u32 S = ccl_local_unions(G, lbits, wbase, lparent, lgid, wsum, total_s, y0, nrows, cap, &my_first);

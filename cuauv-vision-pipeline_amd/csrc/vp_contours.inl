@@ -72,7 +72,7 @@ __device__ __forceinline__ void ct_root_pixel(const ccl_geom& G, const u64* __re
 __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, ccl_geom Gf, ccl_geom Gb, const u32* __restrict__ fg_flags,
                                                   const u32* __restrict__ bg_flags, const u32* __restrict__ bg_parent,
                                                   const u32* __restrict__ outside, int mode, u64* __restrict__ startmap, u64* __restrict__ holemap,
-                                                  u64* __restrict__ selmap)
+                                                  u64* __restrict__ selmap, u32* __restrict__ partsum2, int nparts)
 {
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (t >= Gf.nw32) return;
@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
     u64* sm = startmap + fo;
     u64* hm = holemap + fo;
     u64* sel = selmap + fo;
+    u32* ps2 = partsum2 + (size_t)f * nparts;      // selected starts per 256 words of the frame (k_ct_prefix scans them)
+    auto select = [&](size_t wi, int bit) {
+        const unsigned long long old = atomicOr((unsigned long long*)&sel[wi], 1ull << bit);
+        if (!((old >> bit) & 1ull)) atomicAdd(ps2 + (wi >> 8), 1u);
+    };
     const u32* bp = bg_parent + (size_t)f * Gb.nids;
     const u32* out = outside + (size_t)f * Gb.nw32;
     u32 m = fg_flags[(size_t)f * Gf.nw32 + t];
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
         }
         const size_t wi = (size_t)y * Gf.ww + (x >> 6);
         atomicOr((unsigned long long*)&sm[wi], 1ull << (x & 63));
-        if (keep) atomicOr((unsigned long long*)&sel[wi], 1ull << (x & 63));
+        if (keep) select(wi, x & 63);
     }
     u32 hb = bg_flags[(size_t)f * Gb.nw32 + t] & ~out[t];   // hole borders: background regions that do not reach the frame
     while (hb) {
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
         const size_t wi = (size_t)y * Gf.ww + (xs >> 6);
         atomicOr((unsigned long long*)&sm[wi], 1ull << (xs & 63));
         atomicOr((unsigned long long*)&hm[wi], 1ull << (xs & 63));
-        if (mode == 1) atomicOr((unsigned long long*)&sel[wi], 1ull << (xs & 63));
+        if (mode == 1) select(wi, xs & 63);
     }
 }
 
@@ -124,7 +129,8 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
 // the crack alone: s = first foreground neighbour clockwise from the crack's direction.  So the states that sweep a W or E
 // crack (and, to cut long flat edges, an N or S crack at x % 8 == 0) are enumerable with bit operations - the "heads" - and
 // they cut every border into short segments that are followed independently, one thread each:
-//   k_ct_headmaps   4 head bitmaps per word (a state that sweeps several eligible cracks belongs to the first one swept)
+//   k_ct_headmaps   4 head bitmaps per word (a state that sweeps several eligible cracks belongs to the first one swept); clears the
+//                   seed bitmaps k_ct_seeds fills next
 //   k_ct_prefix     popcount prefix -> dense head index + head list (pixel, type), terminal marks cleared; the same kernel
 //                   ranks the selected start pixels (cv2's contour order)
 //   k_ct_starts     start pixel of every border -> its start state -> the head that owns it = the terminal of that cycle
@@ -175,13 +181,19 @@ __device__ __forceinline__ void ct_block_sum(u32 c, u32* __restrict__ partsum)
     if (threadIdx.x == 0) partsum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ws4[0] + ws4[1] + ws4[2] + ws4[3];
 }
 
-__global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps, u32* __restrict__ partsum)
+// (also clears this word of the three seed bitmaps and the block's entry of the selected-start partial sums, which k_ct_seeds fills
+// afterwards: one launch instead of a memset, this one and a counting pass)
+__global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps, u32* __restrict__ partsum,
+                                                     u64* __restrict__ maps3, size_t mstride, u32* __restrict__ partsum2)
 {
     const int nwords = G.h * G.ww;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
     u32 cnt = 0;
+    if (threadIdx.x == 0) partsum2[(size_t)f * gridDim.x + blockIdx.x] = 0u;
     if (idx < nwords) {
+        const size_t wi = (size_t)f * nwords + idx;
+        maps3[wi] = 0ull; maps3[mstride + wi] = 0ull; maps3[2 * mstride + wi] = 0ull;
         const u64* fb = bits + (size_t)f * nwords;
         const int y = idx / G.ww, j = idx - y * G.ww;
         u64 c, n[8];
@@ -200,13 +212,6 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
         cnt = (u32)(__popcll(hw) + __popcll(he) + __popcll(hn) + __popcll(hs));
     }
     ct_block_sum(cnt, partsum);
-}
-
-// popcount of one bitmap per word, summed per block of 256 words
-__global__ __launch_bounds__(256) void k_ct_partsum(const u64* __restrict__ map, int nwords, u32* __restrict__ partsum)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    ct_block_sum(idx < nwords ? (u32)__popcll(map[(size_t)blockIdx.y * nwords + idx]) : 0u, partsum);
 }
 
 // exclusive prefix of the popcounts of `nm` bitmaps per word -> base[word]; total -> total_out[f * tstride].
@@ -679,22 +684,16 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s));
     VP_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fb_fork, 0));
     ctx->stream = side;
-    int rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags);
+    int rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags, nullptr, outside);   // (clears `outside` on the way)
     ctx->stream = s;
     if (rc == VP_OK) {
-        hipError_t e = hipMemsetAsync(outside, 0, nids / 8 * n, side);
-        if (e != hipSuccess) rc = vp_fail(ctx, VP_ERR_HIP, "hipMemsetAsync", e);
-        else hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, side, d_bits, Gb, bg_parent, outside);
+        hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, side, d_bits, Gb, bg_parent, outside);
     }
     // join whatever was queued on the side stream, also after an error
     const hipError_t j1 = hipEventRecord(ctx->ev_fb_join, side);
     if (rc == VP_OK) rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
     if (rc == VP_OK) {
-        hipError_t e = hipMemsetAsync(maps3, 0, 3 * mstride * 8, s);
-        if (e != hipSuccess) rc = vp_fail(ctx, VP_ERR_HIP, "hipMemsetAsync", e);
-    }
-    if (rc == VP_OK) {
-        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum);
+        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2);
         hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
     }
     const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_fb_join, 0) : j1;
@@ -702,8 +701,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     if (j1 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", j1);
     if (j2 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", j2);
     hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
-                       outside, mode, startmap, holemap, selmap);
-    hipLaunchKernelGGL(k_ct_partsum, wgrid, dim3(256), 0, s, selmap, nwords, partsum2);
+                       outside, mode, startmap, holemap, selmap, partsum2, (int)nparts);
     hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, selmap, 1, nwords, partsum2, sbase, &aux->nsel, 2, w, Gf.ww, (u32*)nullptr, (u32*)nullptr, hcap);
     hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, sbase, hmaps, hbase, hrank, hcap, starts, shead,
                        max_contours);
