@@ -346,22 +346,45 @@ __device__ __forceinline__ int ct_head_type(int s, int t, int x)
 
 // start pixel of every border -> terminal head.  starts[r] = pixel | hole << 31 and shead[r] = head index (CT_NONE: single
 // pixel) for the selected borders in raster order; hrank[head] = r, or CT_UNSEL for a border the mode does not return.
+// (the rank of a word's first selected start = number of selected starts before it in raster order, from the per-block counts
+// k_ct_seeds made plus a scan of this block's words: cv2's contour order; the last block publishes the total)
 __global__ __launch_bounds__(256) void k_ct_starts(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ startmap,
-                                                   const u64* __restrict__ holemap, const u64* __restrict__ selmap, const u32* __restrict__ sbase,
-                                                   const u64* __restrict__ hmaps, const u32* __restrict__ hbase, u32* __restrict__ hrank, size_t hcap,
-                                                   u32* __restrict__ starts, u32* __restrict__ shead, int max_contours)
+                                                   const u64* __restrict__ holemap, const u64* __restrict__ selmap, const u32* __restrict__ partsum2,
+                                                   u32* __restrict__ nsel_out, const u64* __restrict__ hmaps, const u32* __restrict__ hbase,
+                                                   u32* __restrict__ hrank, size_t hcap, u32* __restrict__ starts, u32* __restrict__ shead,
+                                                   int max_contours)
 {
+    __shared__ u32 wsum[4], wtot[4];
     const int nwords = G.h * G.ww;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nwords) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int idx = blockIdx.x * 256 + tid;
     const int f = blockIdx.y;
     const size_t fo = (size_t)f * nwords;
+    const bool valid = idx < nwords;
+    const u32* ps = partsum2 + (size_t)f * gridDim.x;
+    u32 c = 0;
+    for (int q = tid; q < (int)blockIdx.x; q += 256) c += ps[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) wtot[wv] = c;
+    const u64 sel = valid ? selmap[fo + idx] : 0ull;
+    const u32 cnt = (u32)__popcll(sel);
+    u32 inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    const u32 carry = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    u32 woff = 0;
+    for (int k = 0; k < wv; k++) woff += wsum[k];
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) nsel_out[(size_t)f * 2] = carry + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (!valid) return;
     u64 sm = startmap[fo + idx];
     if (!sm) return;
-    const u64 hm = holemap[fo + idx], sel = selmap[fo + idx];
+    const u64 hm = holemap[fo + idx];
     const u64* fb = bits + fo;
     const int y = idx / G.ww, j = idx - y * G.ww;
-    u32 r = sbase[fo + idx];
+    u32 r = carry + woff + inc - cnt;
     while (sm) {
         const int b = __ffsll((long long)sm) - 1;
         sm &= sm - 1;
@@ -653,7 +676,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     u64* maps3 = (u64*)vp_ws_take(ctx, 3 * vp_align(words * 8));   // startmap, holemap, selmap: cleared together
     u64* hmaps = (u64*)vp_ws_take(ctx, words * 32);
     u32* hbase = (u32*)vp_ws_take(ctx, words * 4);
-    u32* sbase = (u32*)vp_ws_take(ctx, words * 4);
+    u32* sbase = (u32*)vp_ws_take(ctx, words * 4);   // (no longer written: k_ct_starts ranks the starts itself; kept so that the scratch layout stays as sized)
     u32* head_pix = (u32*)vp_ws_take(ctx, hcap * n * 4);
     u32* hrank = (u32*)vp_ws_take(ctx, hcap * n * 4);
     unsigned long long* node = (unsigned long long*)vp_ws_take(ctx, hcap * n * 8);
@@ -702,9 +725,8 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     if (j2 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", j2);
     hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
                        outside, mode, startmap, holemap, selmap, partsum2, (int)nparts);
-    hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, selmap, 1, nwords, partsum2, sbase, &aux->nsel, 2, w, Gf.ww, (u32*)nullptr, (u32*)nullptr, hcap);
-    hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, sbase, hmaps, hbase, hrank, hcap, starts, shead,
-                       max_contours);
+    hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, partsum2, &aux->nsel, hmaps, hbase, hrank, hcap, starts,
+                       shead, max_contours);
     hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
                        max_contours, max_points);
     hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), 0, s, aux, node, hcap);
