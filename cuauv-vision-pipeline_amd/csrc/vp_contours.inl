@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
 //                   ranks the selected start pixels (cv2's contour order)
 //   k_ct_starts     start pixel of every border -> its start state -> the head that owns it = the terminal of that cycle
 //   k_ct_seg<false> follow each segment to the next head: node[k] = (next head, points emitted)
-//   k_ct_jump       pointer jumping on (next, distance) pairs until every head points at its terminal
-//   k_ct_offsets    per contour: length = distance of the terminal around its cycle; exclusive scan
+//   k_ct_jump       pointer jumping on (next, distance) pairs until every head points at its terminal; then per contour:
+//                   length = distance of the terminal around its cycle, exclusive scan -> offsets
 //   k_ct_seg<true>  follow each segment again, writing its points at offset[contour] + (length - distance to terminal)
 // OpenCV's start rule (icvFetchContour: first neighbour clockwise from W for an outer border, from E for a hole border) is
 // the head rule for the W / E crack of the start pixel, and its CHAIN_APPROX_SIMPLE filter (keep a point when the direction
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_ct_starts(const u64* __restrict__ bits,
 
 // one thread per head: follow the border from the head's state to the next head.
 //   !WRITE: node[k] = (next head | CT_TERM if that is a terminal) << 32 | points emitted
-//    WRITE: the points go to their final place (see k_ct_offsets)
+//    WRITE: the points go to their final place (see ct_offsets_body)
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ hmaps, const u32* __restrict__ hbase,
                                                 const u32* __restrict__ head_pix, const u32* __restrict__ hrank, size_t hcap,
@@ -491,59 +491,22 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
 // 64-bit load is always a consistent (older or newer) statement of that invariant, so the rounds need no double buffering.
 // Up to CTJ_LDS heads the table lives in LDS for the rounds.
 #define CTJ_LDS 8192
-__global__ __launch_bounds__(1024) void k_ct_jump(const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, size_t hcap)
-{
-    __shared__ unsigned long long tab[CTJ_LDS];
-    const int f = blockIdx.x;
-    const u32 H = aux[f].nheads;
-    unsigned long long* nd = node + (size_t)f * hcap;
-    if (H <= CTJ_LDS) {
-        for (u32 k = threadIdx.x; k < H; k += 1024) tab[k] = nd[k];
-        __syncthreads();
-        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
-            int changed = 0;
-            for (u32 k = threadIdx.x; k < H; k += 1024) {
-                const unsigned long long v = tab[k];
-                const u32 J = (u32)(v >> 32);
-                if (J & CT_TERM) continue;
-                const unsigned long long v2 = tab[J];
-                tab[k] = (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2);
-                changed = 1;
-            }
-            if (!__syncthreads_or(changed)) break;
-        }
-        for (u32 k = threadIdx.x; k < H; k += 1024) nd[k] = tab[k];
-        return;
-    }
-    for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
-        int changed = 0;
-        for (u32 k = threadIdx.x; k < H; k += 1024) {
-            const unsigned long long v = __hip_atomic_load(nd + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u32 J = (u32)(v >> 32);
-            if (J & CT_TERM) continue;
-            const unsigned long long v2 = __hip_atomic_load(nd + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(nd + k, (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            changed = 1;
-        }
-        if (!__syncthreads_or(changed)) break;
-    }
-}
-
 // per frame: contour lengths from the terminals, exclusive scan -> offsets, total -> out[f].n_points; single-pixel contours are
-// written here (one block per frame)
-__global__ __launch_bounds__(256) void k_ct_offsets(ccl_geom G, const ct_aux* __restrict__ aux, const u32* __restrict__ starts, const u32* __restrict__ shead,
-                                                    const unsigned long long* __restrict__ node, size_t hcap, int32_t* __restrict__ counts,
-                                                    uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
-                                                    ct_frame_out* __restrict__ out, int max_contours, long long max_points)
+// written here.  All NT threads of the block take part.
+template <int NT>
+__device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, const ct_aux* __restrict__ aux, const u32* __restrict__ starts,
+                                                const u32* __restrict__ shead, const unsigned long long* __restrict__ node, size_t hcap,
+                                                int32_t* __restrict__ counts, uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets,
+                                                int32_t* __restrict__ points, ct_frame_out* __restrict__ out, int max_contours, long long max_points)
 {
-    __shared__ u32 wsum[4];
+    __shared__ u32 wsum[NT / 64];
     __shared__ u32 carry;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nsel = (int)aux[f].nsel;
     const int K = min(nsel, max_contours);
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < K; base += 256) {
+    for (int base = 0; base < K; base += NT) {
         const int i = base + tid;
         u32 v = 0, st = 0, sh = 0;
         if (i < K) {
@@ -571,10 +534,56 @@ __global__ __launch_bounds__(256) void k_ct_offsets(ccl_geom G, const ct_aux* __
             }
         }
         __syncthreads();
-        if (tid == 255) carry += woff + inc;
+        if (tid == NT - 1) carry += woff + inc;
         __syncthreads();
     }
     if (tid == 0) { out[f].n_contours = nsel; out[f].n_points = (int32_t)carry; }
+}
+
+// One block per frame: pointer jumping over the (next head, distance) pairs until every head points at its terminal, then the
+// contour lengths / offsets from the terminals (what used to be a launch of its own).
+__global__ __launch_bounds__(1024) void k_ct_jump(ccl_geom G, const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, size_t hcap,
+                                                  const u32* __restrict__ starts, const u32* __restrict__ shead, int32_t* __restrict__ counts,
+                                                  uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
+                                                  ct_frame_out* __restrict__ out, int max_contours, long long max_points)
+{
+    __shared__ unsigned long long tab[CTJ_LDS];
+    const int f = blockIdx.x;
+    const u32 H = aux[f].nheads;
+    unsigned long long* nd = node + (size_t)f * hcap;
+    if (H <= CTJ_LDS) {
+        for (u32 k = threadIdx.x; k < H; k += 1024) tab[k] = nd[k];
+        __syncthreads();
+        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
+            int changed = 0;
+            for (u32 k = threadIdx.x; k < H; k += 1024) {
+                const unsigned long long v = tab[k];
+                const u32 J = (u32)(v >> 32);
+                if (J & CT_TERM) continue;
+                const unsigned long long v2 = tab[J];
+                tab[k] = (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2);
+                changed = 1;
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+        for (u32 k = threadIdx.x; k < H; k += 1024) nd[k] = tab[k];
+    } else {
+        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
+            int changed = 0;
+            for (u32 k = threadIdx.x; k < H; k += 1024) {
+                const unsigned long long v = __hip_atomic_load(nd + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 J = (u32)(v >> 32);
+                if (J & CT_TERM) continue;
+                const unsigned long long v2 = __hip_atomic_load(nd + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(nd + k, (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                changed = 1;
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();               // the block's own stores to node[] are visible to all its threads from here on
+    ct_offsets_body<1024>(G, aux, starts, shead, node, hcap, counts, is_hole_out, offsets, points, out, max_contours, max_points);
 }
 #undef dx8
 #undef dy8
@@ -729,8 +738,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
                        shead, max_contours);
     hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
                        max_contours, max_points);
-    hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), 0, s, aux, node, hcap);
-    hipLaunchKernelGGL(k_ct_offsets, dim3((unsigned)n), dim3(256), 0, s, Gf, aux, starts, shead, node, hcap, d_counts, d_is_hole, d_offsets, d_points, info,
+    hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), 0, s, Gf, aux, node, hcap, starts, shead, d_counts, d_is_hole, d_offsets, d_points, info,
                        max_contours, max_points);
     hipLaunchKernelGGL((k_ct_seg<true>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
                        max_contours, max_points);
