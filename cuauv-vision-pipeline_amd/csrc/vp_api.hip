@@ -1104,8 +1104,12 @@ static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_devic
     const size_t hdr_pad = vp_align(hdr_bytes);
     uint8_t* hs = (uint8_t*)vp_hstage(ctx, hdr_pad + spec_pts * 8);
     if (!hs) return vp_fail(ctx, VP_ERR_NOMEM, "pinned staging");
-    VP_TRY(d2h(ctx, hs, d_hdr, hdr_bytes));
-    if (spec_pts) VP_TRY(d2h(ctx, hs + hdr_pad, d_points, spec_pts * 8));
+    if (spec_pts && reinterpret_cast<uint8_t*>(d_points) == d_hdr + hdr_pad) {
+        VP_TRY(d2h(ctx, hs, d_hdr, hdr_pad + spec_pts * 8));           // header and points lie back to back in the workspace: one copy
+    } else {
+        VP_TRY(d2h(ctx, hs, d_hdr, hdr_bytes));
+        if (spec_pts) VP_TRY(d2h(ctx, hs + hdr_pad, d_points, spec_pts * 8));
+    }
     VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t* info = reinterpret_cast<const int32_t*>(hs);
     const int K = info[0];
