@@ -21,7 +21,7 @@ def _ring(cx, cy, r, n):
     return np.stack([cx + r * np.cos(t), cy + r * np.sin(t)], 1).round().astype(np.int32).reshape(-1, 1, 2)
 
 
-@pytest.mark.parametrize("thickness", [1, 2, 3, 4, 10, 17])
+@pytest.mark.parametrize("thickness", [1, 2, 3, 4, 10, 17, 31, 32, 33, 40])
 @pytest.mark.parametrize("closed", [True, False])
 def test_native_equals_python(thickness, closed):
     rng = np.random.default_rng(thickness)
