@@ -65,3 +65,37 @@ def test_random_chain(vp, oracle, seed):
             got, gh = out["contours"][f]
             assert len(got) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got, exp)), (seed, "contours")
             assert np.array_equal(gh, eh)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_single_image_contours(vp, oracle, block):
+    """Seeded sweep of single-image contour extraction (the form every module's outer_contours / all_contours call takes): random
+    sizes - widths that allow 8-, 16- and only 32-row strips in the union-finds -, densities from isolated pixels to nearly full,
+    rings, blocks; both retrieval modes and approximations; host and device-resident masks.  tools/fuzz_contours.py runs more seeds."""
+    from vision.utils import feature
+    from vision.utils.color import range_threshold
+    for seed in range(1000 + 12 * block, 1000 + 12 * (block + 1)):
+        rng = np.random.default_rng(seed)
+        h = int(rng.integers(1, 260))
+        w = int(rng.choice([rng.integers(1, 500), 8 * rng.integers(1, 60), 64 * rng.integers(1, 8), 2 * rng.integers(1, 200) + 1]))
+        kind = seed % 4
+        if kind == 0:
+            m = (rng.random((h, w)) < rng.choice([0.01, 0.1, 0.3, 0.5, 0.7, 0.95])).astype(np.uint8) * 255
+        elif kind == 1:
+            yy, xx = np.mgrid[0:h, 0:w]
+            m = np.zeros((h, w), np.uint8)
+            for _ in range(int(rng.integers(1, 10))):
+                cx, cy, rx, ry = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(1, max(2, w / 3)), rng.uniform(1, max(2, h / 3))
+                ring = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2
+                m[(ring <= 1) & (ring >= rng.choice([0.0, 0.3, 0.7]))] = 255
+        elif kind == 2:
+            m = np.full((h, w), 255, np.uint8)
+            m[rng.random((h, w)) < 0.02] = 0
+        else:
+            m = np.ascontiguousarray(np.kron((rng.random(((h + 7) // 8, (w + 7) // 8)) < 0.5).astype(np.uint8) * 255, np.ones((8, 8), np.uint8))[:h, :w])
+        mode, method = int(rng.integers(0, 2)), int(rng.integers(1, 3))
+        src = range_threshold(m, 128, 255) if seed % 3 == 0 else m
+        got, gh = feature.find_contours(src, mode, method, with_holes=True)
+        exp, eh = oracle.find_contours(m, mode, method, with_holes=True)
+        assert len(got) == len(exp) and all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(got, exp)) and np.array_equal(gh, eh), \
+            (seed, h, w, kind, mode, method, len(got), len(exp))
