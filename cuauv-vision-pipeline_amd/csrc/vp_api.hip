@@ -846,6 +846,50 @@ int vp_convex_hull_i32(const int32_t* pts, int npts, int32_t* out, int* nout)
     return VP_OK;
 }
 
+// cv2.minAreaRect of the stand-in for integer points (host code; modules/bins.py:62 calls it for every contour): rotating calipers
+// over the hull above - for every hull edge the extent of the hull along and across it, the first edge of smallest area wins -
+// in the doubles of the Python statements (vision/cv2_facade.py _min_area_rect_loop; edge lengths as sqrt of an exact integer).
+// out5 = cx, cy, width, height, angle in degrees (OpenCV >= 4.5.1 convention: angle in (0, 90]), already rounded to float.
+int vp_min_area_rect_i32(const int32_t* pts, int npts, float* out5)
+{
+    if (!pts || !out5 || npts < 0) return VP_ERR_INVALID;
+    std::vector<int32_t> hull((size_t)std::max(npts, 1) * 2);
+    int n = 0;
+    if (vp_convex_hull_i32(pts, npts, hull.data(), &n) != VP_OK) return VP_ERR_INVALID;
+    if (n == 0) { for (int i = 0; i < 5; i++) out5[i] = 0.f; return VP_OK; }
+    if (n == 1) { out5[0] = (float)hull[0]; out5[1] = (float)hull[1]; out5[2] = out5[3] = 0.f; out5[4] = 90.f; return VP_OK; }
+    bool have = false;
+    double best_area = 0, bcx = 0, bcy = 0, bwd = 0, bht = 0, bang = 0;
+    const int edges = n > 2 ? n : 1;
+    for (int i = 0; i < edges; i++) {
+        const int i1 = (i + 1) % n;
+        const double ex = (double)hull[2 * i1] - (double)hull[2 * i], ey = (double)hull[2 * i1 + 1] - (double)hull[2 * i + 1];
+        const double ln = sqrt(ex * ex + ey * ey);
+        if (ln == 0) continue;
+        const double ux = ex / ln, uy = ey / ln;
+        double amax = 0, amin = 0, bmax = 0, bmin = 0;
+        for (int k = 0; k < n; k++) {
+            const double hx = (double)hull[2 * k], hy = (double)hull[2 * k + 1];
+            const double a = hx * ux + hy * uy, b = -hx * uy + hy * ux;
+            if (k == 0) { amax = amin = a; bmax = bmin = b; }
+            else { amax = std::max(amax, a); amin = std::min(amin, a); bmax = std::max(bmax, b); bmin = std::min(bmin, b); }
+        }
+        const double wd = amax - amin, ht = bmax - bmin;
+        if (!have || wd * ht < best_area) {
+            const double ca = (amax + amin) / 2, cb = (bmax + bmin) / 2;
+            have = true;
+            best_area = wd * ht;
+            bcx = ca * ux - cb * uy; bcy = ca * uy + cb * ux; bwd = wd; bht = ht;
+            bang = atan2(uy, ux) * (180.0 / 3.141592653589793);
+        }
+    }
+    if (!have) { out5[0] = (float)hull[0]; out5[1] = (float)hull[1]; out5[2] = out5[3] = 0.f; out5[4] = 90.f; return VP_OK; }
+    while (bang <= 0) { bang += 90; std::swap(bwd, bht); }
+    while (bang > 90) { bang -= 90; std::swap(bwd, bht); }
+    out5[0] = (float)bcx; out5[1] = (float)bcy; out5[2] = (float)bwd; out5[3] = (float)bht; out5[4] = (float)bang;
+    return VP_OK;
+}
+
 // counts[k] points per polyline, back to back in pts; one call draws them all (a frame's contours).
 // All stamps carry one colour, so the image is "colour wherever some stamp covers": the stamps are collected in a coverage bit plane
 // (one bit per pixel, 259 KB at 1080p, per thread, left zeroed) and the image is written once, row by row, run by run.

@@ -103,6 +103,7 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_draw_polyline_u8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "vp_convex_hull_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "vp_min_area_rect_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vp_polygon_sums_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vp_draw_polylines_u8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "vp_cvt_color_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

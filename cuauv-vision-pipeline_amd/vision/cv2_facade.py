@@ -190,6 +190,13 @@ def _convex_hull(points):
 def minAreaRect(points):
     """Minimum-area enclosing rectangle by rotating calipers over the convex hull: ((cx, cy), (w, h), angle in degrees).
     Angle convention of OpenCV >= 4.5.1: in (0, 90], width measured along the edge that defines the angle."""
+    p = np.asarray(points).reshape(-1, 2)
+    if np.issubdtype(p.dtype, np.integer) and len(p) and np.abs(p).max(initial=0) < 2**31:
+        # contours: hull and calipers in libvp's host routine (the doubles of _min_area_rect_loop, statement by statement)
+        p32 = p if (p.dtype == np.int32 and p.flags.c_contiguous) else np.ascontiguousarray(p, np.int32)
+        out = (_vp.C.c_float * 5)()
+        _vp.check(_vp.lib().vp_min_area_rect_i32(p32.ctypes.data, len(p32), out))
+        return (out[0], out[1]), (out[2], out[3]), out[4]
     hull = _convex_hull(points)
     if len(hull) == 0:
         return (0.0, 0.0), (0.0, 0.0), 0.0
@@ -198,7 +205,7 @@ def minAreaRect(points):
     n = len(hull)
     # every edge at once (columns): the same products and sums as edge by edge, the first edge of minimal area wins
     e = (np.roll(hull, -1, axis=0) - hull)[: (n if n > 2 else 1)]
-    ln = np.array([math.hypot(x, y) for x, y in e.tolist()])
+    ln = np.array([math.sqrt(x * x + y * y) for x, y in e.tolist()])
     keep = ln != 0
     if not keep.any():
         return (float(hull[0, 0]), float(hull[0, 1])), (0.0, 0.0), 90.0
@@ -234,7 +241,7 @@ def _min_area_rect_loop(points):
     n = len(hull)
     for i in range(n if n > 2 else 1):
         e = hull[(i + 1) % n] - hull[i]
-        ln = math.hypot(e[0], e[1])
+        ln = math.sqrt(e[0] * e[0] + e[1] * e[1])     # (exact under the root for integer points)
         if ln == 0:
             continue
         ux, uy = e[0] / ln, e[1] / ln

@@ -168,6 +168,9 @@ int vp_polygon_sums_i32(const int32_t* pts_xy, int npts, int64_t* out3);
  * lexicographically smallest point, collinear points dropped; `out` holds up to npts points.  Used by the cv2.minAreaRect stand-in
  * (modules/bins.py:62). */
 int vp_convex_hull_i32(const int32_t* pts, int npts, int32_t* out, int* nout);
+/* cv2.minAreaRect stand-in for integer points (host code): rotating calipers over that hull; out5 = centre x, y, width, height,
+ * angle in degrees in (0, 90] (OpenCV >= 4.5.1 convention), as floats.  modules/bins.py:62 calls it for every contour. */
+int vp_min_area_rect_i32(const int32_t* pts, int npts, float* out5);
 
 /* utils/draw.py:283-327 `draw_contours` / `draw_polylines` (modules/red_buoy.py:39): in-place polyline on a HOST image (no device
  * work, no context): Bresenham steps with a square brush of `thickness` pixels - the Python mirror's rasteriser in C.  pts = npts

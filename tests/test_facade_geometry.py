@@ -37,9 +37,18 @@ def test_native_hull_equals_python_hull():
 
 
 def test_min_area_rect_equals_the_edge_by_edge_form():
+    """Integer points (contours) take libvp's host routine, anything else the all-edges-at-once numpy form: both give exactly what the
+    statements give edge by edge."""
     rng = np.random.default_rng(2)
     for pts in _shapes(rng):
-        assert cv2.minAreaRect(pts.reshape(-1, 1, 2)) == cv2._min_area_rect_loop(pts.reshape(-1, 1, 2)), pts[:5]
+        exp = cv2._min_area_rect_loop(pts.reshape(-1, 1, 2))
+        assert cv2.minAreaRect(pts.reshape(-1, 1, 2)) == exp, pts[:5]                       # native
+        assert cv2.minAreaRect(pts.astype(np.int64)) == exp                                 # native after conversion
+        assert cv2.minAreaRect(pts.astype(np.float64).reshape(-1, 1, 2)) == exp, pts[:5]    # numpy form on the same points
+    for _ in range(20):                                                                    # points that are not integers
+        f = rng.uniform(-50, 900, (int(rng.integers(1, 60)), 2))
+        assert cv2.minAreaRect(f) == cv2._min_area_rect_loop(f)
+    assert cv2.minAreaRect(np.zeros((0, 1, 2), np.int32)) == ((0.0, 0.0), (0.0, 0.0), 0.0)
     (cx, cy), (w, h), ang = cv2.minAreaRect(np.array([[10, 10], [10, 30], [50, 30], [50, 10]], np.int32))
     assert (cx, cy) == (30.0, 20.0) and sorted((w, h)) == [20.0, 40.0] and ang in (90.0,)
     box = cv2.boxPoints(((30.0, 20.0), (w, h), ang))
