@@ -46,8 +46,7 @@ def test_cvt_color(vp, oracle, h, w):
 
 
 def test_cvt_color_exhaustive_slices(vp, oracle):
-    """All 2^24 colours are too many for the oracle in seconds; cover every (b,g) x 8 r-values and the
-    grey axis plus the full gamma / cbrt table index range."""
+    """every (b,g) x 7 r-values (test_cvt_color_all_colours below runs all 2^24 triples)"""
     from vision.utils import color
     b, g = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
     for r in (0, 1, 37, 128, 200, 254, 255):
@@ -67,6 +66,21 @@ def test_cvt_color_all_colours(vp, oracle):
     assert np.array_equal(color.bgr_to_hls(img)[0], oracle.bgr2hls(img))
     assert np.array_equal(color.bgr_to_ycrcb(img)[0], oracle.bgr2ycrcb(img))
     assert np.array_equal(color.bgr_to_hsv(img)[0], oracle.bgr2hsv(img))
+    olab = oracle.bgr2lab(img)
+    assert np.array_equal(color.bgr_to_lab(img)[0], olab)
+    assert np.array_equal(color.bgr_to_gray(img)[0], oracle.bgr2gray(img))
+    # the fused convert + threshold kernels of the batched chain over the same 2^24 colours: every single-channel form of the LAB
+    # kernel (it computes only the channels the bounds constrain), the three-channel form, HSV and grey
+    from vision import _vp
+    from vision.utils import chain
+    ohsv, ogray = oracle.bgr2hsv(img), oracle.bgr2gray(img)
+    for mode, conv, lo, hi in ((_vp.BGR2LAB, olab, (60, 0, 0), (200, 255, 255)), (_vp.BGR2LAB, olab, (0, 150, 0), (255, 255, 255)),
+                               (_vp.BGR2LAB, olab, (0, 0, 90), (255, 255, 140)), (_vp.BGR2LAB, olab, (20, 110, 100), (240, 160, 170)),
+                               (_vp.BGR2HSV, ohsv, (10, 20, 60), (30, 100, 255)), (_vp.BGR2HSV, ohsv, (170, 0, 0), (179, 255, 255))):
+        out = chain.run_chain(img[None], mode, lo, hi, [], ccl=0, want=("threshed",))
+        assert np.array_equal(out["threshed"][0], oracle.inrange(conv, lo, hi)), (mode, lo, hi)
+    out = chain.run_chain(img[None], _vp.BGR2GRAY, (100, 0, 0), (180, 255, 255), [], ccl=0, want=("threshed",))
+    assert np.array_equal(out["threshed"][0], oracle.inrange(ogray, 100, 180))
 
 
 def test_cvt_color_strided_view(vp, oracle):
