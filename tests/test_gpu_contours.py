@@ -285,3 +285,52 @@ def test_batches_at_1080p_every_strip_height(vp, oracle, n):
         exp, eh = oracle.find_contours(cl, 1, 2, with_holes=True)
         got, gh = out["contours"][f]
         assert _same(got, exp) and np.array_equal(gh, eh), (n, f, len(got), len(exp))
+
+
+def _all_4x4_patterns(pitch=5):
+    """Every one of the 2^16 binary 4x4 patterns once, in a 256 x 256 grid of cells `pitch` pixels apart (a background gap keeps the
+    patterns apart; the pitch of 5 puts them at every alignment against the 64-bit words and the strips of the kernels)."""
+    n = 256
+    m = np.zeros((n * pitch + 3, n * pitch + 7), np.uint8)
+    v = np.arange(1 << 16, dtype=np.uint32).reshape(n, n)
+    for b in range(16):
+        m[(b // 4):(b // 4) + n * pitch:pitch, (b % 4):(b % 4) + n * pitch:pitch][:n, :n] = ((v >> b) & 1).astype(np.uint8) * 255
+    return m
+
+
+def test_every_4x4_pattern(vp, oracle):
+    """Exhaustive over local shapes: all 65,536 patterns of 4x4 pixels (rings with holes, diagonal contacts, single pixels, full
+    blocks) in one image - contours in both retrieval modes and approximations, and the component labelling in both numberings."""
+    from vision.utils import feature
+    m = _all_4x4_patterns()
+    for mode, method in ((1, 1), (0, 2), (1, 2)):
+        got, gh = feature.find_contours(m, mode, method, with_holes=True)
+        exp, eh = oracle.find_contours(m, mode, method, with_holes=True)
+        assert len(got) == len(exp) > 60000, (mode, method, len(got), len(exp))
+        assert np.array_equal(gh, eh)
+        assert np.array_equal(np.concatenate([c.reshape(-1, 2) for c in got]), np.concatenate([c.reshape(-1, 2) for c in exp]))
+        assert [len(c) for c in got] == [len(c) for c in exp]
+    for numbering in (2, 1):
+        n, lab, st, ce = feature.connected_components(m, numbering=numbering, max_labels=200000)
+        on, olab, ost, oce = oracle.ccl(m, block=numbering)
+        assert n == on and np.array_equal(lab, olab) and np.array_equal(st[:on], ost) and np.array_equal(ce[:on].view(np.uint64), oce.view(np.uint64))
+    # a pitch of 4 packs the patterns edge to edge into one texture (components span cells)
+    m4 = _all_4x4_patterns(4)
+    got = feature.find_contours(m4, 1, 2)
+    exp = oracle.find_contours(m4, 1, 2)
+    assert len(got) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got, exp))
+
+
+def test_every_4x4_pattern_through_morphology(vp, oracle):
+    """The same exhaustive image through the bit-plane morphology (rectangles, all four operators and the gradient) and the generic
+    path (cross, ellipse), both pitches."""
+    from vision import _vp
+    from vision.utils import transform
+    for pitch in (5, 4):
+        m = _all_4x4_patterns(pitch)
+        for shape, k in ((_vp.SHAPE_RECT, (3, 3)), (_vp.SHAPE_RECT, (5, 3)), (_vp.SHAPE_RECT, (2, 4)), (_vp.SHAPE_CROSS, (3, 3)), (_vp.SHAPE_ELLIPSE, (5, 5))):
+            se = transform._structuring_element(shape, k[0], k[1])
+            for name, op in (("erode", oracle.ERODE), ("dilate", oracle.DILATE), ("morph_remove_noise", oracle.OPEN), ("morph_close_holes", oracle.CLOSE),
+                             ("morph_borders", oracle.GRADIENT)):
+                got = getattr(transform, name)(m, se)
+                assert np.array_equal(got, oracle.morph(op, m, se)), (pitch, shape, k, name)
