@@ -467,3 +467,49 @@ def test_color_distance_equals_numpy1_vectors(oracle):
         assert np.array_equal(sq, c["sq"])
         if c["percentile"] is not None:                # numpy 2 on the very same float32 image gives the same threshold
             assert min(np.percentile(c["dists"], c["percentile"]), c["distance_arg"] ** 2) == c["distance"]
+
+
+def _all_4x4_patterns(pitch=5):
+    n = 256
+    m = np.zeros((n * pitch + 3, n * pitch + 7), np.uint8)
+    v = np.arange(1 << 16, dtype=np.uint32).reshape(n, n)
+    for b in range(16):
+        m[(b // 4):(b // 4) + n * pitch:pitch, (b % 4):(b % 4) + n * pitch:pitch][:n, :n] = ((v >> b) & 1).astype(np.uint8) * 255
+    return m
+
+
+@pytest.mark.parametrize("pitch", [5, 4])
+def test_every_4x4_pattern_against_scipy(oracle, pitch):
+    """All 65,536 binary 4x4 patterns in one image (apart, and packed edge to edge), SciPy as the witness: the oracle's labelling is
+    the same partition with exact statistics, its contour lists hold one outer border per 8-connected component and one hole border
+    per 4-connected background region that does not reach the frame, and its rectangle / cross morphology is SciPy's."""
+    m = _all_4x4_patterns(pitch)
+    ref, nref = ndi.label(m, structure=np.ones((3, 3)))
+    for block in (1, 2):
+        n, lab, st, ce = oracle.ccl(m, block)
+        assert n == nref + 1
+        pairs = np.unique(np.stack([lab.ravel(), ref.ravel()]), axis=1)
+        assert pairs.shape[1] == n                                        # one-to-one: the same partition
+        area = np.bincount(lab.ravel(), minlength=n)
+        assert np.array_equal(st[1:, 4], area[1:])
+        ys, xs = np.nonzero(lab)
+        l = lab[ys, xs]
+        assert np.array_equal(ce[1:, 0], (np.bincount(l, xs, n) / np.maximum(area, 1))[1:]) and np.array_equal(ce[1:, 1], (np.bincount(l, ys, n) / np.maximum(area, 1))[1:])
+    bg, nbg = ndi.label(m == 0, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    touching = np.unique(np.concatenate([bg[0], bg[-1], bg[:, 0], bg[:, -1]]))
+    holes = nbg - len(touching[touching > 0])
+    cs, hole_flags = oracle.find_contours(m, 1, 1, with_holes=True)
+    assert len(cs) == nref + holes and int(hole_flags.sum()) == holes
+    outer = oracle.find_contours(m, 0, 1)
+    assert len(outer) <= nref and (pitch == 4 or len(outer) == nref)      # apart: no pattern lies inside another's hole
+    for c in cs[:2000]:                                                   # every border pixel is foreground; a border is 8-connected and closed
+        p = c.reshape(-1, 2)
+        assert (m[p[:, 1], p[:, 0]] > 0).all()
+        d = np.abs(np.diff(np.vstack([p, p[:1]]), axis=0))
+        assert d.max(initial=0) <= 1
+    for k in (np.ones((3, 3), np.uint8), np.ones((2, 3), np.uint8), np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)):
+        # cv2 anchors a kernel at size // 2 for both operators; SciPy's erosion does the same, its dilation mirrors the structure
+        # about that centre, which an even axis answers with origin -1
+        assert np.array_equal(oracle.morph(oracle.ERODE, m, k) > 0, ndi.binary_erosion(m > 0, structure=k, border_value=1))
+        assert np.array_equal(oracle.morph(oracle.DILATE, m, k) > 0,
+                              ndi.binary_dilation(m > 0, structure=k, border_value=0, origin=tuple(-1 if s % 2 == 0 else 0 for s in k.shape)))
