@@ -502,6 +502,15 @@ def test_every_4x4_pattern_against_scipy(oracle, pitch):
     assert len(cs) == nref + holes and int(hole_flags.sum()) == holes
     outer = oracle.find_contours(m, 0, 1)
     assert len(outer) <= nref and (pitch == 4 or len(outer) == nref)      # apart: no pattern lies inside another's hole
+    # the points of all borders together (no approximation) are exactly the foreground pixels with a 4-neighbour in the background or
+    # outside the frame - stated with array shifts, no tracing
+    f = m > 0
+    pad = np.pad(f, 1)
+    inner = pad[:-2, 1:-1] & pad[2:, 1:-1] & pad[1:-1, :-2] & pad[1:-1, 2:]
+    allp = np.concatenate([c.reshape(-1, 2) for c in cs])
+    traced = np.zeros(m.shape, bool)
+    traced[allp[:, 1], allp[:, 0]] = True
+    assert np.array_equal(traced, f & ~inner)
     for c in cs[:2000]:                                                   # every border pixel is foreground; a border is 8-connected and closed
         p = c.reshape(-1, 2)
         assert (m[p[:, 1], p[:, 0]] > 0).all()
