@@ -511,6 +511,15 @@ def test_every_4x4_pattern_against_scipy(oracle, pitch):
     traced = np.zeros(m.shape, bool)
     traced[allp[:, 1], allp[:, 0]] = True
     assert np.array_equal(traced, f & ~inner)
+    # outer borders start at their component's first pixel in raster order, and the list runs from the last start to the first
+    first = np.full(nref + 1, -1, np.int64)
+    flat = ref.ravel()
+    idx = np.nonzero(flat)[0]
+    first[flat[idx][::-1]] = idx[::-1]                                    # (reverse assignment: the smallest index wins)
+    starts = np.array([int(c[0, 0, 1]) * m.shape[1] + int(c[0, 0, 0]) for c, hflag in zip(cs, hole_flags) if not hflag])
+    assert np.array_equal(np.sort(starts), np.sort(first[1:]))
+    allstarts = np.array([int(c[0, 0, 1]) * m.shape[1] + int(c[0, 0, 0]) for c in cs])
+    assert (np.diff(allstarts) < 0).all()
     for c in cs[:2000]:                                                   # every border pixel is foreground; a border is 8-connected and closed
         p = c.reshape(-1, 2)
         assert (m[p[:, 1], p[:, 0]] > 0).all()
