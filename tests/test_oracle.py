@@ -492,6 +492,19 @@ def test_every_4x4_pattern_against_scipy(oracle, pitch):
         assert pairs.shape[1] == n                                        # one-to-one: the same partition
         area = np.bincount(lab.ravel(), minlength=n)
         assert np.array_equal(st[1:, 4], area[1:])
+        # numbering, stated without the scan: components in the order of their first 2x2 block in block-raster order (two foreground
+        # pixels of one block are always connected, so a block belongs to one component) - or of their first pixel for the pixel scan
+        yy, xx = np.nonzero(lab)
+        key = ((yy >> 1) * ((m.shape[1] + 1) >> 1) + (xx >> 1)) if block == 2 else (yy * m.shape[1] + xx)
+        firstkey = np.full(n, np.iinfo(np.int64).max, np.int64)
+        np.minimum.at(firstkey, lab[yy, xx], key)
+        assert (np.diff(firstkey[1:]) > 0).all()
+        lo_x, lo_y = np.full(n, 1 << 30), np.full(n, 1 << 30)
+        hi_x, hi_y = np.full(n, -1), np.full(n, -1)
+        np.minimum.at(lo_x, lab[yy, xx], xx); np.minimum.at(lo_y, lab[yy, xx], yy)
+        np.maximum.at(hi_x, lab[yy, xx], xx); np.maximum.at(hi_y, lab[yy, xx], yy)
+        assert np.array_equal(st[1:, 0], lo_x[1:]) and np.array_equal(st[1:, 1], lo_y[1:])
+        assert np.array_equal(st[1:, 2], (hi_x - lo_x + 1)[1:]) and np.array_equal(st[1:, 3], (hi_y - lo_y + 1)[1:])
         ys, xs = np.nonzero(lab)
         l = lab[ys, xs]
         assert np.array_equal(ce[1:, 0], (np.bincount(l, xs, n) / np.maximum(area, 1))[1:]) and np.array_equal(ce[1:, 1], (np.bincount(l, ys, n) / np.maximum(area, 1))[1:])
