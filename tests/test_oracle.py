@@ -533,6 +533,14 @@ def test_every_4x4_pattern_against_scipy(oracle, pitch):
     assert np.array_equal(np.sort(starts), np.sort(first[1:]))
     allstarts = np.array([int(c[0, 0, 1]) * m.shape[1] + int(c[0, 0, 0]) for c in cs])
     assert (np.diff(allstarts) < 0).all()
+    # CHAIN_APPROX_SIMPLE = the full point list without the points a border runs straight through (cyclically)
+    simple = oracle.find_contours(m, 1, 2)
+    assert len(simple) == len(cs)
+    for full, short in zip(cs, simple):
+        p = full.reshape(-1, 2).astype(np.int64)
+        if len(p) > 1:
+            p = p[((np.roll(p, -1, axis=0) - p) != (p - np.roll(p, 1, axis=0))).any(axis=1)]
+        assert np.array_equal(p, short.reshape(-1, 2))
     for c in cs[:2000]:                                                   # every border pixel is foreground; a border is 8-connected and closed
         p = c.reshape(-1, 2)
         assert (m[p[:, 1], p[:, 0]] > 0).all()
