@@ -40,41 +40,42 @@ def test_lab_tables_variants(oracle):
     assert g0[0] == 0 and g0[255] == 2040 and c0[2040] == 32768
 
 
-def test_lab_against_analytic_float64(oracle):
-    rng = np.random.default_rng(0)
-    bgr = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
-    lab = oracle.bgr2lab(bgr).astype(np.float64)
-    rgb = bgr[:, :, ::-1].astype(np.float64) / 255
-    lin = np.where(rgb <= 0.04045, rgb / 12.92, ((rgb + 0.055) / 1.055) ** 2.4)
+def _all_colours(chunk=1 << 20):
+    for c0 in range(0, 1 << 24, chunk):
+        v = np.arange(c0, c0 + chunk, dtype=np.uint32)
+        yield np.stack([v & 255, (v >> 8) & 255, v >> 16], axis=1).astype(np.uint8).reshape(1024, -1, 3)
+
+
+def test_lab_and_hsv_against_analytic_float64_all_colours(oracle):
+    """Every one of the 2^24 BGR triples against the textbook formulas in float64 (sRGB gamma, D65 XYZ, CIE L*a*b* scaled to 8 bits;
+    hexcone HSV with H in half degrees).  HSV: the 8-bit result is the analytic value rounded (never further than 0.65 away).
+    LAB: the 8-bit path quantises linear light to 1/2040 and the cube root to a table, which costs up to 2.7 levels in a / b for very
+    dark pixels (true of cv2 as well); 99.86 % of all values are within 1, the mean distance is 0.27."""
     M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
-    xyz = lin @ M.T / np.array([0.950456, 1.0, 1.088754])
-    f = np.where(xyz > 216 / 24389, np.cbrt(xyz), 841 / 108 * xyz + 16 / 116)
-    L = (116 * f[..., 1] - 16) * 255 / 100
-    a = 500 * (f[..., 0] - f[..., 1]) + 128
-    b = 200 * (f[..., 1] - f[..., 2]) + 128
-    ref = np.stack([L, a, b], -1)
-    err = np.abs(lab - ref)
-    # the 8-bit path quantises linear light to 1/2040, which costs up to ~2 levels in a/b for very dark
-    # pixels (true of cv2 as well); everywhere else it is within rounding of the analytic value
-    assert err.max() <= 3.0 and np.mean(err <= 1.0) > 0.99 and err.mean() < 0.35
-
-
-def test_hsv_against_analytic(oracle):
-    rng = np.random.default_rng(1)
-    bgr = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
-    hsv = oracle.bgr2hsv(bgr).astype(np.float64)
-    b, g, r = [bgr[..., i].astype(np.float64) for i in range(3)]
-    v = np.maximum(np.maximum(b, g), r)
-    mn = np.minimum(np.minimum(b, g), r)
-    d = v - mn
-    s = np.where(v > 0, 255 * d / np.maximum(v, 1), 0)
-    dd = np.maximum(d, 1)
-    h = np.where(v == r, (g - b) / dd, np.where(v == g, 2 + (b - r) / dd, 4 + (r - g) / dd)) * 30
-    h = np.where(d == 0, 0, np.where(h < 0, h + 180, h))
-    assert np.array_equal(hsv[..., 2], v)
-    assert np.max(np.abs(hsv[..., 1] - s)) <= 1.0
-    dh = np.abs(hsv[..., 0] - h)
-    assert np.max(np.minimum(dh, 180 - dh)) <= 1.0
+    worst, within1, total, summed, s_worst, h_worst = 0.0, 0, 0, 0.0, 0.0, 0.0
+    for bgr in _all_colours():
+        lab = oracle.bgr2lab(bgr).astype(np.float64)
+        rgb = bgr[:, :, ::-1].astype(np.float64) / 255
+        lin = np.where(rgb <= 0.04045, rgb / 12.92, ((rgb + 0.055) / 1.055) ** 2.4)
+        xyz = lin @ M.T / np.array([0.950456, 1.0, 1.088754])
+        f = np.where(xyz > 216 / 24389, np.cbrt(xyz), 841 / 108 * xyz + 16 / 116)
+        ref = np.stack([(116 * f[..., 1] - 16) * 255 / 100, 500 * (f[..., 0] - f[..., 1]) + 128, 200 * (f[..., 1] - f[..., 2]) + 128], -1)
+        err = np.abs(lab - ref)
+        worst, within1, total, summed = max(worst, err.max()), within1 + int((err <= 1.0).sum()), total + err.size, summed + err.sum()
+        hsv = oracle.bgr2hsv(bgr).astype(np.float64)
+        b, g, r = [bgr[..., i].astype(np.float64) for i in range(3)]
+        v = np.maximum(np.maximum(b, g), r)
+        d = v - np.minimum(np.minimum(b, g), r)
+        sat = np.where(v > 0, 255 * d / np.maximum(v, 1), 0)
+        dd = np.maximum(d, 1)
+        h = np.where(v == r, (g - b) / dd, np.where(v == g, 2 + (b - r) / dd, 4 + (r - g) / dd)) * 30
+        h = np.where(d == 0, 0, np.where(h < 0, h + 180, h))
+        assert np.array_equal(hsv[..., 2], v)
+        s_worst = max(s_worst, np.abs(hsv[..., 1] - sat).max())
+        dh = np.abs(hsv[..., 0] - h)
+        h_worst = max(h_worst, np.minimum(dh, 180 - dh).max())
+    assert worst <= 3.0 and within1 / total > 0.998 and summed / total < 0.3, (worst, within1 / total, summed / total)
+    assert s_worst <= 0.6 and h_worst <= 0.7, (s_worst, h_worst)
 
 
 def test_inrange_known(oracle):
