@@ -71,6 +71,7 @@ def test_lab_and_hsv_against_analytic_float64_all_colours(oracle):
         h = np.where(v == r, (g - b) / dd, np.where(v == g, 2 + (b - r) / dd, 4 + (r - g) / dd)) * 30
         h = np.where(d == 0, 0, np.where(h < 0, h + 180, h))
         assert np.array_equal(hsv[..., 2], v)
+        assert np.abs(oracle.bgr2gray(bgr) - (0.114 * b + 0.587 * g + 0.299 * r)).max() <= 0.51      # grey: the weighted sum, rounded
         s_worst = max(s_worst, np.abs(hsv[..., 1] - sat).max())
         dh = np.abs(hsv[..., 0] - h)
         h_worst = max(h_worst, np.minimum(dh, 180 - dh).max())
