@@ -480,18 +480,17 @@ def _all_4x4_patterns(pitch=5):
     return m
 
 
-@pytest.mark.parametrize("pitch", [5, 4])
-def test_every_4x4_pattern_against_scipy(oracle, pitch):
-    """All 65,536 binary 4x4 patterns in one image (apart, and packed edge to edge), SciPy as the witness: the oracle's labelling is
-    the same partition with exact statistics, its contour lists hold one outer border per 8-connected component and one hole border
-    per 4-connected background region that does not reach the frame, and its rectangle / cross morphology is SciPy's."""
-    m = _all_4x4_patterns(pitch)
+def _check_labelling_against_scipy(oracle, m):
+    """Labels, statistics, centroids and the numbering of both scans against SciPy's labelling and plain array operations."""
     ref, nref = ndi.label(m, structure=np.ones((3, 3)))
     for block in (1, 2):
         n, lab, st, ce = oracle.ccl(m, block)
         assert n == nref + 1
-        pairs = np.unique(np.stack([lab.ravel(), ref.ravel()]), axis=1)
-        assert pairs.shape[1] == n                                        # one-to-one: the same partition
+        a, b = lab.ravel(), ref.ravel()                                   # one-to-one in both directions: the same partition
+        fwd, back = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        fwd[a] = b
+        back[b] = a
+        assert np.array_equal(fwd[a], b) and np.array_equal(back[b], a)
         area = np.bincount(lab.ravel(), minlength=n)
         assert np.array_equal(st[1:, 4], area[1:])
         # numbering, stated without the scan: components in the order of their first 2x2 block in block-raster order (two foreground
@@ -507,9 +506,18 @@ def test_every_4x4_pattern_against_scipy(oracle, pitch):
         np.maximum.at(hi_x, lab[yy, xx], xx); np.maximum.at(hi_y, lab[yy, xx], yy)
         assert np.array_equal(st[1:, 0], lo_x[1:]) and np.array_equal(st[1:, 1], lo_y[1:])
         assert np.array_equal(st[1:, 2], (hi_x - lo_x + 1)[1:]) and np.array_equal(st[1:, 3], (hi_y - lo_y + 1)[1:])
-        ys, xs = np.nonzero(lab)
-        l = lab[ys, xs]
-        assert np.array_equal(ce[1:, 0], (np.bincount(l, xs, n) / np.maximum(area, 1))[1:]) and np.array_equal(ce[1:, 1], (np.bincount(l, ys, n) / np.maximum(area, 1))[1:])
+        l = lab[yy, xx]
+        assert np.array_equal(ce[1:, 0], (np.bincount(l, xx, n) / np.maximum(area, 1))[1:]) and np.array_equal(ce[1:, 1], (np.bincount(l, yy, n) / np.maximum(area, 1))[1:])
+    return ref, nref
+
+
+@pytest.mark.parametrize("pitch", [5, 4])
+def test_every_4x4_pattern_against_scipy(oracle, pitch):
+    """All 65,536 binary 4x4 patterns in one image (apart, and packed edge to edge), SciPy as the witness: the oracle's labelling is
+    the same partition with exact statistics, its contour lists hold one outer border per 8-connected component and one hole border
+    per 4-connected background region that does not reach the frame, and its rectangle / cross morphology is SciPy's."""
+    m = _all_4x4_patterns(pitch)
+    ref, nref = _check_labelling_against_scipy(oracle, m)
     bg, nbg = ndi.label(m == 0, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
     touching = np.unique(np.concatenate([bg[0], bg[-1], bg[:, 0], bg[:, -1]]))
     holes = nbg - len(touching[touching > 0])
@@ -554,3 +562,15 @@ def test_every_4x4_pattern_against_scipy(oracle, pitch):
         assert np.array_equal(oracle.morph(oracle.ERODE, m, k) > 0, ndi.binary_erosion(m > 0, structure=k, border_value=1))
         assert np.array_equal(oracle.morph(oracle.DILATE, m, k) > 0,
                               ndi.binary_dilation(m > 0, structure=k, border_value=0, origin=tuple(-1 if s % 2 == 0 else 0 for s in k.shape)))
+
+
+def test_labelling_of_full_frames_against_scipy(oracle):
+    """1080p: the threshold mask of an S1 frame (blobs + salt), the same after OPEN / CLOSE, uniform noise at 50 %."""
+    img = F.s1_buoy(0)
+    th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(img)[:, :, 1]), 150, 255)
+    k = np.ones((5, 5), np.uint8)
+    masks = [th, oracle.morph(oracle.CLOSE, oracle.morph(oracle.OPEN, th, k), k)]
+    g = F.s3_noise(1)[:, :, 0]
+    masks += [oracle.inrange(np.ascontiguousarray(g), 128, 255)]
+    for m in masks:
+        _check_labelling_against_scipy(oracle, m)
