@@ -511,20 +511,16 @@ def _check_labelling_against_scipy(oracle, m):
     return ref, nref
 
 
-@pytest.mark.parametrize("pitch", [5, 4])
-def test_every_4x4_pattern_against_scipy(oracle, pitch):
-    """All 65,536 binary 4x4 patterns in one image (apart, and packed edge to edge), SciPy as the witness: the oracle's labelling is
-    the same partition with exact statistics, its contour lists hold one outer border per 8-connected component and one hole border
-    per 4-connected background region that does not reach the frame, and its rectangle / cross morphology is SciPy's."""
-    m = _all_4x4_patterns(pitch)
-    ref, nref = _check_labelling_against_scipy(oracle, m)
+def _check_contours_against_scipy(oracle, m, ref, nref, apart):
+    """Contour lists against statements that need no tracing: counts from SciPy's labellings of foreground and background, the union
+    of all border points, start pixels and list order, the SIMPLE lists as a filter of the full lists."""
     bg, nbg = ndi.label(m == 0, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
     touching = np.unique(np.concatenate([bg[0], bg[-1], bg[:, 0], bg[:, -1]]))
     holes = nbg - len(touching[touching > 0])
     cs, hole_flags = oracle.find_contours(m, 1, 1, with_holes=True)
     assert len(cs) == nref + holes and int(hole_flags.sum()) == holes
     outer = oracle.find_contours(m, 0, 1)
-    assert len(outer) <= nref and (pitch == 4 or len(outer) == nref)      # apart: no pattern lies inside another's hole
+    assert len(outer) <= nref and (not apart or len(outer) == nref)      # apart: no pattern lies inside another's hole
     # the points of all borders together (no approximation) are exactly the foreground pixels with a 4-neighbour in the background or
     # outside the frame - stated with array shifts, no tracing
     f = m > 0
@@ -556,6 +552,16 @@ def test_every_4x4_pattern_against_scipy(oracle, pitch):
         assert (m[p[:, 1], p[:, 0]] > 0).all()
         d = np.abs(np.diff(np.vstack([p, p[:1]]), axis=0))
         assert d.max(initial=0) <= 1
+
+
+@pytest.mark.parametrize("pitch", [5, 4])
+def test_every_4x4_pattern_against_scipy(oracle, pitch):
+    """All 65,536 binary 4x4 patterns in one image (apart, and packed edge to edge), SciPy as the witness: the oracle's labelling is
+    the same partition with exact statistics, its contour lists hold one outer border per 8-connected component and one hole border
+    per 4-connected background region that does not reach the frame, and its rectangle / cross morphology is SciPy's."""
+    m = _all_4x4_patterns(pitch)
+    ref, nref = _check_labelling_against_scipy(oracle, m)
+    _check_contours_against_scipy(oracle, m, ref, nref, apart=pitch == 5)
     for k in (np.ones((3, 3), np.uint8), np.ones((2, 3), np.uint8), np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)):
         # cv2 anchors a kernel at size // 2 for both operators; SciPy's erosion does the same, its dilation mirrors the structure
         # about that centre, which an even axis answers with origin -1
@@ -572,5 +578,12 @@ def test_labelling_of_full_frames_against_scipy(oracle):
     masks = [th, oracle.morph(oracle.CLOSE, oracle.morph(oracle.OPEN, th, k), k)]
     g = F.s3_noise(1)[:, :, 0]
     masks += [oracle.inrange(np.ascontiguousarray(g), 128, 255)]
-    for m in masks:
-        _check_labelling_against_scipy(oracle, m)
+    for i, m in enumerate(masks):
+        ref, nref = _check_labelling_against_scipy(oracle, m)
+        if i < 2:                                        # (the noise mask has 10^5 borders: its contour lists are checked at a smaller size below)
+            _check_contours_against_scipy(oracle, m, ref, nref, apart=False)
+    rng = np.random.default_rng(4)
+    for p in (0.1, 0.5, 0.9):
+        m = F.random_mask(rng, 200, 300, p)
+        ref, nref = ndi.label(m, structure=np.ones((3, 3)))
+        _check_contours_against_scipy(oracle, m, ref, nref, apart=False)
