@@ -46,7 +46,7 @@ def _all_colours(chunk=1 << 20):
         yield np.stack([v & 255, (v >> 8) & 255, v >> 16], axis=1).astype(np.uint8).reshape(1024, -1, 3)
 
 
-def test_lab_and_hsv_against_analytic_float64_all_colours(oracle):
+def test_conversions_against_analytic_float64_all_colours(oracle):
     """Every one of the 2^24 BGR triples against the textbook formulas in float64 (sRGB gamma, D65 XYZ, CIE L*a*b* scaled to 8 bits;
     hexcone HSV with H in half degrees).  HSV: the 8-bit result is the analytic value rounded (never further than 0.65 away).
     LAB: the 8-bit path quantises linear light to 1/2040 and the cube root to a table, which costs up to 2.7 levels in a / b for very
@@ -75,6 +75,17 @@ def test_lab_and_hsv_against_analytic_float64_all_colours(oracle):
         s_worst = max(s_worst, np.abs(hsv[..., 1] - sat).max())
         dh = np.abs(hsv[..., 0] - h)
         h_worst = max(h_worst, np.minimum(dh, 180 - dh).max())
+        # YCrCb (Y as grey; Cr / Cb from the rounded Y, hence up to 0.9 away) and HLS (the same hue; lightness and saturation rounded)
+        ycc = oracle.bgr2ycrcb(bgr).astype(np.float64)
+        yy = 0.299 * r + 0.587 * g + 0.114 * b
+        assert np.abs(ycc[..., 0] - yy).max() <= 0.51
+        assert np.abs(ycc[..., 1] - np.clip((r - yy) * 0.713 + 128, 0, 255)).max() <= 0.9 and np.abs(ycc[..., 2] - np.clip((b - yy) * 0.564 + 128, 0, 255)).max() <= 0.9
+        hls = oracle.bgr2hls(bgr).astype(np.float64)
+        hi, lo = v / 255, (v - d) / 255
+        sat_l = np.where(d > 0, np.where(hi + lo < 1, (hi - lo) / np.maximum(hi + lo, 1e-12), (hi - lo) / np.maximum(2 - hi - lo, 1e-12)), 0)
+        assert np.abs(hls[..., 1] - (hi + lo) / 2 * 255).max() <= 0.501 and np.abs(hls[..., 2] - sat_l * 255).max() <= 0.501
+        dh = np.abs(hls[..., 0] - h)
+        assert np.minimum(dh, 180 - dh).max() <= 0.7
     assert worst <= 3.0 and within1 / total > 0.998 and summed / total < 0.3, (worst, within1 / total, summed / total)
     assert s_worst <= 0.6 and h_worst <= 0.7, (s_worst, h_worst)
 
