@@ -34,16 +34,19 @@ class HandlerBase(ABC):
 
 
 class HandlerMixin:
+    """Gives a module a name -> handler table (reference core/handlers.py:77-99: `handlers`, `handler_names`; a name used twice is a
+    KeyError) and lends every handler the module's services."""
+
     def __init__(self, handlers: List[HandlerBase] = []):
-        self._handlers: Dict[str, HandlerBase] = {}
-        self._handler_names = set()
-        for handler in handlers:
-            self._handlers[handler.name] = handler
-            if handler.name in self._handler_names:
+        table: Dict[str, HandlerBase] = {}
+        for h in handlers:
+            if h.name in table:
                 raise KeyError("Duplicate handler names found!")
-            self._handler_names.add(handler.name)
-        for handler in self._handlers.values():
-            handler.register(self)
+            table[h.name] = h
+        self._handlers = table
+        self._handler_names = set(table)
+        for h in table.values():
+            h.register(self)
 
     @property
     def handlers(self):
