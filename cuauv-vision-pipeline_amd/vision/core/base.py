@@ -367,16 +367,16 @@ class ModuleBase:
     process(direction, image) — or the @sources-decorated handlers — on a worker thread, one frame at a time."""
 
     def __init__(self, video_sources: List[Union[VideoSource, str]] = [], tuners: List[TunerBase] = [], fps: int = 10, **kwargs):
-        parser = argparse.ArgumentParser(f"{__file__}", description="CLI to run this particular vision module",
+        parser = argparse.ArgumentParser(f"{__file__}", description="runs this vision module against its camera directions",
                                          formatter_class=argparse.RawTextHelpFormatter)
         parser.add_argument("-f", "--fps", type=int, default=fps,
-                            help="maximum fps to run (capped at speed of video sources) (recommended to specify a value <= 10)")
-        parser.add_argument("--verbose", action="store_true", help="display debug messages")
+                            help="upper bound on loop iterations per second (the sources set the real rate)")
+        parser.add_argument("--verbose", action="store_true", help="log what the loop is doing")
         parser.add_argument("--enable-performance", action="store_true",
-                            help="disable posting to help with performance during competition runs")
+                            help="post() becomes a no-op: nothing is copied or published for the GUI")
         parser.add_argument("sources", nargs="*", type=str,
-                            help="video sources as {name}[aliases]:<t1>:<t4>:<t8>, t1 in u8/i8, t4 in u32/i32/f32, t8 in u64/i64/f64;\n"
-                                 "defaults are used when empty.  Example: 'forward:f64', 'forward:i8:f32'")
+                            help="directions to read, each `name[alias,...]:<1-byte type>:<4-byte type>:<8-byte type>` with types from u8 i8 / u32 i32 f32 /\n"
+                                 "u64 i64 f64 (e.g. forward, zed[forward,depth]:f32); none given: the module's own list")
         args = parser.parse_args()
         if "_" in self.__class__.__name__:
             raise RuntimeError(f"Class name '{self.__class__.__name__}'cannot have an underscore")
