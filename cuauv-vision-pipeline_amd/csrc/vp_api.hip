@@ -1063,6 +1063,54 @@ int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, int 
     return vpk_inrange_u8(ctx, d_src, src_stride, w, h, cn, q, d_dst);
 }
 
+// The polylines of vp_draw_polylines_u8 drawn into a packed device image (bins.py draws its rectangles into an overlay that only ever
+// leaves the device when it is posted).  Points and counts are host arrays; the same pixels as the host rasteriser.
+int vp_draw_polylines_dev(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* pts, const int32_t* counts, int npolys, int closed,
+                          const uint8_t* color, int thickness)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!d_img || !pts || !counts || !color || w <= 0 || h <= 0 || cn < 1 || cn > 4 || npolys < 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_draw_polylines_dev arguments");
+    if (thickness < 1) thickness = 1;
+    if (thickness > 255) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "vp_draw_polylines_dev: thickness");
+    // brush centres: every Bresenham step of every segment whose stamp can reach the image (consecutive repeats dropped)
+    std::vector<int32_t> cen;
+    auto line = [&](int x0, int y0, int x1, int y1) {
+        const int dx = abs(x1 - x0), dy = -abs(y1 - y0);
+        const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+        long long err = (long long)dx + dy;
+        for (;;) {
+            if (x0 + thickness > 0 && x0 - thickness < w && y0 + thickness > 0 && y0 - thickness < h) {
+                const size_t n = cen.size();
+                if (n < 2 || cen[n - 2] != x0 || cen[n - 1] != y0) { cen.push_back(x0); cen.push_back(y0); }
+            }
+            if (x0 == x1 && y0 == y1) break;
+            const long long e2 = 2 * err;
+            if (e2 >= dy) { err += dy; x0 += sx; }
+            if (e2 <= dx) { err += dx; y0 += sy; }
+        }
+    };
+    size_t o = 0;
+    for (int k = 0; k < npolys; k++) {
+        const int npts = counts[k];
+        if (npts < 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_draw_polylines_dev: counts");
+        const int32_t* p = pts + 2 * o;
+        o += (size_t)npts;
+        if (npts == 0) continue;
+        if (npts == 1) { line(p[0], p[1], p[0], p[1]); continue; }
+        const int last = closed ? npts : npts - 1;
+        for (int i = 0; i < last; i++) {
+            const int j = i + 1 < npts ? i + 1 : 0;
+            line(p[2 * i], p[2 * i + 1], p[2 * j], p[2 * j + 1]);
+        }
+    }
+    const int ncen = (int)(cen.size() / 2);
+    if (ncen == 0) return VP_OK;
+    VP_TRY(vp_ws_reserve(ctx, vp_align(cen.size() * 4) + 4096));
+    TAKE(d_cen, int32_t*, cen.size() * 4);
+    VP_TRY(h2d(ctx, d_cen, cen.data(), cen.size() * 4));     // pageable source: staged by the runtime before the call returns
+    return vpk_draw_stamps(ctx, d_img, w, h, cn, d_cen, ncen, thickness, color);
+}
+
 // cv2.addWeighted on two device images of n bytes each (modules/bins.py:20: the mask overlay); d_dst may be one of the sources
 int vp_add_weighted_u8_dev(vp_ctx* ctx, const uint8_t* d_a, double alpha, const uint8_t* d_b, double beta, double gamma, size_t n, uint8_t* d_dst)
 {

@@ -536,6 +536,38 @@ __global__ __launch_bounds__(256) void k_add_weighted_u8(const uint8_t* __restri
     }
 }
 
+// Overlay drawing into a device image: the host has walked the Bresenham steps of the polylines (the statement sequence of the host
+// rasteriser, vp_draw_polylines_u8 / vision/utils/draw.py _line) and hands over the brush centres; one thread per (centre, brush pixel)
+// writes the colour.  Stamps overlap freely: everything is written in one colour.
+__global__ __launch_bounds__(256) void k_draw_stamps(uint8_t* __restrict__ img, int w, int h, int cn, const int2* __restrict__ centre, int ncentres,
+                                                    int thickness, uchar4 color)
+{
+    const int t2 = thickness * thickness;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)ncentres * t2) return;
+    const int ci = (int)(i / t2), bi = (int)(i - (long long)ci * t2);
+    const int2 c = centre[ci];
+    const int r0 = (thickness - 1) / 2;
+    const int px = c.x - r0 + bi % thickness, py = c.y - r0 + bi / thickness;
+    if (px < 0 || px >= w || py < 0 || py >= h) return;
+    uint8_t* q = img + ((size_t)py * w + px) * cn;
+    q[0] = color.x;
+    if (cn > 1) q[1] = color.y;
+    if (cn > 2) q[2] = color.z;
+    if (cn > 3) q[3] = color.w;
+}
+
+int vpk_draw_stamps(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* d_centres, int ncentres, int thickness, const uint8_t* color)
+{
+    if (ncentres <= 0) return VP_OK;
+    const uchar4 c = make_uchar4(color[0], cn > 1 ? color[1] : 0, cn > 2 ? color[2] : 0, cn > 3 ? color[3] : 0);
+    const long long total = (long long)ncentres * thickness * thickness;
+    hipLaunchKernelGGL(k_draw_stamps, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_img, w, h, cn, reinterpret_cast<const int2*>(d_centres),
+                       ncentres, thickness, c);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
+}
+
 int vpk_add_weighted_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double alpha, double beta, double gamma, uint8_t* dst)
 {
     hipLaunchKernelGGL(k_add_weighted_u8, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, ctx->stream, a, b, n, alpha, beta, gamma, dst);

@@ -124,6 +124,36 @@ def _native_polylines(mat, polys, closed, color, thickness):
                                     len(polys), int(bool(closed)), col.ctypes.data, int(thickness)) == 0
 
 
+def _device_polylines(mat, polys, closed, color, thickness):
+    """The same polylines drawn by the device into an image that lives there and has no host copy (libvp vp_draw_polylines_dev):
+    returns False when the image is not of that kind - then it is drawn on the host, as before."""
+    from vision.devmat import DeviceMat
+    if not isinstance(mat, DeviceMat) or mat.dtype != np.uint8 or mat.ndim not in (2, 3) or mat._host is not None or thickness > 255:
+        return False
+    from vision import _vp
+    ctx = _vp.default_context()
+    cn = 1 if mat.ndim == 2 else mat.shape[2]
+    if cn > 4 or not mat.device_valid_for(ctx):
+        return False
+    flat = getattr(polys, "_flat", None)
+    if flat is not None:
+        if len(polys) == 0:
+            return True
+        counts, p32 = polys._counts, flat
+    else:
+        polys = [np.asarray(p).reshape(-1, 2) for p in polys]
+        if not polys:
+            return True
+        counts = np.fromiter((len(p) for p in polys), np.int32, len(polys))
+        p32 = np.ascontiguousarray(np.concatenate(polys) if len(polys) > 1 else polys[0], np.int32)
+    col = np.zeros(4, np.uint8)
+    col[:cn] = np.asarray(color, np.uint8).ravel()[:cn] if np.ndim(color) else np.uint8(color)
+    _vp.check(_vp.lib().vp_draw_polylines_dev(ctx.handle, mat.dev_ptr, mat.shape[1], mat.shape[0], cn, p32.ctypes.data, counts.ctypes.data, len(counts),
+                                              int(bool(closed)), col.ctypes.data, int(thickness)), ctx.handle)
+    mat.binary = False
+    return True
+
+
 def _native_polyline(mat, pts, closed, color, thickness):
     return _native_polylines(mat, [pts], closed, color, thickness)
 
@@ -131,10 +161,12 @@ def _native_polyline(mat, pts, closed, color, thickness):
 def draw_polylines(mat: np.ndarray, points, isClosed: bool = False, color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
     """utils/draw.py:304-327; modifies `mat` in place."""
     from vision.devmat import to_host
-    mat = to_host(mat)
     pts = np.asarray(points, np.int64).reshape(-1, 2)
     if len(pts) == 0:
         return
+    if thickness >= 0 and _device_polylines(mat, [pts], isClosed, color, max(thickness, 1)):
+        return
+    mat = to_host(mat)
     if thickness >= 0 and _native_polyline(mat, pts, isClosed, color, max(thickness, 1)):
         return
     color = np.asarray(color, mat.dtype)[: (mat.shape[2] if mat.ndim == 3 else 1)]
@@ -153,6 +185,8 @@ def draw_polylines(mat: np.ndarray, points, isClosed: bool = False, color: Tuple
 def draw_contours(mat: np.ndarray, contours: List[np.ndarray], color: Tuple[int, int, int] = (0, 0, 255), thickness: int = 1) -> None:
     """utils/draw.py:283-301 (cv2.drawContours(mat, contours, -1, color, thickness)); modifies `mat` in place."""
     from vision.devmat import to_host
+    if thickness >= 0 and _device_polylines(mat, contours, True, color, max(thickness, 1)):
+        return
     mat = to_host(mat)
     if thickness >= 0 and _native_polylines(mat, contours, True, color, max(thickness, 1)):
         return

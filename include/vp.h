@@ -195,6 +195,10 @@ int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, in
                       uint8_t* dst_dev);
 int vp_morph_u8_dev(vp_ctx* ctx, int op, const uint8_t* src_dev, int w, int h, int cn, const uint8_t* kernel, int kw, int kh,
                     int anchor_x, int anchor_y, int iterations, int binary_hint, uint8_t* dst_dev);
+/* vp_draw_polylines_u8 into a packed device image (points and counts are host arrays): the same pixels, written by the device, so
+ * that an overlay which is only posted (modules/bins.py:20-79) never has to visit the host. */
+int vp_draw_polylines_dev(vp_ctx* ctx, uint8_t* img_dev, int w, int h, int cn, const int32_t* pts, const int32_t* counts, int npolys,
+                          int closed, const uint8_t* color, int thickness);
 /* cv2.addWeighted(a, alpha, b, beta, gamma) on two device images of n bytes (modules/bins.py:20, the mask overlay):
  * saturate(round-half-even(a*alpha + b*beta + gamma)) in correctly rounded doubles; dst may be one of the sources. */
 int vp_add_weighted_u8_dev(vp_ctx* ctx, const uint8_t* a_dev, double alpha, const uint8_t* b_dev, double beta, double gamma, size_t n,

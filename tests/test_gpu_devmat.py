@@ -303,3 +303,51 @@ def test_frames_read_straight_into_page_locked_memory(vp):
         from vision.utils.color import bgr_to_gray
         g, _ = bgr_to_gray(one)
         assert np.asarray(g).shape == (200, 320)
+
+
+def test_overlays_drawn_on_the_device(vp):
+    """draw_contours / drawContours / draw_polylines into an image that lives on the device and has no host copy: drawn there (nothing
+    is downloaded), with the pixels of the host rasteriser - contours, open polylines, thick brushes, points outside the image, one- and
+    four-channel images; an image with a host copy is drawn on the host as before."""
+    from vision import cv2_facade as cv2
+    from vision import devmat
+    from vision.utils import draw as D
+    from vision.utils.color import gray_to_bgr, range_threshold
+    rng = np.random.default_rng(12)
+    img = F.s2_bins(0, 333, 201)
+    polys = [np.array([[10, 10], [300, 20], [320, 190], [5, 150]], np.int32).reshape(-1, 1, 2), np.array([[-40, 100], [400, 120]], np.int32).reshape(-1, 1, 2),
+             rng.integers(-20, 350, (12, 1, 2)).astype(np.int32), np.array([[[150, 100]]], np.int32)]
+    for thickness in (1, 2, 4, 9, 17):
+        for closed in (True, False):
+            over = cv2.addWeighted(img, 0.5, img, 0.5, 0)                   # a device image (pending, then computed by the draw)
+            assert isinstance(over, devmat.DeviceMat)
+            for p in polys:
+                D.draw_polylines(over, p, closed, (0, 255, 0), thickness)
+            assert over._host is None, "the overlay was downloaded for drawing"
+            ref = img.copy()
+            for p in polys:
+                D.draw_polylines(ref, p, closed, (0, 255, 0), thickness)
+            assert np.array_equal(over, ref), (thickness, closed)
+    # bins.py: cv2.drawContours(overlayed, [box_points], 0, (0, 255, 0), 4) for every rectangle
+    over = cv2.addWeighted(img, 0.7, img, 0.3, 0)
+    ref = np.asarray(cv2.addWeighted(img, 0.7, img, 0.3, 0)).copy()
+    boxes = [np.intp(cv2.boxPoints(((100.0 + 30 * i, 90.0), (60.0, 30.0), 20.0 * i + 5))) for i in range(5)]
+    for b in boxes:
+        assert cv2.drawContours(over, [b], 0, (0, 255, 0), 4) is over
+        cv2.drawContours(ref, [b], 0, (0, 255, 0), 4)
+    assert over._host is None and np.array_equal(over, ref)
+    # one channel (a mask) and the contour tuple of find_contours
+    g = np.ascontiguousarray(img[:, :, 1])
+    m = range_threshold(g, 60, 200)
+    from vision.utils.feature import outer_contours
+    cs = outer_contours(m)
+    m2 = range_threshold(g, 60, 200)
+    D.draw_contours(m2, cs, 128, 3)
+    ref = np.asarray(range_threshold(g, 60, 200)).copy()
+    D.draw_contours(ref, cs, 128, 3)
+    assert m2._host is None and not m2.binary and np.array_equal(m2, ref)
+    # an image whose host copy exists is drawn on the host
+    vis = gray_to_bgr(g)[0]
+    h = np.asarray(vis)
+    D.draw_contours(vis, cs, (1, 2, 3), 2)
+    assert vis._host is not None and (h == np.asarray(vis)).all() and (np.asarray(vis)[..., 0] == 1).any()

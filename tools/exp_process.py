@@ -245,5 +245,5 @@ for rep in range(40):
     cs = st("outer_contours", lambda: _outer(cl))
     rects = st("minAreaRect x contours", lambda: [cv2.minAreaRect(c) for c in cs])
     boxes = st("boxPoints + np.intp", lambda: [np.intp(cv2.boxPoints(r)) for r in rects])
-    st("drawContours x rectangles (first one downloads the overlay)", lambda: [cv2.drawContours(over, [b], 0, (0, 255, 0), 4) for b in boxes])
+    st("drawContours x rectangles (into the overlay, on the device)", lambda: [cv2.drawContours(over, [b], 0, (0, 255, 0), 4) for b in boxes])
 print("bins body, per statement, host time inside a call, ms:", {k: round(1e3 * v / 40, 3) for k, v in hb.items()}, "sum", round(1e3 * sum(hb.values()) / 40, 3))
