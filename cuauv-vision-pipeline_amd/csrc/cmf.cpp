@@ -220,6 +220,30 @@ std::unique_ptr<Block> attach(const std::string& direction, bool creator, size_t
     return b;
 }
 
+// Copies the metadata of slot `s` (frame number `uid`) into the caller's Frame; returns the payload size, clamped to the entry size
+// (metadata read while the writer is at work can be torn: the sequence numbers decide afterwards whether they are kept).
+size_t snapshot_meta(const ShmHeader* h, const ShmSlot& s, uint64_t uid, Frame* frame)
+{
+    ShmSlot meta;
+    racy_read(reinterpret_cast<unsigned char*>(&meta) + kSlotMetaOffset, reinterpret_cast<const unsigned char*>(&s) + kSlotMetaOffset,
+              sizeof(ShmSlot) - kSlotMetaOffset);
+    frame->width = meta.width; frame->height = meta.height; frame->depth = meta.depth; frame->type_size = meta.type_size;
+    frame->acquisition_time = meta.acquisition_time;
+    frame->uid = uid;
+    size_t total = meta.total_size;
+    if (total > h->max_entry_size_bytes) total = h->max_entry_size_bytes;
+    frame->total_size = total;
+    frame->plane_count = (size_t)meta.plane_count <= CMF_MAX_PLANE_CNT ? (size_t)meta.plane_count : 0;
+    for (size_t i = 0; i < CMF_MAX_PLANE_CNT; i++) {
+        const ShmPlane& m = meta.planes[i];
+        FramePlane& o = frame->planes[i];
+        o.width = m.width; o.height = m.height; o.depth = m.depth; o.type_size = m.type_size; o.offset = m.offset;
+        memcpy(o.name, m.name, CMF_PLANE_NAME_MAX_LEN);
+        o.name[CMF_PLANE_NAME_MAX_LEN - 1] = '\0';
+    }
+    return total;
+}
+
 }  // namespace
 
 extern "C" {
@@ -371,29 +395,50 @@ int read_frame(Block* block, Frame* frame, bool block_thread)
         const uint64_t uid = load_acq(&h->uid);
         const ShmSlot& s = h->slots[uid % CMF_BUFFER_CNT];
         const uint64_t end = load_acq(&s.seq_end);
-        ShmSlot meta;
-        racy_read(reinterpret_cast<unsigned char*>(&meta) + kSlotMetaOffset, reinterpret_cast<const unsigned char*>(&s) + kSlotMetaOffset,
-                  sizeof(ShmSlot) - kSlotMetaOffset);
-        frame->width = meta.width; frame->height = meta.height; frame->depth = meta.depth; frame->type_size = meta.type_size;
-        frame->acquisition_time = meta.acquisition_time;
-        frame->uid = uid;
-        size_t total = meta.total_size;
-        if (total > h->max_entry_size_bytes) total = h->max_entry_size_bytes;   // torn metadata: retry below
-        frame->total_size = total;
-        frame->plane_count = (size_t)meta.plane_count <= CMF_MAX_PLANE_CNT ? (size_t)meta.plane_count : 0;
-        for (size_t i = 0; i < CMF_MAX_PLANE_CNT; i++) {
-            const ShmPlane& m = meta.planes[i];
-            FramePlane& o = frame->planes[i];
-            o.width = m.width; o.height = m.height; o.depth = m.depth; o.type_size = m.type_size; o.offset = m.offset;
-            memcpy(o.name, m.name, CMF_PLANE_NAME_MAX_LEN);
-            o.name[CMF_PLANE_NAME_MAX_LEN - 1] = '\0';
-        }
+        const size_t total = snapshot_meta(h, s, uid, frame);
         racy_read(frame->data, h->payload + (uid % CMF_BUFFER_CNT) * h->max_entry_size_bytes, total);
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
         const uint64_t begin = load_acq(&s.seq_begin);
         if (begin == end) return SUCCESS;
         if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
     }
+}
+
+int cmf_peek_frame(Block* block, Frame* frame, const void** payload, uint64_t* ticket)
+{
+    if (!block || !block->shm || !frame || !payload || !ticket) { set_err("null block, frame, payload or ticket"); return CMF_ERR_INVALID; }
+    ShmHeader* h = block->shm;
+    if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    if (frame->uid >= load_acq(&h->uid)) return NO_NEW_FRAME;
+    for (;;) {
+        const uint64_t uid = load_acq(&h->uid);
+        const ShmSlot& s = h->slots[uid % CMF_BUFFER_CNT];
+        const uint64_t end = load_acq(&s.seq_end);
+        snapshot_meta(h, s, uid, frame);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        if (load_acq(&s.seq_begin) == end) {               // the metadata are those of a complete frame
+            *payload = h->payload + (uid % CMF_BUFFER_CNT) * h->max_entry_size_bytes;
+            *ticket = end;
+            return SUCCESS;
+        }
+        if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    }
+}
+
+int cmf_peek_validate(Block* block, uint64_t uid, uint64_t ticket)
+{
+    if (!block || !block->shm) { set_err("null block"); return CMF_ERR_INVALID; }
+    const ShmSlot& s = block->shm->slots[uid % CMF_BUFFER_CNT];
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);               // the caller's copy of the payload comes before this load
+    return load_acq(&s.seq_begin) == ticket ? 1 : 0;
+}
+
+int cmf_block_mapping(Block* block, void** base, uint64_t* bytes)
+{
+    if (!block || !block->shm || !base || !bytes) { set_err("null block or result pointer"); return CMF_ERR_INVALID; }
+    *base = block->shm;
+    *bytes = (uint64_t)block->mapped;
+    return 0;
 }
 
 Frame* create_frame(void)

@@ -102,7 +102,7 @@ vp_ctx* vp_create(int device)
     static const int32_t expectC[9] = {1777, 1541, 778, 871, 2929, 296, 73, 448, 3575};
     if (memcmp(labC, expectC, sizeof labC) != 0) { vp_fail(nullptr, VP_ERR_INVALID, "Lab coefficient table mismatch"); delete ctx; return nullptr; }
     const size_t bytes = 512 + 4096 + 1024 + 1024;
-    if ((e = hipMalloc(&ctx->d_tables, bytes)) != hipSuccess) { vp_fail(nullptr, VP_ERR_NOMEM, "hipMalloc tables", e); delete ctx; return nullptr; }
+    if ((e = hipMalloc(&ctx->d_tables, bytes + 256)) != hipSuccess) { vp_fail(nullptr, VP_ERR_NOMEM, "hipMalloc tables", e); delete ctx; return nullptr; }
     uint8_t* base = (uint8_t*)ctx->d_tables;
     hipMemcpy(base, gamma.data(), 512, hipMemcpyHostToDevice);
     hipMemcpy(base + 512, cbrt.data(), 4096, hipMemcpyHostToDevice);
@@ -113,6 +113,8 @@ vp_ctx* vp_create(int device)
     ctx->tab.cbrt = (const uint16_t*)(base + 512);
     ctx->tab.sdiv = (const int32_t*)(base + 512 + 4096);
     ctx->tab.hdiv = (const int32_t*)(base + 512 + 4096 + 1024);
+    ctx->cb_folds_own = (u32*)(base + bytes);       // a word of the context's own: workspace pointers do not survive a later call
+    hipMemset(ctx->cb_folds_own, 0, 4);
     return ctx;
 }
 
@@ -229,7 +231,7 @@ int vp_dev_alloc(vp_ctx* ctx, size_t bytes, void** p)
 }
 int vp_dev_free(vp_ctx* ctx, void* p)
 {
-    if (!ctx) return VP_ERR_INVALID;
+    if (!ctx) return hipFree(p) == hipSuccess ? VP_OK : VP_ERR_HIP;   // device memory outlives the context it was allocated through
     VP_HIP(ctx, hipFree(p));
     return VP_OK;
 }
@@ -245,6 +247,24 @@ int vp_host_free(vp_ctx* ctx, void* p)
 {
     if (!ctx) return hipHostFree(p) == hipSuccess ? VP_OK : VP_ERR_HIP;   // page-locked memory is not tied to a context
     VP_HIP(ctx, hipHostFree(p));
+    return VP_OK;
+}
+int vp_host_register(vp_ctx* ctx, void* p, size_t bytes)
+{
+    if (!ctx || !p || !bytes) return VP_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();                       // a refusal is an answer, not a fault of the context
+        snprintf(ctx->err, sizeof ctx->err, "hipHostRegister refused %zu bytes: %s", bytes, hipGetErrorString(e));
+        return VP_ERR_UNSUPPORTED;
+    }
+    return VP_OK;
+}
+int vp_host_unregister(vp_ctx* ctx, void* p)
+{
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctx ? vp_fail(ctx, VP_ERR_HIP, "hipHostUnregister", e) : VP_ERR_HIP; }
     return VP_OK;
 }
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst, const void* src, size_t bytes)

@@ -20,6 +20,7 @@
 // one of them could differ (a comparison within e of its boundary, a product gain * v within e of an integer: about one frame in
 // 10^5) three threads run the fold itself, in the reference's order, and the tables are built from its result.
 #include "vp_internal.h"
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 
@@ -705,14 +706,15 @@ int vpk_color_balance(vp_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, 
     double* powtab = nullptr;
     if (flags & VP_CB_ADAPTIVE_CAST) {
         static double host_tab[256];
-        static bool made = false;
-        if (!made) { for (int v = 0; v < 256; v++) host_tab[v] = pow((255. - v) / 255., 0.25); made = true; }
+        static std::once_flag made;                  // contexts are per thread: two of them may get here together
+        std::call_once(made, [] { for (int v = 0; v < 256; v++) host_tab[v] = pow((255. - v) / 255., 0.25); });
         powtab = (double*)vp_ws_take(ctx, sizeof host_tab);
         if (!powtab) return vp_fail(ctx, VP_ERR_NOMEM, "colour balance workspace");
         VP_HIP(ctx, hipMemcpyAsync(powtab, host_tab, sizeof host_tab, hipMemcpyHostToDevice, s));
     }
     hipLaunchKernelGGL(k_cb_plan1, dim3((unsigned)n), dim3(256), 0, s, P, hist, neq, d_src, plans, lut, folds, force_fold, (const double*)powtab);
-    ctx->cb_folds_dev = folds;
+    VP_HIP(ctx, hipMemcpyAsync(ctx->cb_folds_own, folds, 4, hipMemcpyDeviceToDevice, s));
+    ctx->cb_folds_dev = ctx->cb_folds_own;
     if (hsv) {
         VP_HIP(ctx, hipMemsetAsync(svhist, 0, (size_t)n * 512 * 4, s));
         if (tiled) hipLaunchKernelGGL((k_cb_hsvhist<true>), grid, dim3(256), 0, s, d_src, P, ctx->tab, lut, svhist);

@@ -44,7 +44,8 @@ struct vp_ctx {
     hipStream_t fb_stream;        // side stream of the labelling: the one-level kernels for crowded frames run here, beside the label write
     hipEvent_t ev_fb_fork, ev_fb_join;
     hipEvent_t ev_upload;         // recorded after an enqueued host-to-device copy (vp_memcpy_h2d_async / vp_wait_uploads)
-    const u32* cb_folds_dev;      // colour balance: device counter of tiles whose running mean had to be folded (last call)
+    const u32* cb_folds_dev;      // colour balance: device counter of tiles whose running mean had to be folded (last call); null or cb_folds_own
+    u32* cb_folds_own;            // context-owned device word the counter is copied to (the workspace it is made in is carved anew per call)
     int ccl_levels;               // 2: two-level labelling with the one-level kernels as fallback (default); 1: one-level only
     int ccl_mcap;                 // components per frame the merge block accepts (-1: its LDS capacity); tests lower it to force the fallback
     vp_prof prof;

@@ -122,6 +122,8 @@ _SIGS = {
     "vp_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vp_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vp_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vp_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vp_draw_polylines_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "vp_add_weighted_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_size_t, C.c_void_p]),

@@ -163,7 +163,7 @@ class ModuleManager:
                 self._tuner_sources[name].deserialize(frame.tobytes("C"))
         messages: List[VideoMessage] = []
         for name, accessor in self._video_accessor.items():
-            status, data, acquisition_time, private = accessor.read_frame_private()
+            status, data, acquisition_time, private = accessor.read_frame_device()
             if status == ReadStatus.FRAMEWORK_DELETED:
                 raise RuntimeError(f"{accessor.direction} was marked for deletion")
             if data is not None:

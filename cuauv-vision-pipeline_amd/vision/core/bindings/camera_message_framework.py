@@ -10,6 +10,7 @@ import ctypes as C
 import enum
 import os
 import sys
+import threading
 import time
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -63,11 +64,50 @@ def _load():
     lib.cmf_frame_set_buffer.argtypes = [C.POINTER(_Frame), C.c_void_p, C.c_uint64]
     lib.cmf_block_entry_size.restype = C.c_uint64
     lib.cmf_block_entry_size.argtypes = [C.c_void_p]
+    lib.cmf_peek_frame.restype = C.c_int
+    lib.cmf_peek_frame.argtypes = [C.c_void_p, C.POINTER(_Frame), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.cmf_peek_validate.restype = C.c_int
+    lib.cmf_peek_validate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    lib.cmf_block_mapping.restype = C.c_int
+    lib.cmf_block_mapping.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     return lib
 
 
 _dllib = _load()
 _PRIVATE_READS = os.environ.get("VP_PRIVATE_READS", "1") != "0"
+_DEVICE_FRAMES = os.environ.get("VP_DEVICE_FRAMES", "1") != "0"
+_registered = {}            # mapping base address -> [reference count, bytes]: block mappings page-locked for the copy engine
+_registered_lock = threading.Lock()
+_device_frames_broken = False   # no device / hipHostRegister refused shared-memory mappings: decided once per process
+
+
+def _register_mapping(ctx, base, nbytes):
+    """Page-locks a block's mapping once per process (blocks are shared between the accessors of a process)."""
+    from vision import _vp
+    with _registered_lock:
+        ent = _registered.get(base)
+        if ent is not None:
+            ent[0] += 1
+            return True
+        if _vp.lib().vp_host_register(ctx.handle, base, nbytes) != 0:
+            return False
+        _registered[base] = [1, nbytes]
+        return True
+
+
+def _unregister_mapping(base):
+    from vision import _vp
+    with _registered_lock:
+        ent = _registered.get(base)
+        if ent is None:
+            return
+        ent[0] -= 1
+        if ent[0] <= 0:
+            del _registered[base]
+            try:
+                _vp.lib().vp_host_unregister(None, base)
+            except Exception:
+                pass
 
 
 def _const_int(name):
@@ -272,7 +312,84 @@ class BlockAccessor:
                 raise RuntimeError(f"plane {idx} with size {nbytes} at offset {off} exceeds frame size {total}")
             planes.append(buf[off:off + nbytes].view(dtype).reshape(h, w, d))
             names.append(m.name.decode())
-        self._private_buf = None                               # handed over: the next read gets a buffer of its own
+        # handed over: the library must forget the buffer (a public read_frame() on this accessor would otherwise copy the next frame
+        # into memory the module owns - or, once the module dropped it, into whatever the pinned pool gave that memory to); the next
+        # private read installs a buffer of its own
+        _dllib.cmf_frame_set_buffer(self._frame_ptr, None, 0)
+        self._private_buf, self._private_installed = None, False
+        self._last_plane_names = tuple(names)
+        self._frame_data = planes[0] if count == 1 else tuple(planes)
+        return status, self._frame_data, self._acquisition_time, True
+
+    def _device_setup(self):
+        """-> the calling thread's device context once this block's mapping is page-locked for it, else None (then for good)."""
+        global _device_frames_broken
+        if not _DEVICE_FRAMES or _device_frames_broken or self._dev_state is False:
+            return None
+        try:
+            from vision import _vp
+            ctx = _vp.default_context()
+        except Exception:
+            _device_frames_broken = True                       # no device in this process: the copying paths serve
+            return None
+        if self._dev_state is None:
+            base, nbytes = C.c_void_p(), C.c_uint64()
+            ok = _dllib.cmf_block_mapping(self._block_ptr, C.byref(base), C.byref(nbytes)) == 0 and \
+                _register_mapping(ctx, base.value, int(nbytes.value))
+            if not ok:
+                self._dev_state = False
+                _device_frames_broken = True                   # the runtime refuses shared-memory mappings: do not ask again
+                return None
+            self._dev_state, self._dev_base = True, base.value
+        return ctx
+
+    def read_frame_device(self):
+        """read_frame_private whose arrays are device images (vision.devmat.DeviceMat: array-likes that reach host memory only when
+        Python looks at them): the newest frame goes from its ring slot to HBM in ONE copy made by the GPU's copy engine out of the
+        page-locked mapping - no seqlock memcpy (lib/camera_message_framework.cpp:421-452), no runtime copy (core/base.py:765-768), no
+        upload by the first operator.  The slot's sequence number is checked AFTER the copy; a copy the writer overtook is dropped and
+        the newer frame fetched.  All planes of a frame share one device allocation.  Falls back to read_frame_private when this
+        process has no device or the mapping cannot be page-locked."""
+        if not self._inside_ctx_manager:
+            raise RuntimeError(f"Attempted to access block while not in a context manager: {_caller_line()}")
+        ctx = self._device_setup()
+        if ctx is None:
+            return self.read_frame_private()
+        from vision import _vp
+        from vision.devmat import DeviceMat, _DevBuf
+        lib = _vp.lib()
+        payload, ticket = C.c_void_p(), C.c_uint64()
+        while True:
+            rc = _dllib.cmf_peek_frame(self._block_ptr, self._frame_ptr, C.byref(payload), C.byref(ticket))
+            if rc < 0:
+                raise RuntimeError(f"read_frame on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
+            status = ReadStatus(rc)
+            if status != ReadStatus.SUCCESS:
+                return status, self._frame_data, self._acquisition_time, True
+            fr = self._frame_ptr.contents
+            total, count = int(fr.total_size), int(fr.plane_count)
+            if count == 0 or total == 0:
+                self._acquisition_time = int(fr.acquisition_time)
+                self._frame_data, self._last_plane_names = None, tuple()
+                return status, None, self._acquisition_time, True
+            buf = _DevBuf(ctx, total)
+            _vp.check(lib.vp_memcpy_h2d_async(ctx.handle, buf.ptr, payload.value, total), ctx.handle)
+            _vp.check(lib.vp_wait_uploads(ctx.handle), ctx.handle)
+            if _dllib.cmf_peek_validate(self._block_ptr, fr.uid, ticket.value) == 1:
+                break
+            self.torn_reads += 1                                # lapped by the writer during the copy: a newer frame is there
+        self._acquisition_time = int(fr.acquisition_time)
+        planes, names = [], []
+        for idx in range(count):
+            m = fr.planes[idx]
+            w, h, d, item, off = int(m.width), int(m.height), int(m.depth), int(m.type_size), int(m.offset)
+            dtype = self._type_lookup.get(item)
+            if dtype is None:
+                raise RuntimeError(f"encountered unsupported type size {item} while reading plane {idx}")
+            if off + w * h * d * item > total:
+                raise RuntimeError(f"plane {idx} with size {w * h * d * item} at offset {off} exceeds frame size {total}")
+            planes.append(DeviceMat.over_buffer(ctx, buf, off, (h, w, d), dtype))
+            names.append(m.name.decode())
         self._last_plane_names = tuple(names)
         self._frame_data = planes[0] if count == 1 else tuple(planes)
         return status, self._frame_data, self._acquisition_time, True
@@ -299,10 +416,14 @@ class BlockAccessor:
         self._frame_ptr = _dllib.create_frame()
         self._acquisition_time, self._frame_data = 0, None
         self._private_buf, self._private_installed = None, False
+        self._dev_state, self._dev_base, self.torn_reads = None, None, 0
         self._inside_ctx_manager = True
         return self
 
     def __exit__(self, exc_type, exc_val, exc_tb):
+        if getattr(self, "_dev_state", None) and self._dev_base is not None:
+            _unregister_mapping(self._dev_base)                 # before the mapping can go away
+            self._dev_state, self._dev_base = None, None
         if self._block_ptr:
             _dllib.delete_block(self._block_ptr)
         if self._frame_ptr:

@@ -19,6 +19,7 @@ from vision.utils import transform as _transform
 
 COLOR_BGR2LAB, COLOR_BGR2HSV, COLOR_BGR2GRAY, COLOR_GRAY2BGR, COLOR_HSV2BGR = 44, 40, 6, 8, 54     # cv2's own enum values
 COLOR_BGR2YCrCb, COLOR_BGR2YCR_CB, COLOR_BGR2HLS = 36, 36, 52
+COLOR_BGR2Luv, COLOR_BGR2LUV = 50, 50     # named by modules/preprocessor.py:76; see DESIGN.md section 7 for what the stand-in does with it
 MORPH_RECT, MORPH_CROSS, MORPH_ELLIPSE = 0, 1, 2
 MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
 RETR_EXTERNAL, RETR_LIST = 0, 1
@@ -335,7 +336,7 @@ def addWeighted(src1, alpha, src2, beta, gamma, dst=None, dtype=-1):
 
         def run(out, da=da, db=db):
             _vp.check(_vp.lib().vp_add_weighted_u8_dev(ctx.handle, da.dev_ptr, fa, db.dev_ptr, fb, fg, n, out.dev_ptr), ctx.handle)
-        if defer_enabled():
+        if defer_enabled() and not (da.host_escaped or db.host_escaped):
             out = DeviceMat.deferred(ctx, da.shape, np.uint8, False, (da, db), run)
         else:
             out = DeviceMat(ctx, da.shape)

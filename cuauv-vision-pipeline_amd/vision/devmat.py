@@ -84,7 +84,8 @@ class _Pool:
     def give(self, ptr, cls):
         ctx = self.ctx()
         if ctx is None or not ctx.handle:
-            return                                   # the context is gone and took its device memory with it
+            _vp.lib().vp_dev_free(None, ptr)         # the context is gone; its device memory is not (plain hipMalloc): free it here
+            return
         with self.lock:
             if self.held + cls <= self.CAP_BYTES:
                 self.free.setdefault(cls, []).append(ptr)
@@ -129,18 +130,20 @@ class DeviceMat:
     """(h, w) or (h, w, c) image, tightly packed, whose authoritative copy may be on the device (`_dev_ok`), on the host
     (`_host` is not None and `_host_ok`), or both."""
     __array_priority__ = 100.0
-    __slots__ = ("_ctx", "_buf", "_shape", "_dtype", "_host", "_dev_ok", "binary", "_pending", "_consumers", "__weakref__")
+    __slots__ = ("_ctx", "_buf", "_off", "_shape", "_dtype", "_host", "_dev_ok", "_escaped", "binary", "_pending", "_consumers", "__weakref__")
 
     def __init__(self, ctx, shape, dtype=np.uint8, binary=False):
         self._ctx = ctx
         self._shape = tuple(int(s) for s in shape)
         self._dtype = np.dtype(dtype)
         self._buf = _DevBuf(ctx, int(np.prod(self._shape)) * self._dtype.itemsize)
+        self._off = 0                       # byte offset of this image inside its device allocation (planes of one frame share one)
         self._host = None
         self._dev_ok = True
+        self._escaped = False               # a writable alias of the host copy is out: the device copy can go stale without notice
         self.binary = bool(binary)          # known to hold only 0 / 255 (a mask made by this library)
         self._pending = None
-        self._consumers = None
+        self._consumers = []                # shared with every reshaped() alias: pending operators that read this image
 
     @classmethod
     def deferred(cls, ctx, shape, dtype, binary, inputs, run):
@@ -149,14 +152,21 @@ class DeviceMat:
         handed to the host for writing - so the result is always the one an immediate launch would have given."""
         m = object.__new__(cls)
         m._ctx, m._shape, m._dtype = ctx, tuple(int(s) for s in shape), np.dtype(dtype)
-        m._buf, m._host, m._dev_ok, m.binary, m._consumers = None, None, True, bool(binary), None
+        m._buf, m._off, m._host, m._dev_ok, m._escaped, m.binary, m._consumers = None, 0, None, True, False, bool(binary), []
         m._pending = run
         for x in inputs:
-            if x._consumers is None:
-                x._consumers = []
-            elif len(x._consumers) > 8:
-                x._consumers = [r for r in x._consumers if (c := r()) is not None and c._pending is not None]
+            if len(x._consumers) > 8:
+                x._consumers[:] = [r for r in x._consumers if (c := r()) is not None and c._pending is not None]
             x._consumers.append(weakref.ref(m))
+        return m
+
+    @classmethod
+    def over_buffer(cls, ctx, buf, offset, shape, dtype):
+        """An image at `offset` bytes inside device allocation `buf` (a _DevBuf the images share): the planes of one frame that was
+        moved out of its ring slot with one copy (vision.core.bindings.camera_message_framework.BlockAccessor.read_frame_device)."""
+        m = object.__new__(cls)
+        m._ctx, m._shape, m._dtype = ctx, tuple(int(s) for s in shape), np.dtype(dtype)
+        m._buf, m._off, m._host, m._dev_ok, m._escaped, m.binary, m._consumers, m._pending = buf, int(offset), None, True, False, False, [], None
         return m
 
     def _force(self):
@@ -168,12 +178,14 @@ class DeviceMat:
             self._buf = _DevBuf(self._ctx, int(np.prod(self._shape)) * self._dtype.itemsize)
             run(self)
 
-    def _before_host_write(self):
-        """Pending operators that read this image run before its contents can change."""
+    def _before_write(self):
+        """Pending operators that read this image run before its contents can change (host-side writes and in-place device writes
+        alike; the list is shared by every reshaped() alias of the image)."""
         cs = self._consumers
         if cs:
-            self._consumers = None
-            for r in cs:
+            pending = cs[:]
+            del cs[:]
+            for r in pending:
                 c = r()
                 if c is not None:
                     c._force()
@@ -183,7 +195,12 @@ class DeviceMat:
     def dev_ptr(self):
         if self._pending is not None:
             self._force()
-        return self._buf.ptr
+        return self._buf.ptr + self._off
+
+    @property
+    def host_escaped(self):
+        """A writable alias of the host copy has been handed out: writes through it are invisible to this object."""
+        return self._escaped
 
     def device_valid_for(self, ctx):
         return self._dev_ok and ctx is self._ctx and bool(ctx.handle)
@@ -207,29 +224,34 @@ class DeviceMat:
         """Same data under another shape (e.g. (h, w, 1) -> (h, w)); shares the device buffer, copies nothing."""
         self._force()
         m = object.__new__(DeviceMat)
-        m._ctx, m._buf, m._dtype, m._dev_ok, m.binary = self._ctx, self._buf, self._dtype, self._dev_ok, self.binary
-        m._pending, m._consumers = None, self._consumers
+        m._ctx, m._buf, m._off, m._dtype, m._dev_ok, m.binary = self._ctx, self._buf, self._off, self._dtype, self._dev_ok, self.binary
+        m._pending, m._consumers, m._escaped = None, self._consumers, self._escaped
         m._shape = tuple(int(x) for x in shape)
         m._host = None if self._host is None else self._host.reshape(m._shape)
         if not self._dev_ok and m._host is None:
             raise RuntimeError("image has neither a valid device nor a host copy")
         return m
 
-    def host(self, writable=True):
-        """The host copy (one D2H the first time).  Handing it out writable makes it the authoritative copy."""
+    def host(self, writable=True, escape=True):
+        """The host copy (one D2H the first time).  Handing it out writable makes it the authoritative copy.  escape=False: the caller
+        writes now and keeps no alias (item assignment, in-place operators, `out=`): the next operator uploads once and the device
+        copy is trusted again."""
         if self._pending is not None:
             self._force()
         if writable:
-            self._before_host_write()
+            self._before_write()
         if self._host is None:
             out = np.empty(self._shape, self._dtype)
             ctx = self._ctx
             if not ctx.handle:
                 raise _vp.VpError("the context that owns this image was closed before the image was read")
-            _vp.check(_vp.lib().vp_memcpy_d2h(ctx.handle, out.ctypes.data, self._buf.ptr, out.nbytes), ctx.handle)
+            _vp.check(_vp.lib().vp_memcpy_d2h(ctx.handle, out.ctypes.data, self._buf.ptr + self._off, out.nbytes), ctx.handle)
             self._host = out
         if writable:
+            # From here on the caller may hold an alias (a view, the array itself) and write through it at any later time without this
+            # object noticing: the device copy is never trusted again, every operator re-uploads the host data (refresh_device).
             self._dev_ok = False
+            self._escaped = self._escaped or escape
             self.binary = False
             return self._host
         v = self._host.view()
@@ -243,7 +265,7 @@ class DeviceMat:
             self._force()
         if self._dev_ok and self._host is None and self._ctx.handle:
             out = np.empty(self._shape, self._dtype)
-            _vp.check(_vp.lib().vp_memcpy_d2h(self._ctx.handle, out.ctypes.data, self._buf.ptr, out.nbytes), self._ctx.handle)
+            _vp.check(_vp.lib().vp_memcpy_d2h(self._ctx.handle, out.ctypes.data, self._buf.ptr + self._off, out.nbytes), self._ctx.handle)
             return out
         return self.host(writable=False).copy()
 
@@ -254,14 +276,15 @@ class DeviceMat:
                 return None                      # not launched yet: `dev_ptr` launches it, on this very context
             self._force()
         if self.device_valid_for(ctx):
-            return self._buf.ptr
+            return self._buf.ptr + self._off
         h = self.host(writable=False)
         if ctx is not self._ctx:
             self._ctx = ctx
             self._buf = _DevBuf(ctx, h.nbytes)
-        _vp.check(_vp.lib().vp_memcpy_h2d(ctx.handle, self._buf.ptr, h.ctypes.data, h.nbytes), ctx.handle)
-        self._dev_ok = True
-        return self._buf.ptr
+            self._off = 0
+        _vp.check(_vp.lib().vp_memcpy_h2d(ctx.handle, self._buf.ptr + self._off, h.ctypes.data, h.nbytes), ctx.handle)
+        self._dev_ok = not self._escaped     # with a writable alias out, the upload is good for this one operator only
+        return self._buf.ptr + self._off
 
     # ---- array protocol -----------------------------------------------------------------------------------------------------------
     shape = property(lambda self: self._shape)
@@ -285,7 +308,7 @@ class DeviceMat:
             return x.host(writable=w) if isinstance(x, DeviceMat) else x
         ins = tuple(conv(x, False) for x in inputs)
         if "out" in kwargs:
-            kwargs["out"] = tuple(conv(x, True) for x in kwargs["out"])
+            kwargs["out"] = tuple((x.host(writable=True, escape=False) if isinstance(x, DeviceMat) else x) for x in kwargs["out"])
         return getattr(ufunc, method)(*ins, **kwargs)
 
     def __array_function__(self, func, types, args, kwargs):
@@ -305,7 +328,7 @@ class DeviceMat:
     def __setitem__(self, key, value):
         if isinstance(value, DeviceMat):
             value = value.host(writable=False)
-        self.host(writable=True)[key] = value
+        self.host(writable=True, escape=False)[key] = value
 
     def __iter__(self):
         return iter(self.host(writable=True))
@@ -340,7 +363,7 @@ def _binop(name, ufunc, swap=False):
 
 def _iop(name, ufunc):
     def f(self, other):
-        h = self.host(writable=True)
+        h = self.host(writable=True, escape=False)
         ufunc(h, other.host(writable=False) if isinstance(other, DeviceMat) else other, out=h)
         return self
     f.__name__ = name

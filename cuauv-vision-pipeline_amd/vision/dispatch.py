@@ -198,16 +198,26 @@ class BatchDispatcher:
         bid = next(iter(self._pending))
         while len(self._pending[bid]) < len(self.devices):
             b, di, res, err = self._out.get()
-            if err is not None:
-                raise err
-            self._pending[b][di] = res
+            self._pending[b][di] = (res, err)          # a failure is an answer too: the batch completes, then raises
         got = self._pending.pop(bid)
-        return bid, [(self.slices[di][0], self.slices[di][1], got[di]) for di in range(len(self.devices))]
+        failed = [err for (_, err) in got.values() if err is not None]
+        if failed:
+            raise failed[0]                            # the batch is gone from the books: the next collect() serves the next batch
+        return bid, [(self.slices[di][0], self.slices[di][1], got[di][0]) for di in range(len(self.devices))]
 
     def close(self):
+        per_dev = len(self._threads) // max(1, len(self.devices))
         for di in range(len(self.devices)):
-            for _ in range(len(self._threads) // max(1, len(self.devices))):
-                self._in[di].put(None)
+            while True:                                # batches nobody will collect any more: make room for the stop marks
+                try:
+                    self._in[di].get_nowait()
+                except queue.Empty:
+                    break
+            for _ in range(per_dev):
+                try:
+                    self._in[di].put(None, timeout=2)  # (a feeder stuck in its runner never makes room: do not wait for ever)
+                except queue.Full:
+                    break
         for t in self._threads:
             t.join(timeout=10)
         self._threads = []

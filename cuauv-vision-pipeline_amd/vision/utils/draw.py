@@ -148,6 +148,7 @@ def _device_polylines(mat, polys, closed, color, thickness):
         p32 = np.ascontiguousarray(np.concatenate(polys) if len(polys) > 1 else polys[0], np.int32)
     col = np.zeros(4, np.uint8)
     col[:cn] = np.asarray(color, np.uint8).ravel()[:cn] if np.ndim(color) else np.uint8(color)
+    mat._before_write()                                  # operators that were deferred on this image read it as it is now
     _vp.check(_vp.lib().vp_draw_polylines_dev(ctx.handle, mat.dev_ptr, mat.shape[1], mat.shape[0], cn, p32.ctypes.data, counts.ctypes.data, len(counts),
                                               int(bool(closed)), col.ctypes.data, int(thickness)), ctx.handle)
     mat.binary = False

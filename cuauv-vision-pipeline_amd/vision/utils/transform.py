@@ -60,7 +60,7 @@ def _morph(op, mat, kernel, iterations, anchor=(-1, -1)):
 
         def run(out, src=src, kernel=kernel):          # (keeps the source image and the kernel array alive until it has run)
             _vp.check(_vp.lib().vp_morph_u8_dev(ctx.handle, op, src.dev_ptr, w, h, cn, kp, kw, kh, ax, ay, it, 1 if binary else 0, out.dev_ptr), ctx.handle)
-        if defer_enabled():
+        if defer_enabled() and not src.host_escaped:   # (an image whose host copy is aliased by the caller can change without notice: launch now)
             if it < 0 or (kp is not None and (ax >= kw or ay >= kh)):
                 raise _vp.VpError("libvp: invalid argument: structuring element")   # what the launch would report, reported at the call
             return DeviceMat.deferred(ctx, src.shape, np.uint8, binary, (src,), run)

@@ -88,6 +88,21 @@ const char* cmf_last_error(void);
 int cmf_frame_set_buffer(Frame* frame, void* buf, uint64_t capacity);
 uint64_t cmf_block_entry_size(Block* block);
 
+/* not in the reference: a read that leaves moving the payload to the caller - a copy engine that takes the frame out of the ring slot
+ * straight into device memory, instead of read_frame's memcpy (lib/camera_message_framework.cpp:421-452) followed by the runtime's
+ * own copy (core/base.py:765-768) and an upload.
+ *   cmf_peek_frame(block, frame, &payload, &ticket): read_frame without the payload copy.  Same statuses and the same uid rule
+ *     (NO_NEW_FRAME while frame->uid is current).  On SUCCESS the metadata of `frame` (sizes, planes, acquisition_time, uid,
+ *     total_size) describe the newest slot, frame->data is left alone, *payload points at the slot's bytes inside the block's mapping
+ *     and *ticket is the slot's sequence number at that moment.
+ *   cmf_peek_validate(block, frame->uid, ticket): call AFTER the bytes have been moved.  1: the writer has not touched the slot since
+ *     the peek, what was copied is the frame the metadata describe.  0: the writer lapped the ring meanwhile; discard the copy and peek
+ *     again (a newer frame exists by then: the slot of frame u is reused for frame u + 3).  Negative: invalid arguments.
+ *   cmf_block_mapping(block, &base, &bytes): the block's mapping in this process, for page-locking it once (hipHostRegister). */
+int cmf_peek_frame(Block* block, Frame* frame, const void** payload, uint64_t* ticket);
+int cmf_peek_validate(Block* block, uint64_t uid, uint64_t ticket);
+int cmf_block_mapping(Block* block, void** base, uint64_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,10 +335,17 @@ int vp_nms_dev(vp_ctx* ctx, const float* boxes_dev, const float* scores_dev, int
 
 /* ---- device memory helpers (so a host program needs no HIP binding of its own) --------- */
 int vp_dev_alloc(vp_ctx* ctx, size_t bytes, void** dev_ptr);
-int vp_dev_free(vp_ctx* ctx, void* dev_ptr);
+int vp_dev_free(vp_ctx* ctx, void* dev_ptr);    /* ctx may be NULL (memory that outlived its context) */
 /* Page-locked host memory: transfers to/from it run at PCIe speed (hipHostMalloc / hipHostFree). */
 int vp_host_alloc(vp_ctx* ctx, size_t bytes, void** host_ptr);
 int vp_host_free(vp_ctx* ctx, void* host_ptr);   /* ctx may be NULL */
+/* Page-locks memory the caller already has (hipHostRegister), so that vp_memcpy_h2d_async from it is a DMA at PCIe speed with no
+ * staging copy: the runtime registers the mapping of a camera_message_framework block once (cmf_block_mapping,
+ * include/camera_message_framework_c.h) and then uploads frames straight out of the ring slots - the replacement for the two host
+ * copies of lib/camera_message_framework.cpp:421-452 + core/base.py:765-768.  VP_ERR_UNSUPPORTED when the runtime refuses the range
+ * (the caller keeps its copying path); unregister before the memory is unmapped. */
+int vp_host_register(vp_ctx* ctx, void* host_ptr, size_t bytes);
+int vp_host_unregister(vp_ctx* ctx, void* host_ptr);   /* ctx may be NULL */
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
 /* The same copy enqueued on the context's stream: src_host must stay unchanged until vp_wait_uploads (or vp_synchronize) returns.
  * vp_wait_uploads waits for the copies only, not for kernels enqueued behind them: an operator enqueues the copy of its input,

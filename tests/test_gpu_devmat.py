@@ -266,9 +266,10 @@ def test_post_takes_a_copy_without_giving_up_the_device_image(vp, oracle):
     th[0:5, :] = 255                                   # after the copy: the copy keeps the old contents
     assert np.array_equal(c, ref) and np.array_equal(d, oracle.morph(oracle.DILATE, ref, np.ones((3, 3), np.uint8)))
     c2 = th.host_copy()                                # host copy authoritative now
-    assert c2 is not np.asarray(th) and c2[0, 0] == 255
-    e = dilate(th, rect_kernel(3))                     # pending: host_copy computes it
+    assert c2[0, 0] == 255
+    e = dilate(th, rect_kernel(3))                     # pending: host_copy computes it (item assignment hands out no alias)
     assert e._pending is not None and np.array_equal(e.host_copy(), np.asarray(e))
+    assert c2 is not np.asarray(th)
 
 
 def test_frames_read_straight_into_page_locked_memory(vp):
@@ -351,3 +352,60 @@ def test_overlays_drawn_on_the_device(vp):
     h = np.asarray(vis)
     D.draw_contours(vis, cs, (1, 2, 3), 2)
     assert vis._host is not None and (h == np.asarray(vis)).all() and (np.asarray(vis)[..., 0] == 1).any()
+
+
+def test_writes_through_an_alias_after_a_re_upload_are_seen(vp, oracle):
+    """A writable host alias handed out once stays writable for ever: an operator that re-uploads the host copy must not make the
+    device copy trusted again, or a later write through the alias would be lost (roi = m[a:b]; op(m); roi[:] = 0; op(m))."""
+    from vision.utils.color import range_threshold
+    from vision.utils.transform import dilate, erode, rect_kernel
+    g = np.ascontiguousarray(F.s1_buoy(2, 320, 200)[:, :, 2])
+    k3 = np.ones((3, 3), np.uint8)
+    ref = oracle.inrange(g, 150, 255)
+    th = range_threshold(g, 150, 255)
+    roi = th[40:90]                                          # a view of the host copy, kept by the caller
+    first = dilate(th, rect_kernel(3))
+    assert first._pending is None, "an operator on an image with an alias out must run at its call"
+    assert np.array_equal(first, oracle.morph(oracle.DILATE, ref, k3))
+    roi[:] = 255                                             # no hook sees this write
+    ref2 = ref.copy(); ref2[40:90] = 255
+    assert np.array_equal(dilate(th, rect_kernel(3)), oracle.morph(oracle.DILATE, ref2, k3))
+    roi[:, 100:200] = 0
+    ref2[40:90, 100:200] = 0
+    assert np.array_equal(erode(th, rect_kernel(3)), oracle.morph(oracle.ERODE, ref2, k3))
+    assert np.array_equal(th, ref2)
+    # a reshaped alias shares the state
+    th3 = range_threshold(g, 150, 255)
+    al = th3.reshaped((1,) + th3.shape).reshaped(th3.shape)
+    v = np.asarray(th3)
+    al2 = th3.reshaped(th3.shape)
+    dilate(al2, rect_kernel(3))
+    v[0:10] = 255
+    ref3 = ref.copy(); ref3[0:10] = 255
+    assert np.array_equal(dilate(al2, rect_kernel(3)), oracle.morph(oracle.DILATE, ref3, k3))
+    del al
+
+
+def test_device_draw_forces_operators_deferred_on_the_image(vp, oracle):
+    """An in-place device write (draw_contours into an image that lives on the device) is a write like any other: a morphology that
+    was deferred on that image - also one registered through a reshaped alias - reads the image as it was at its call."""
+    from vision.devmat import DeviceMat
+    from vision.utils.color import range_threshold
+    from vision.utils.draw import draw_contours
+    from vision.utils.transform import dilate, rect_kernel
+    g = np.ascontiguousarray(F.s1_buoy(5, 320, 200)[:, :, 2])
+    k3 = np.ones((3, 3), np.uint8)
+    ref = oracle.inrange(g, 150, 255)
+    th = range_threshold(g, 150, 255)
+    assert isinstance(th, DeviceMat) and th._host is None
+    alias = th.reshaped(th.shape)
+    d1 = dilate(th, rect_kernel(3))
+    d2 = dilate(alias, rect_kernel(3))
+    assert d1._pending is not None and d2._pending is not None
+    square = np.array([[[20, 20]], [[120, 20]], [[120, 90]], [[20, 90]]], np.int32)
+    draw_contours(th, [square], color=(255, 255, 255), thickness=3)
+    assert th._host is None, "the overlay was meant to be drawn by the device"
+    assert d1._pending is None and d2._pending is None, "pending readers must run before the device write"
+    exp = oracle.morph(oracle.DILATE, ref, k3)
+    assert np.array_equal(d1, exp) and np.array_equal(d2, exp)
+    assert not np.array_equal(np.asarray(th), ref)           # and the drawing did land
