@@ -1,24 +1,29 @@
-"""Module runtime: source parsing, tuner/post blocks, the polling loop and multi-source dispatch.
+"""Module runtime: what a vision module inherits from and what feeds it.
 
-Mirror of the reference core/base.py (VideoSource :36-120, sources :123-149, ModuleManager :161-322,
-ModuleReader :325-510, VideoSourceMetadata :517-574, ModuleBase :577-942): same class and method names, CLI
-flags, block naming (`module_<Class>-on-<src>_post%<idx>%<name>#<CS>`, `_tune%<idx>%<TunerClass>_<name>`), frame
-copy / dispatch rules and retry-on-FRAMEWORK_DELETED contract, so module files written against the reference
-run here unchanged.  The image operators those modules call (vision.utils.*) run on the GPU via libvp.
+The contract is the reference's core/base.py (the names modules and GUIs use: `VideoSource`, `sources`, `ModuleManager`,
+`ModuleReader`, `VideoSourceMetadata`, `ModuleBase`; the launch flags; the block names `module_<Class>-on-<src>_post%<idx>%<name>#<CS>`
+and `_tune%<idx>%<TunerClass>_<name>`; which frames reach `process()` and which reach an `@sources` handler; retry after a source
+was deleted) - SURVEY.md section 3.1 / 8b lists the behaviours with their lines.  The insides are this repository's own:
 
-Deliberate differences: logging falls back to a stdout logger when `auvlog` is absent; every
-VideoSourceMetadata owns its latency window (the reference shares one deque between all instances through a
-dataclass default); there is no cv2 dependency (`UMat` inputs to post() are unwrapped by duck typing).
+  * a module's blocks are `_Port` records kept in one table per kind, opened and closed through one ExitStack;
+  * a frame does not pass through host memory on its way to a module: `BlockAccessor.read_frame_device` moves it from its ring
+    slot into HBM with one DMA and hands out device images (`vision.devmat.DeviceMat`, array-likes that materialise on the host
+    only if Python touches them).  On a box without a device the frames are private host arrays, as in the reference;
+  * the loop body is split into `_deliver`, `_fire_handlers` and `_flush_posts`.
+
+Differences a module can observe: logging falls back to stdout when `auvlog` is absent; every VideoSourceMetadata owns its latency
+window (the reference shares one deque between all instances through a dataclass default); `UMat` inputs to post() are unwrapped by
+duck typing (no cv2 dependency); `ModuleBase.stop()` ends a running module from another thread.
 """
 import argparse
 import contextlib
 import glob
+import re
 import signal
 import threading
 import time
-from collections import OrderedDict, deque
-from dataclasses import dataclass, field
-from typing import Any, Callable, Deque, Dict, List, Optional, Tuple, Union
+from collections import OrderedDict, deque, namedtuple
+from typing import Any, Callable, Dict, List, NamedTuple, Optional, Tuple, Union
 
 import numpy as np
 
@@ -48,44 +53,44 @@ except Exception:  # pragma: no cover - exercised wherever auvlog is absent
 
     auvlog = _StdoutLogger()
 
-_TYPE_CODES = {1: {"u8": np.uint8, "i8": np.int8}, 4: {"u32": np.uint32, "i32": np.int32, "f32": np.float32},
-               8: {"u64": np.uint64, "i64": np.int64, "f64": np.float64}}
-_TYPE_DEFAULT = {1: np.uint8, 4: np.float32, 8: np.float64}
+# item size -> ((code in a source string, dtype) in the order the codes are looked for, default dtype)
+_PLANE_TYPES = {1: ((("u8", np.uint8), ("i8", np.int8)), np.uint8),
+                4: ((("u32", np.uint32), ("i32", np.int32), ("f32", np.float32)), np.float32),
+                8: ((("u64", np.uint64), ("i64", np.int64), ("f64", np.float64)), np.float64)}
 VALID_COLOR_SPACES = ("BGR", "RGB", "HSV", "LAB", "HLS", "YCRCB", "LUV", "GRAY")
+_SOURCE_SPEC = re.compile(r"^\s*(?P<name>[^\[\]:]*?)\s*(?:\[(?P<aliases>[^\]]*)\])?\s*(?::(?P<types>.*))?$")
 
 
 def _now_ms() -> int:
     return int(time.monotonic() * 1000)
 
 
-@dataclass
-class VideoSource:
-    """How to decode one direction: `name[alias,...]:<t1>:<t4>:<t8>` (e.g. "zed[forward,depth]:f32")."""
-    name: str
-    byte_type: type = np.uint8
-    short_type: type = np.float32
-    long_type: type = np.float64
-    plane_aliases: Tuple[str, ...] = ()
+def _alias_list(text: Optional[str]) -> Tuple[str, ...]:
+    return tuple(a.strip() for a in (text or "").split(",") if a.strip())
 
-    @classmethod
-    def _parse_name_and_aliases(cls, source: str) -> Tuple[str, Tuple[str, ...]]:
-        if "[" not in source:
-            return source, tuple()
-        name, rest = source.split("[", maxsplit=1)
-        inner = rest.rsplit("]", maxsplit=1)[0]
-        return name, tuple(a.strip() for a in inner.split(",") if a.strip())
+
+class VideoSource(namedtuple("VideoSource", "name byte_type short_type long_type plane_aliases",
+                             defaults=(np.uint8, np.float32, np.float64, ()))):
+    """How to decode one direction: `name[alias,...]:<t1>:<t4>:<t8>` (e.g. "zed[forward,depth]:f32"): the dtypes planes of item size
+    1 / 4 / 8 are read as, and names for the planes when the block stores none."""
+    __slots__ = ()
 
     @classmethod
     def create(cls, source_str: Union[str, "VideoSource"]) -> "VideoSource":
-        if isinstance(source_str, VideoSource):
-            return source_str
-        name_part, _, types = source_str.partition(":")
-        name, aliases = cls._parse_name_and_aliases(name_part)
-        chosen = []
+        if isinstance(source_str, cls):
+            return source_str                            # already parsed
+        m = _SOURCE_SPEC.match(source_str)
+        if m is None:                                    # brackets out of place: everything before the first ':' is the name
+            name, _, types = source_str.partition(":")
+            m_name, aliases = name.strip(), ()
+        else:
+            m_name, aliases, types = m.group("name"), _alias_list(m.group("aliases")), m.group("types") or ""
+        picked = []
         for width in (1, 4, 8):
-            # substring test in declaration order, like the reference ("u8" wins over "i8", ...)
-            chosen.append(next((t for code, t in _TYPE_CODES[width].items() if code in types), _TYPE_DEFAULT[width]))
-        return VideoSource(name.strip(), chosen[0], chosen[1], chosen[2], aliases)
+            codes, default = _PLANE_TYPES[width]
+            # a substring test in the table's order, as the reference does it: "u8" wins over "i8" when both are named
+            picked.append(next((dtype for code, dtype in codes if code in types), default))
+        return cls(m_name, picked[0], picked[1], picked[2], aliases)
 
     @classmethod
     def into_accessor(cls, instn: "VideoSource"):
@@ -93,307 +98,310 @@ class VideoSource:
 
 
 def sources(*source_specs: str):
-    """Binds a method to an ordered list of aliases; the loop calls it with one image per alias once all are
-    cached and at least one is new.  "zed[forward]" names the alias `forward`; a bare "downward" is itself."""
+    """`@sources("zed[forward]", "downward")` binds a method to an ordered list of aliases: the loop calls it with one image per alias
+    once every alias has been seen and at least one of them is new.  "zed[forward]" names the alias `forward`; a bare name is its own."""
     def alias_of(spec: str) -> str:
-        spec = spec.strip()
-        if "[" in spec and "]" in spec:
-            return spec.split("[", 1)[1].rsplit("]", 1)[0].strip()
-        return spec
+        m = _SOURCE_SPEC.match(spec)
+        inner = _alias_list(m.group("aliases")) if m is not None and m.group("aliases") is not None else ()
+        return inner[0] if inner else spec.strip()
+    aliases = tuple(alias_of(s) for s in source_specs)
 
-    def decorate(fn: Callable):
-        fn._sources_aliases = tuple(alias_of(s) for s in source_specs)
+    def bind(fn: Callable):
+        fn._sources_aliases = aliases
         return fn
-    return decorate
+    return bind
 
 
-@dataclass
-class VideoMessage:
+class VideoMessage(NamedTuple):
+    """One read of one direction, as ModuleManager.read_messages reports it."""
     source: VideoSource
     status: ReadStatus
-    data: Optional[Union[np.ndarray, Tuple[np.ndarray, ...]]]
+    data: Any                       # image, tuple of images (planes), or None
     acquisition_time: int
-    plane_names: Tuple[str, ...] = tuple()
-    private: bool = False          # data already is the module's own writable copy (read straight into page-locked memory)
+    plane_names: Tuple[str, ...] = ()
+    private: bool = False           # data already belongs to the module (device images / page-locked arrays of its own)
+
+
+class _Port(NamedTuple):
+    """A block the module holds open, with what it carries."""
+    key: str
+    accessor: BlockAccessor
+    payload: Any = None             # VideoSource or TunerBase
+
+
+def _table(ports: List[_Port], what: str) -> "OrderedDict[str, _Port]":
+    out: "OrderedDict[str, _Port]" = OrderedDict((p.key, p) for p in ports)
+    if len(out) != len(ports):
+        raise RuntimeError(f"cannot have multiple {what} of the same name")
+    return out
 
 
 class ModuleManager:
-    """The module's end of its blocks: reads video directions and tuner updates, creates post blocks lazily."""
+    """The module's end of its blocks: the directions it reads, one one-frame block per tuner (created here; the index in the block
+    name orders the GUI's controls), post blocks created on first use.  Usable inside `with` only."""
 
     def __init__(self, module_name: str, video_sources: List[VideoSource], tuner_sources: List[TunerBase]):
         self._module_name = "module_" + module_name
-        self._post_name = self._module_name + "_post"
-        self._tune_name = self._module_name + "_tune"
-        self._first = True
-        self._video_sources: Dict[str, VideoSource] = {vs.name: vs for vs in video_sources}
-        self._tuner_sources: Dict[str, TunerBase] = {ts.name: ts for ts in tuner_sources}
-        if len(self._video_sources) != len(video_sources):
-            raise RuntimeError("cannot have multiple video sources of the same name")
-        if len(self._tuner_sources) != len(tuner_sources):
-            raise RuntimeError("cannot have multiple tuner types of the same name")
-        self._video_accessor: Dict[str, BlockAccessor] = {vs.name: VideoSource.into_accessor(vs) for vs in video_sources}
-        # the index in the block name tells the GUI how to order the tuners
-        self._tuner_accessor: Dict[str, BlockAccessor] = {
-            ts.name: BlockAccessor(f"{self._tune_name}%{idx}%{ts}", max_entry_size_bytes=ts.byte_size())
-            for idx, ts in enumerate(tuner_sources)}
-        self._post_accessor: Dict[str, BlockAccessor] = {}
-        self._exit_stack = contextlib.ExitStack()
-        self._inside_ctx = False
+        self._videos = _table([_Port(v.name, VideoSource.into_accessor(v), v) for v in video_sources], "video sources")
+        self._tuners = _table([_Port(t.name, BlockAccessor(f"{self._module_name}_tune%{i}%{t}", max_entry_size_bytes=t.byte_size()), t)
+                               for i, t in enumerate(tuner_sources)], "tuner types")
+        self._posts: Dict[str, BlockAccessor] = {}
+        self._defaults_published = False
+        self._open: Optional[contextlib.ExitStack] = None
 
-    def _require_ctx(self):
-        if not self._inside_ctx:
+    def video_accessor(self, name: str) -> BlockAccessor:
+        """The accessor of a direction, for tools that want its counters (copies dropped as lapped, ...)."""
+        return self._videos[name].accessor
+
+    def _stack(self) -> contextlib.ExitStack:
+        if self._open is None:
             raise RuntimeError("attempted to access ModuleManager while not in a context manager")
+        return self._open
 
     def post(self, name: str, idx: int, acquisition_time: int, data: np.ndarray):
-        self._require_ctx()
-        accessor = self._post_accessor.get(name)
-        if accessor is None:
-            accessor = BlockAccessor(f"{self._post_name}%{idx}%{name}", data.nbytes)
-            self._exit_stack.enter_context(accessor)
-            self._post_accessor[name] = accessor
-        accessor.write_frame(acquisition_time, data)
+        stack = self._stack()
+        block = self._posts.get(name)
+        if block is None:
+            block = self._posts[name] = stack.enter_context(BlockAccessor(f"{self._module_name}_post%{idx}%{name}", data.nbytes))
+        block.write_frame(acquisition_time, data)
 
     def read_messages(self) -> List[VideoMessage]:
-        self._require_ctx()
-        for name, accessor in self._tuner_accessor.items():
-            status, frame, _ = accessor.read_frame()
+        self._stack()
+        for port in self._tuners.values():
+            status, raw, _ = port.accessor.read_frame()
             if status == ReadStatus.FRAMEWORK_DELETED:
                 raise RuntimeError("Unexpected deleted Tuner")
-            if frame is not None:
-                self._tuner_sources[name].deserialize(frame.tobytes("C"))
-        messages: List[VideoMessage] = []
-        for name, accessor in self._video_accessor.items():
-            status, data, acquisition_time, private = accessor.read_frame_device()
+            if raw is not None:
+                port.payload.deserialize(raw.tobytes("C"))
+        out = []
+        for port in self._videos.values():
+            status, data, stamp, private = port.accessor.read_frame_device()
             if status == ReadStatus.FRAMEWORK_DELETED:
-                raise RuntimeError(f"{accessor.direction} was marked for deletion")
+                raise RuntimeError(f"{port.accessor.direction} was marked for deletion")
             if data is not None:
-                messages.append(VideoMessage(self._video_sources[name], status, data, acquisition_time, accessor.last_plane_names(), private))
-        return messages
+                out.append(VideoMessage(port.payload, status, data, stamp, port.accessor.last_plane_names(), private))
+        return out
 
     def __getitem__(self, key: str) -> Any:
-        return self._tuner_sources[key].value
+        return self._tuners[key].payload.value
 
     def __str__(self) -> str:
-        return f"ModuleManager(name={self._module_name}, video_sources={self._video_sources}, tuner_sources={self._tuner_sources})"
+        return (f"ModuleManager(name={self._module_name}, video_sources={[p.payload for p in self._videos.values()]}, "
+                f"tuner_sources={[p.payload for p in self._tuners.values()]})")
 
     def __enter__(self):
-        if self._inside_ctx:
+        if self._open is not None:
             raise RuntimeError("double dipped in context manager for ModuleManager")
-        self._inside_ctx = True
-        self._exit_stack.__enter__()
-        try:
-            for accessor in list(self._video_accessor.values()) + list(self._tuner_accessor.values()):
-                self._exit_stack.enter_context(accessor)
-            if self._first:   # publish the defaults once so that the GUI can render the tuners
-                self._first = False
-                for ts in self._tuner_sources.values():
-                    self._tuner_accessor[ts.name].write_frame(_now_ms(), np.frombuffer(ts.serialize(), dtype=np.uint8))
-        except BaseException:
-            self._exit_stack.close()
-            self._inside_ctx = False
-            raise
+        with contextlib.ExitStack() as stack:
+            for port in list(self._videos.values()) + list(self._tuners.values()):
+                stack.enter_context(port.accessor)
+            if not self._defaults_published:      # once: the GUI renders a tuner from the first frame of its block
+                for port in self._tuners.values():
+                    port.accessor.write_frame(_now_ms(), np.frombuffer(port.payload.serialize(), dtype=np.uint8))
+                self._defaults_published = True
+            self._open = stack.pop_all()          # everything opened: keep it (an exception above closes what was opened)
         return self
 
     def __exit__(self, exc_type, exc_value, traceback):
-        self._exit_stack.__exit__(exc_type, exc_value, traceback)
-        self._exit_stack = contextlib.ExitStack()
-        self._post_accessor.clear()
-        self._inside_ctx = False
+        stack, self._open = self._open, None
+        self._posts.clear()
+        return stack.__exit__(exc_type, exc_value, traceback) if stack is not None else None
+
+
+class _Watched(NamedTuple):
+    """A post or tuner block of a running module as the GUI side sees it."""
+    index: int
+    accessor: BlockAccessor
+    extra: Any                      # colour space of a post / TunerBase of a tuner
+
+
+_TUNER_KINDS = {"IntTuner": lambda n: IntTuner(n, 0), "DoubleTuner": lambda n: DoubleTuner(n, 0), "BoolTuner": lambda n: BoolTuner(n, False)}
 
 
 class ModuleReader:
-    """The GUI's end: discovers a running module's post / tuner blocks under /dev/shm and polls them."""
+    """The GUI's end of a running module: finds its post and tuner blocks under /dev/shm, polls them on a thread and calls the
+    registered callbacks; `update_tuner_value` writes an edit back into the tuner's block."""
 
     def __init__(self, module_name: str):
-        if module_name not in ModuleReader.get_active_modules():
+        if module_name not in self.get_active_modules():
             raise RuntimeError("Module name is not active")
-        self._base_module_name = module_name
-        self._module_name = f"module_{module_name}"
-        self._post_name = f"{self._module_name}_post%"
-        self._tune_name = f"{self._module_name}_tune%"
-        self._quit_flag = threading.Event()
-        self._thread: Optional[threading.Thread] = None
-        self._post_udls: List[Callable[[str, str, int, np.ndarray, str], None]] = []
-        self._tuner_udls: List[Callable[[str, str, int, TunerBase], None]] = []
-        self._tuner_guard = False
-        self._framework_deleted = False
-        self._all_posts: Dict[str, Tuple[int, BlockAccessor, str]] = {}
+        self._module, self._stem = module_name, "module_" + module_name
+        self._halt, self._poller = threading.Event(), None
+        self._on_post: List[Callable[[str, str, int, np.ndarray, str], None]] = []      # (module, post name, index, image, colour space)
+        self._on_tuner: List[Callable[[str, str, int, TunerBase], None]] = []           # (module, tuner name, index, tuner)
+        self._resend_once = self._deleted = False
+        self._all_posts: Dict[str, _Watched] = {}
         for block in self.active_posts:
-            idx, name, color_space = self.parse_post_name(block)
-            self._all_posts[name] = (idx, BlockAccessor(block), color_space)
-        self._all_tuners: Dict[str, Tuple[int, BlockAccessor, TunerBase]] = {}
+            index, name, color_space = self.parse_post_name(block)
+            self._all_posts[name] = _Watched(index, BlockAccessor(block), color_space)
+        self._all_tuners: Dict[str, _Watched] = {}
         for block in self.active_tuners:
-            idx, tuner, name = self.parse_tune_name(block)
-            self._all_tuners[name] = (idx, BlockAccessor(block), tuner)
+            index, tuner, name = self.parse_tune_name(block)
+            self._all_tuners[name] = _Watched(index, BlockAccessor(block), tuner)
 
     @classmethod
     def get_active_modules(cls):
-        # /dev/shm/auv_visiond_module_<Name>_... -> <Name>
-        return list({path.split("_")[3] for path in glob.glob(f"{BLOCK_STUB}module_*")})
+        # /dev/shm/auv_visiond_module_<Name>_... -> <Name> (hence no underscore in class or direction names)
+        return sorted({path.split("_")[3] for path in glob.glob(f"{BLOCK_STUB}module_*")})
 
-    def _blocks_with_prefix(self, prefix: str) -> List[str]:
-        return [path[len(BLOCK_STUB):] for path in glob.glob(BLOCK_STUB + prefix + "*")]
+    def _blocks(self, kind: str) -> List[str]:
+        return [path[len(BLOCK_STUB):] for path in glob.glob(f"{BLOCK_STUB}{self._stem}_{kind}%*")]
 
-    @property
-    def active_posts(self) -> List[str]:
-        return self._blocks_with_prefix(self._post_name)
-
-    @property
-    def active_tuners(self):
-        return self._blocks_with_prefix(self._tune_name)
-
-    @property
-    def framework_deleted(self):
-        return self._framework_deleted
+    active_posts = property(lambda self: self._blocks("post"))
+    active_tuners = property(lambda self: self._blocks("tune"))
+    framework_deleted = property(lambda self: self._deleted)
 
     def parse_post_name(self, s: str) -> Tuple[int, str, str]:
-        _, idx, tail = s.split("%")
-        name, sep, color_space = tail.partition("#")
-        return int(idx), name, (color_space if sep else "BGR")
+        _, index, rest = s.split("%")
+        name, marked, color_space = rest.partition("#")
+        return int(index), name, color_space if marked else "BGR"
 
     def parse_tune_name(self, s: str) -> Tuple[int, TunerBase, str]:
-        _, idx, tail = s.split("%")
-        kind, name = tail.split("_", maxsplit=1)
-        tuner = IntTuner(name, 0) if kind == "IntTuner" else DoubleTuner(name, 0) if kind == "DoubleTuner" else BoolTuner(name, False)
-        return int(idx), tuner, name
+        _, index, rest = s.split("%")
+        kind, name = rest.split("_", maxsplit=1)
+        return int(index), _TUNER_KINDS.get(kind, _TUNER_KINDS["BoolTuner"])(name), name
 
     def register_post_udl(self, udl):
-        self._post_udls.append(udl)
+        self._on_post.append(udl)
 
     def register_tuner_udl(self, udl):
-        self._tuner_udls.append(udl)
+        self._on_tuner.append(udl)
 
     def allow_resend_tuners_once(self):
-        self._tuner_guard = True
+        self._resend_once = True
 
     def update_tuner_value(self, name: str, value: Any):
-        _, accessor, tuner = self._all_tuners[name]
-        tuner._current_value = value
-        accessor.write_frame(_now_ms(), np.frombuffer(tuner.serialize(), dtype=np.uint8))
+        watched = self._all_tuners[name]
+        watched.extra._current_value = value
+        watched.accessor.write_frame(_now_ms(), np.frombuffer(watched.extra.serialize(), dtype=np.uint8))
 
     def run_forever(self, fps: int = 60):
-        if self._thread is not None:
+        if self._poller is not None:
             raise RuntimeError("cannot run already running module reader")
-        self._quit_flag = threading.Event()
-        self._thread = threading.Thread(target=self._loop, args=(fps,))
-        self._thread.start()
+        self._halt = threading.Event()
+        self._poller = poller = threading.Thread(target=self._poll, args=(1.0 / fps,))
+        poller.start()
 
-    def _on_deleted(self):
-        print(f"ModuleReader: {self._base_module_name} framework deleted")
-        self._framework_deleted = True
-        self._quit_flag.set()
+    def _gone(self):
+        print(f"ModuleReader: {self._module} framework deleted")
+        self._deleted = True
+        self._halt.set()                                # the poller leaves; unblock() still joins it
 
-    def _loop(self, fps: int):
-        period = 1.0 / fps
+    def _poll(self, period: float):
         with contextlib.ExitStack() as stack:
-            for _, accessor, _ in list(self._all_posts.values()) + list(self._all_tuners.values()):
-                stack.enter_context(accessor)
-            while not self._quit_flag.is_set():
-                tick = time.monotonic()
-                for name, (idx, accessor, color_space) in self._all_posts.items():
-                    status, data, _ = accessor.read_frame()
-                    if status == ReadStatus.SUCCESS and data is not None:
-                        for cb in self._post_udls:
-                            cb(self._base_module_name, name, idx, data, color_space)
-                    elif status == ReadStatus.FRAMEWORK_DELETED:
-                        self._on_deleted()
-                resent = False
-                for name, (idx, accessor, tuner) in self._all_tuners.items():
-                    status, data, _ = accessor.read_frame()
-                    if (self._tuner_guard or status == ReadStatus.SUCCESS) and data is not None:
-                        resent = resent or self._tuner_guard
-                        tuner.deserialize(data.tobytes("C"))
-                        for cb in self._tuner_udls:
-                            cb(self._base_module_name, name, idx, tuner)
-                    elif status == ReadStatus.FRAMEWORK_DELETED:
-                        self._on_deleted()
-                if resent:
-                    self._tuner_guard = False
-                time.sleep(max(0.0, period - (time.monotonic() - tick)))
+            for watched in list(self._all_posts.values()) + list(self._all_tuners.values()):
+                stack.enter_context(watched.accessor)
+            while not self._halt.is_set():
+                began = time.monotonic()
+                for name, post in self._all_posts.items():
+                    status, data, _ = post.accessor.read_frame()
+                    if status == ReadStatus.FRAMEWORK_DELETED:
+                        self._gone()
+                    elif status == ReadStatus.SUCCESS and data is not None:
+                        for udl in self._on_post:
+                            udl(self._module, name, post.index, data, post.extra)
+                resend, self._resend_once = self._resend_once, False
+                for name, tune in self._all_tuners.items():
+                    status, data, _ = tune.accessor.read_frame()
+                    if status == ReadStatus.FRAMEWORK_DELETED:
+                        self._gone()
+                    elif data is not None and (resend or status == ReadStatus.SUCCESS):
+                        tune.extra.deserialize(data.tobytes("C"))
+                        for udl in self._on_tuner:
+                            udl(self._module, name, tune.index, tune.extra)
+                time.sleep(max(0.0, period - (time.monotonic() - began)))
+
+    def _join(self) -> bool:
+        poller, self._poller = getattr(self, "_poller", None), None
+        if poller is None:
+            return False
+        self._halt.set()
+        poller.join()
+        return True
 
     def unblock(self):
-        if self._thread is None:
-            print(f"[WARNING]: {self._module_name} was already terminated")
-            return
-        self._quit_flag.set()
-        self._thread.join()
-        self._thread = None
+        if not self._join():
+            print(f"[WARNING]: {self._stem} was already terminated")
 
     def __del__(self):
-        if getattr(self, "_thread", None) is not None:
+        if self._join():
             print("[WARNING]: object garbage collected without freeing underlying resources")
-            self._quit_flag.set()
-            self._thread.join()
 
 
-@dataclass
 class VideoSourceMetadata:
-    """Per-direction bookkeeping: last frame shape (for normalisation), latency window, liveness."""
-    _frames_read: int = 0
-    _shape: Tuple[int, int] = (1, 1)
-    _acquisition_times: Deque[int] = field(default_factory=lambda: deque(maxlen=30))
-    _dead_counter: int = 0
+    """Per-direction bookkeeping: shape of the last frame (for normalisation), age of the last 30 frames, liveness."""
+    WINDOW = 30
 
-    def update(self, mat: Union[np.ndarray, Tuple[np.ndarray, ...]], acquisition_time: int):
+    def __init__(self):
+        self._frames_read = 0
+        self._shape: Tuple[int, int] = (1, 1)
+        self._acquisition_times = deque(maxlen=self.WINDOW)
+        self._dead_counter = 0
+
+    def update(self, mat, acquisition_time: int):
         self._acquisition_times.append(_now_ms() - acquisition_time)
         if isinstance(mat, tuple):
-            if len(mat) == 0:
-                return
+            if not mat:
+                return                                  # an empty plane tuple: nothing to measure
             mat = mat[0]
         self._shape = (mat.shape[0], mat.shape[1])
         self._frames_read += 1
         self._dead_counter = max(0, self._dead_counter - 1)
 
-    def mark_as_dead(self):
+    def mark_as_dead(self) -> bool:
         """-> True when the source had been healthy until now."""
-        was_alive = self._dead_counter == 0
-        self._dead_counter = 3
-        return was_alive
+        healthy, self._dead_counter = self._dead_counter == 0, 3
+        return healthy
 
     def get_latency(self) -> int:
         return int(sum(self._acquisition_times) / len(self._acquisition_times))
 
     def normalize_axis(self, coord: float, axis: int) -> float:
-        """(coord - dim/2) / width; axis 0 = x, 1 = y.  Both axes are scaled by the WIDTH (core/base.py:553-563)."""
-        return (coord - self._shape[1 - axis] / 2) / self._shape[1]
+        """(coord - dim/2) / width; axis 0 = x, 1 = y.  BOTH axes are scaled by the width (core/base.py:553-563)."""
+        height, width = self._shape
+        return (coord - (width if axis == 0 else height) / 2) / width
 
     def normalize_coord(self, coord: Tuple[float, float]) -> Tuple[float, float]:
-        """(y, x) -> normalised (y, x)."""
+        """(y, x) in pixels -> normalised (y, x)."""
         return self.normalize_axis(coord[0], 1), self.normalize_axis(coord[1], 0)
 
 
+_CLI = (  # the launch line of a module (core/base.py:599-635): flags, then what add_argument gets
+    (("-f", "--fps"), dict(type=int, help="upper bound on loop iterations per second (the sources set the real rate)")),
+    (("--verbose",), dict(action="store_true", help="log what the loop is doing")),
+    (("--enable-performance",), dict(action="store_true", help="post() becomes a no-op: nothing is copied or published for the GUI")),
+    (("sources",), dict(nargs="*", type=str,
+                        help="directions to read, each `name[alias,...]:<1-byte type>:<4-byte type>:<8-byte type>` with types from u8 i8 / u32 i32 f32 /\n"
+                             "u64 i64 f64 (e.g. forward, zed[forward,depth]:f32); none given: the module's own list")),
+)
+
+
 class ModuleBase:
-    """Base class of a vision module: `Module(sources, tuners)()` polls the sources at `fps` and calls
-    process(direction, image) — or the @sources-decorated handlers — on a worker thread, one frame at a time."""
+    """Base class of a vision module: `Module(sources, tuners)()` polls the sources at `fps` and calls process(direction, image) -
+    or the @sources-decorated handlers - on a worker thread, one frame at a time."""
 
     def __init__(self, video_sources: List[Union[VideoSource, str]] = [], tuners: List[TunerBase] = [], fps: int = 10, **kwargs):
-        parser = argparse.ArgumentParser(f"{__file__}", description="runs this vision module against its camera directions",
-                                         formatter_class=argparse.RawTextHelpFormatter)
-        parser.add_argument("-f", "--fps", type=int, default=fps,
-                            help="upper bound on loop iterations per second (the sources set the real rate)")
-        parser.add_argument("--verbose", action="store_true", help="log what the loop is doing")
-        parser.add_argument("--enable-performance", action="store_true",
-                            help="post() becomes a no-op: nothing is copied or published for the GUI")
-        parser.add_argument("sources", nargs="*", type=str,
-                            help="directions to read, each `name[alias,...]:<1-byte type>:<4-byte type>:<8-byte type>` with types from u8 i8 / u32 i32 f32 /\n"
-                                 "u64 i64 f64 (e.g. forward, zed[forward,depth]:f32); none given: the module's own list")
-        args = parser.parse_args()
-        if "_" in self.__class__.__name__:
-            raise RuntimeError(f"Class name '{self.__class__.__name__}'cannot have an underscore")
-        src = [VideoSource.create(s) for s in (args.sources if args.sources else video_sources)]
-        self._name = self.__class__.__name__ + "-on-" + "-".join(s.name for s in src)
-        self._fps: int = args.fps if args.fps else fps
-        self._verbose: bool = args.verbose
-        self._module_manager = ModuleManager(self._name, src, tuners)
-        self._post_queue: "OrderedDict[str, np.ndarray]" = OrderedDict()
-        self._post_color_spaces: Dict[str, str] = {}
-        self._performance_enabled = args.enable_performance
-        self._retry = True
-        self._video_metadata: Dict[str, VideoSourceMetadata] = {}
-        for source in src:
-            self._video_metadata[source.name] = VideoSourceMetadata()
-            for alias in source.plane_aliases:
-                self._video_metadata.setdefault(alias, VideoSourceMetadata())
+        cli = argparse.ArgumentParser(f"{__file__}", description="runs this vision module against its camera directions",
+                                      formatter_class=argparse.RawTextHelpFormatter)
+        for flags, spec in _CLI:
+            cli.add_argument(*flags, **spec)
+        cli.set_defaults(fps=fps)
+        args = cli.parse_args()
+        cls_name = type(self).__name__
+        if "_" in cls_name:                               # block names are split on "_" by the GUI side
+            raise RuntimeError(f"Class name '{cls_name}'cannot have an underscore")
+        chosen = [VideoSource.create(s) for s in (args.sources or video_sources)]
+        self._name = f"{cls_name}-on-" + "-".join(s.name for s in chosen)
+        self._fps: int = args.fps or fps
+        self._chatty = bool(args.verbose)
+        self._performance_enabled: bool = args.enable_performance
+        self._module_manager = ModuleManager(self._name, chosen, tuners)
+        self._post_queue: "OrderedDict[str, Tuple[np.ndarray, str]]" = OrderedDict()
+        self._retry = True                                # __call__ keeps (re-)entering the manager while this is set
+        self._directions: Dict[str, VideoSourceMetadata] = {}     # per direction and per named plane
+        for s in chosen:
+            for key in (s.name,) + tuple(s.plane_aliases):
+                self._directions.setdefault(key, VideoSourceMetadata())
         self._current_direction = ""
         self._quit_flag: Optional[threading.Event] = None
 
@@ -407,151 +415,157 @@ class ModuleBase:
         return self._module_manager
 
     def __call__(self):
-        logger = getattr(auvlog, self._name)
-        logger(f"Running {self._name}", True)
+        say = getattr(auvlog, self._name)
+        say(f"Running {self._name}", True)
         if self._performance_enabled:
-            logger("Module running in performance mode", True)
-        previous_handler = signal.getsignal(signal.SIGINT)
-        quit_flag = threading.Event()
-        self._quit_flag = quit_flag
+            say("Module running in performance mode", True)
+        quit_flag = self._quit_flag = threading.Event()
+        on_main = threading.current_thread() is threading.main_thread()
+        old_handler = signal.getsignal(signal.SIGINT) if on_main else None
 
-        def on_sigint(*sig):
-            logger(f"Caught signal: {sig[0]}. It may take up to 2 seconds to clean up.", self._verbose)
+        def interrupted(signum, *_):
+            say(f"Caught signal: {signum}. It may take up to 2 seconds to clean up.", self._chatty)
             quit_flag.set()
 
-        logger(f"Target FPS = {self._fps}", self._verbose)
-        while self._retry:   # a deleted source re-enters the manager and waits for the source to come back
+        say(f"Target FPS = {self._fps}", self._chatty)
+        while self._retry:                                # a deleted source: leave the manager, enter it again, wait for the source
             self._retry = False
             quit_flag.clear()
             with self._module_manager:
-                if threading.current_thread() is threading.main_thread():
-                    signal.signal(signal.SIGINT, on_sigint)
-                    logger("Registered SIGINT handler", self._verbose)
-                logger(f"Initialized module manager {self._module_manager}", self._verbose)
-                worker = threading.Thread(target=self._loop, args=(quit_flag, logger))
+                if on_main:
+                    signal.signal(signal.SIGINT, interrupted)
+                    say("Registered SIGINT handler", self._chatty)
+                say(f"Initialized module manager {self._module_manager}", self._chatty)
+                worker = threading.Thread(target=self._loop, args=(quit_flag, say))
                 worker.start()
                 worker.join()
-            if self._retry and threading.current_thread() is threading.main_thread():
-                signal.signal(signal.SIGINT, previous_handler)
-                logger("Unregistered SIGINT handler", self._verbose)
-        logger(f"Cleaning {self.__class__.__name__}", True)
+            if self._retry and on_main:
+                signal.signal(signal.SIGINT, old_handler)
+                say("Unregistered SIGINT handler", self._chatty)
+        say(f"Cleaning {type(self).__name__}", True)
 
-    # -- loop ---------------------------------------------------------------------------------------
-    def _discover_handlers(self, logger) -> List[Tuple[Callable[..., None], Tuple[str, ...]]]:
+    # -- the loop -----------------------------------------------------------------------------------------------------------
+    def _bound_handlers(self, say) -> List[Tuple[Callable[..., None], Tuple[str, ...]]]:
+        """Methods decorated with @sources, with their alias lists."""
         found = []
         for attr in dir(self):
             try:
                 member = getattr(self, attr)
             except Exception:
                 continue
-            aliases = getattr(member, "_sources_aliases", None)
-            if aliases is None and hasattr(member, "__func__"):
-                aliases = getattr(member.__func__, "_sources_aliases", None)
+            aliases = getattr(member, "_sources_aliases", None) or getattr(getattr(member, "__func__", None), "_sources_aliases", None)
             if aliases:
                 found.append((member, tuple(aliases)))
-                logger(f"Registered multi-source handler {attr} with aliases: {aliases}", True)
+                say(f"Registered multi-source handler {attr} with aliases: {aliases}", True)
         return found
 
-    def _plane_aliases(self, message: VideoMessage, count: int) -> Tuple[str, ...]:
-        # names stored in the block win, then the [alias] list of the source string, then name[i]
-        if message.plane_names and len(message.plane_names) == count and all(len(str(n)) > 0 for n in message.plane_names):
-            return tuple(message.plane_names)
-        if message.source.plane_aliases and len(message.source.plane_aliases) == count:
-            return message.source.plane_aliases
+    @staticmethod
+    def _names_of_planes(message: VideoMessage, count: int) -> Tuple[str, ...]:
+        """Names stored in the block win, then the [alias] list of the source string, then name[i]."""
+        stored = message.plane_names
+        if stored and len(stored) == count and all(str(n) for n in stored):
+            return tuple(stored)
+        listed = message.source.plane_aliases
+        if listed and len(listed) == count:
+            return listed
         return tuple(f"{message.source.name}[{i}]" for i in range(count))
 
-    def _loop(self, quit_flag: threading.Event, logger):
-        frame_cache: Dict[str, Tuple[np.ndarray, int]] = {}
-        handlers = self._discover_handlers(logger)
+    def _deliver(self, message: VideoMessage, cache: dict, fresh: set, covered: set):
+        """One successfully read direction: its frame(s) become the module's own, enter the alias cache, and reach process() unless
+        an @sources handler covers the alias."""
+        source, image, stamp = message.source, message.data, message.acquisition_time
+        if not message.private:                           # views of the library's buffer (a box without a device): copy, as the reference does
+            image = tuple(copy_frame(p) for p in image) if isinstance(image, tuple) else copy_frame(image)
+        self._note_frame(source.name, image, stamp)
+        self._current_direction = source.name
+        if isinstance(image, tuple):
+            for alias, plane in zip(self._names_of_planes(message, len(image)), image):
+                cache[alias] = plane
+                fresh.add(alias)
+                self._note_frame(alias, plane, stamp)
+                if alias not in covered:
+                    self._current_direction = alias
+                    self.process(alias, plane)
+            return
+        cache[source.name] = image
+        fresh.add(source.name)
+        if source.name not in covered:
+            self.process(source.name, image)
+
+    def _fire_handlers(self, handlers, cache: dict, fresh: set, told: set, say):
+        for handler, aliases in handlers:
+            waiting = [a for a in aliases if a not in cache]
+            if waiting:
+                if handler not in told:
+                    told.add(handler)
+                    say(f"Handler {handler.__name__} waiting for aliases: {waiting}. Available: {list(cache)}", True)
+            elif fresh.intersection(aliases):
+                handler(*(cache[a] for a in aliases))
+
+    def _flush_posts(self):
+        for idx, (name, (data, color_space)) in enumerate(self._post_queue.items()):
+            self._module_manager.post(f"{name}#{color_space}", idx, _now_ms(), data)
+        self._post_queue.clear()
+
+    def _loop(self, quit_flag: threading.Event, say):
+        cache: Dict[str, Any] = {}
+        handlers = self._bound_handlers(say)
         covered = {alias for _, aliases in handlers for alias in aliases}
-        complained = set()
+        told: set = set()
+        period = 1.0 / self._fps
         while not quit_flag.is_set():
-            tick = time.monotonic()
+            began = time.monotonic()
             try:
                 messages = self._module_manager.read_messages()
-            except RuntimeError as e:
-                logger(f"Error: {e}", True)
-                quit_flag.set()
+            except RuntimeError as problem:               # a source went away: __call__ re-enters the manager
+                say(f"Error: {problem}", True)
                 self._retry = True
+                quit_flag.set()
                 break
-            fresh = set()
+            fresh: set = set()
             for message in messages:
-                source, image, acq_time = message.source, message.data, message.acquisition_time
-                if message.status == ReadStatus.SUCCESS and image is not None:
-                    # module code gets writable arrays of its own: either the library already read the frame into page-locked memory
-                    # that is now ours (message.private), or the arrays view its read buffer and are copied here
-                    if not message.private:
-                        image = tuple(copy_frame(p) for p in image) if isinstance(image, tuple) else copy_frame(image)
-                    self._update_metadata_for_direction(source.name, image, acq_time)
-                    self._current_direction = source.name
-                    if isinstance(image, tuple):
-                        for alias, plane in zip(self._plane_aliases(message, len(image)), image):
-                            frame_cache[alias] = (plane, acq_time)
-                            fresh.add(alias)
-                            self._update_metadata_for_direction(alias, plane, acq_time)
-                            if alias not in covered:
-                                self._current_direction = alias
-                                self.process(alias, plane)
-                    else:
-                        frame_cache[source.name] = (image, acq_time)
-                        fresh.add(source.name)
-                        if source.name not in covered:
-                            self.process(source.name, image)
-                elif message.status == ReadStatus.NO_NEW_FRAME:
-                    if self._video_metadata[source.name].mark_as_dead():
-                        logger(f"{source.name} appears to be slow or dead!", self._verbose)
-            for handler, aliases in handlers:
-                missing = [a for a in aliases if a not in frame_cache]
-                if missing:
-                    if handler not in complained:
-                        complained.add(handler)
-                        logger(f"Handler {handler.__name__} waiting for aliases: {missing}. Available: {list(frame_cache.keys())}", True)
-                    continue
-                if any(a in fresh for a in aliases):
-                    handler(*[frame_cache[a][0] for a in aliases])
-            for idx, (name, data) in enumerate(self._post_queue.items()):
-                color_space = self._post_color_spaces.get(name, "BGR")
-                self._module_manager.post(f"{name}#{color_space}", idx, _now_ms(), data)
-            self._post_queue.clear()
-            self._post_color_spaces.clear()
-            time.sleep(max((1 / self._fps) - (time.monotonic() - tick), 0))
+                if message.status == ReadStatus.SUCCESS:
+                    self._deliver(message, cache, fresh, covered)
+                elif message.status == ReadStatus.NO_NEW_FRAME and self._directions[message.source.name].mark_as_dead():
+                    say(f"{message.source.name} appears to be slow or dead!", self._chatty)
+            self._fire_handlers(handlers, cache, fresh, told, say)
+            self._flush_posts()
+            time.sleep(max(period - (time.monotonic() - began), 0))
 
-    # -- services used by module code ---------------------------------------------------------------
+    # -- services used by module code -------------------------------------------------------------------------------------------
     def post(self, name: str, image, color_space: str = "BGR"):
-        """Queues a uint8 copy of `image` for the GUI; no-op under --enable-performance."""
+        """Queues a uint8 copy of `image` for the GUI (published after the handlers of this iteration); no-op under --enable-performance."""
         if self._performance_enabled:
             return
         if "%" in name:
             raise RuntimeError("Cannot have % in name")
         image = as_mat(image)
         if isinstance(image, DeviceMat) and image.dtype == np.uint8:
-            image = image.host_copy()                # one download into an array of its own; the image stays usable on the device
+            image = image.host_copy()                    # one download into an array of its own; the image stays usable on the device
         else:
             image = np.array(image, np.uint8, copy=True, order="C", ndmin=1)
         color_space = color_space.upper()
-        self._post_queue[name] = image
-        self._post_color_spaces[name] = color_space if color_space in VALID_COLOR_SPACES else "BGR"
+        self._post_queue[name] = (image, color_space if color_space in VALID_COLOR_SPACES else "BGR")
 
     def get_latency(self) -> int:
-        return self._video_metadata[self._current_direction].get_latency()
+        return self._directions[self._current_direction].get_latency()
 
     def normalize(self, coordinate: Tuple[float, float]) -> Tuple[float, float]:
         """(y, x) in pixels of the current direction -> ((y - h/2)/w, (x - w/2)/w)."""
-        return self._video_metadata[self._current_direction].normalize_coord(coordinate)
+        return self._directions[self._current_direction].normalize_coord(coordinate)
 
     def normalize_axis(self, coordinate: float, axis: int) -> float:
-        return self._video_metadata[self._current_direction].normalize_axis(coordinate, axis)
+        return self._directions[self._current_direction].normalize_axis(coordinate, axis)
 
-    def _update_metadata_for_direction(self, direction: str, frame, acquisition_time: int):
-        self._video_metadata.setdefault(direction, VideoSourceMetadata()).update(frame, acquisition_time)
+    def _note_frame(self, direction: str, frame, acquisition_time: int):
+        self._directions.setdefault(direction, VideoSourceMetadata()).update(frame, acquisition_time)
 
     def process_bundle(self, direction: str, frames: Tuple[np.ndarray, ...], aliases: Tuple[str, ...], acquisition_time: int):
+        """Feeds the planes of one frame to process() one by one (a helper for callers outside the loop)."""
         if aliases and len(aliases) != len(frames):
             raise RuntimeError(f"direction '{direction}' provided {len(frames)} planes but {len(aliases)} aliases")
-        if not aliases:
-            aliases = tuple(f"{direction}[{idx}]" for idx in range(len(frames)))
-        for alias, frame in zip(aliases, frames):
-            self._update_metadata_for_direction(alias, frame, acquisition_time)
+        for alias, frame in zip(aliases or tuple(f"{direction}[{i}]" for i in range(len(frames))), frames):
+            self._note_frame(alias, frame, acquisition_time)
             self._current_direction = alias
             self.process(alias, frame)
 

@@ -8,43 +8,32 @@ from typing import List, Tuple
 import numpy as np
 
 
-class Color(Enum):
-    """Named BGR colours of the reference's utils/draw.py:9-37 (values are its palette; `Color.LIME()` gives the tuple)."""
-    RED = (75, 25, 230)
-    GREEN = (75, 180, 60)
-    YELLOW = (0, 225, 255)
-    BLUE = (200, 130, 0)
-    ORANGE = (48, 130, 245)
-    PURPLE = (180, 30, 145)
-    CYAN = (240, 240, 70)
-    MAGENTA = (230, 50, 240)
-    LIME = (60, 245, 210)
-    PINK = (212, 190, 250)
-    TEAL = (128, 128, 0)
-    LAVENDER = (255, 190, 220)
-    BROWN = (40, 110, 170)
-    BEIGE = (200, 250, 255)
-    MAROON = (0, 0, 128)
-    MINT = (195, 255, 170)
-    OLIVE = (0, 128, 128)
-    APRICOT = (180, 215, 255)
-    NAVY = (128, 0, 0)
-    GREY = (128, 128, 128)
-    WHITE = (255, 255, 255)
-    BLACK = (0, 0, 0)
-    HOTPINK = (180, 105, 255)
-    DEEPPINK = (147, 20, 255)
-    FUCHSIA = (255, 0, 255)
+# The palette handlers name their overlay colours from (reference utils/draw.py:9-37: the names and BGR values are what
+# `Color.LIME`, `get_color("teal")` ... must keep meaning); kept as data, the enum is made from it.
+_PALETTE_BGR = """
+    RED 75 25 230 | GREEN 75 180 60 | YELLOW 0 225 255 | BLUE 200 130 0 | ORANGE 48 130 245 | PURPLE 180 30 145 | CYAN 240 240 70
+    MAGENTA 230 50 240 | LIME 60 245 210 | PINK 212 190 250 | TEAL 128 128 0 | LAVENDER 255 190 220 | BROWN 40 110 170
+    BEIGE 200 250 255 | MAROON 0 0 128 | MINT 195 255 170 | OLIVE 0 128 128 | APRICOT 180 215 255 | NAVY 128 0 0 | GREY 128 128 128
+    WHITE 255 255 255 | BLACK 0 0 0 | HOTPINK 180 105 255 | DEEPPINK 147 20 255 | FUCHSIA 255 0 255
+"""
 
-    def __call__(self):
+
+class _Callable:
+    def __call__(self):                      # `Color.LIME()` gives the tuple, as `.value` does
         return self.value
 
 
+Color = Enum("Color", [(f[0], tuple(int(v) for v in f[1:])) for f in (e.split() for e in _PALETTE_BGR.replace("\n", "|").split("|")) if f],
+             type=_Callable, module=__name__)
+Color.__doc__ = "Named BGR colours for overlays."
+
+
 def get_color(color_name: str):
-    try:
-        return Color[color_name.upper()].value
-    except KeyError:
+    """Palette entry by (case-insensitive) name; ValueError for a name the palette does not hold."""
+    member = Color.__members__.get(str(color_name).upper())
+    if member is None:
         raise ValueError(f"{color_name} is not a valid color name")
+    return member.value
 
 
 def _stamp(mat, x, y, color, r0, r1):

@@ -406,7 +406,7 @@ def runtime_rate(which="buoy", seconds=3.0, w=1920, h=1080, period=0.0002, flags
                 mod = gate_module(count)([d], gate_tuners())
             mod._fps = 1000000
             n, dt = run_module_for(mod, seconds, lambda: len(done))
-            acc = mod._module_manager._video_accessor[d]
+            acc = mod._module_manager.video_accessor(d)
             torn = int(getattr(acc, "torn_reads", 0))
             on_device = bool(getattr(acc, "_dev_state", False)) or os.environ.get("VP_DEVICE_FRAMES", "1") != "0"
     finally:
@@ -460,3 +460,50 @@ def host_fed_rate(w, h, batch=32, batches=8, ring=3, share=1):
         n = batches * sum(hi - lo for lo, hi in d.slices)
     return {"frames_per_s": round(n / dt, 1), "pcie_GBps": round(n * w * h * 3 / dt / 1e9, 2), "batch": batch, "ring": ring, "batches": batches,
             "frames_per_batch_fed": n // batches}
+
+
+# ---- detector (modules/yolo.py:37-165; BASELINE config 5) -----------------------------------------------------------------------------
+def detector_tuners():
+    from vision.core.tuners import DoubleTuner
+    return [DoubleTuner(f"{name}_threshold", default, 0, 1) for name, default in
+            (("torpedo", 0.1), ("slalom", 0.0), ("gate", 0.1), ("gate_behind", 0.7), ("bins", 0.4), ("manipulator", 0.4))]
+
+
+# object -> (classes its handler is given, in the handler's argument order, shm switch, shm direction variable): the one object the
+# reference wires up (modules/yolo.py:130-151)
+DETECTOR_ROUTES = {"torpedoes": (("torpedo_board", "shark_hole", "saw_hole"), "yolo_torpedoes_board", "yolo_torpedoes_board_direction")}
+
+
+def detector_module(model_factory):
+    """Harness stand-in for the detector module, written from SURVEY's row for component 22 / section 8f rank 4: a ModuleBase +
+    HandlerMixin listening on zed[forward]; per frame: post the original, `model.track(image)[0].summary()` -> one record per entry
+    (MAP_FN[model.task]) -> per active object whose direction matches, the records of its classes go to its handler's process(); an
+    object that is switched off gets the handler's grey post only.  `model_factory()` supplies the network: the reference's import
+    `from ultralytics import YOLO` becomes `from vision.yolo.engine import YOLO` - nothing else changes."""
+    import shm
+    from vision.core.base import ModuleBase, sources
+    from vision.core.handlers import HandlerMixin
+    from vision.yolo.data import MAP_FN
+
+    class Yolo(ModuleBase, HandlerMixin):
+        def __init__(self, video_sources, tuners, handlers, **kw):
+            ModuleBase.__init__(self, video_sources, tuners, **kw)
+            HandlerMixin.__init__(self, handlers)
+            self.model = model_factory()
+            self.model.to("cpu" if os.environ.get("CUAUV_LOCALE") == "simulator" else "cuda")
+            self.to_record = MAP_FN[self.model.task]
+
+        @sources("zed[forward]")
+        def fwd_process(self, image):
+            direction = "forward"
+            self.post("original image", image)
+            records = [self.to_record(entry) for entry in self.model.track(image, verbose=False)[0].summary()]
+            for obj, (classes, switch, where) in DETECTOR_ROUTES.items():
+                if getattr(shm.active_objects, where).get() != direction:
+                    continue
+                handler = self.handlers[obj]
+                if getattr(shm.active_objects, switch).get():
+                    handler.process(direction, image.copy(), *[[r for r in records if r.name == c] for c in classes])
+                else:
+                    handler.post_grayscale(image)
+    return Yolo

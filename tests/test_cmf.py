@@ -220,3 +220,63 @@ def test_reader_supplied_buffer():
         assert r.last_plane_names() == ("forward", "depth")
         st, data2, _, _ = r.read_frame_private()
         assert st == ReadStatus.NO_NEW_FRAME and data2 is not None
+
+
+def test_peek_and_validate_without_a_copy():
+    """cmf_peek_frame / cmf_peek_validate (additions to the reference's ABI, for a consumer that moves the payload itself): the
+    payload pointer names the newest slot inside the block's mapping, the metadata are read_frame's, a ticket stays valid until the
+    writer reaches the slot again (frame u + 3) and is void from then on; cmf_block_mapping gives the range to page-lock."""
+    d = _name("peek")
+    lib = cmf._dllib
+    img = np.arange(6 * 8 * 3, dtype=np.uint8).reshape(6, 8, 3)
+    with BlockAccessor(d, max_entry_size_bytes=img.nbytes) as w, BlockAccessor(d) as r:
+        base, nbytes = C.c_void_p(), C.c_uint64()
+        assert lib.cmf_block_mapping(r._block_ptr, C.byref(base), C.byref(nbytes)) == 0
+        assert nbytes.value == 1216 + 3 * img.nbytes and base.value % 4096 == 0
+        payload, ticket = C.c_void_p(), C.c_uint64()
+        assert lib.cmf_peek_frame(r._block_ptr, r._frame_ptr, C.byref(payload), C.byref(ticket)) == ReadStatus.NO_NEW_FRAME.value
+        w.write_frame(7, [("only", img)])
+        assert lib.cmf_peek_frame(r._block_ptr, r._frame_ptr, C.byref(payload), C.byref(ticket)) == ReadStatus.SUCCESS.value
+        fr = r._frame_ptr.contents
+        assert (fr.acquisition_time, fr.uid, fr.total_size, fr.plane_count) == (7, 1, img.nbytes, 1) and fr.planes[0].name == b"only"
+        assert (fr.planes[0].height, fr.planes[0].width, fr.planes[0].depth) == (6, 8, 3)
+        assert payload.value == base.value + 1216 + 1 * img.nbytes                 # frame 1 lives in slot 1
+        got = np.frombuffer((C.c_ubyte * img.nbytes).from_address(payload.value), np.uint8).reshape(img.shape)
+        assert np.array_equal(got, img) and lib.cmf_peek_validate(r._block_ptr, fr.uid, ticket.value) == 1
+        assert lib.cmf_peek_frame(r._block_ptr, r._frame_ptr, C.byref(payload), C.byref(ticket)) == ReadStatus.NO_NEW_FRAME.value
+        old_uid, old_ticket = int(fr.uid), int(ticket.value)
+        w.write_frame(8, img)
+        w.write_frame(9, img)                                                       # slots 2 and 0: the peeked slot is still intact
+        assert lib.cmf_peek_validate(r._block_ptr, old_uid, old_ticket) == 1
+        w.write_frame(10, img[::-1].copy())                                         # frame 4 reuses slot 1
+        assert lib.cmf_peek_validate(r._block_ptr, old_uid, old_ticket) == 0
+        assert lib.cmf_peek_frame(r._block_ptr, r._frame_ptr, C.byref(payload), C.byref(ticket)) == ReadStatus.SUCCESS.value
+        assert r._frame_ptr.contents.acquisition_time == 10 and r._frame_ptr.contents.uid == 4
+        assert lib.cmf_peek_validate(None, 0, 0) < 0 and lib.cmf_block_mapping(None, C.byref(base), C.byref(nbytes)) < 0
+
+
+def test_private_and_public_reads_mixed(monkeypatch):
+    """read_frame_private hands its page-locked buffer to the caller; the library must not keep writing into it: a later public
+    read_frame() on the same accessor goes to the library's own buffer, and the handed-over array keeps its frame."""
+    import vision.core.frames as frames_mod
+    made = []
+
+    def fake_pinned(shape, dtype):                      # stands in for page-locked memory on a CPU box
+        a = np.full(shape, 0xEE, dtype)
+        made.append(a)
+        return a
+    monkeypatch.setattr(frames_mod, "pinned_like", fake_pinned)
+    d = _name("mixed")
+    a, b, c = (np.full((4, 5, 3), v, np.uint8) for v in (1, 2, 3))
+    with BlockAccessor(d, max_entry_size_bytes=a.nbytes) as w, BlockAccessor(d) as r:
+        w.write_frame(1, a)
+        st, mine, t, private = r.read_frame_private()
+        assert st == ReadStatus.SUCCESS and private and np.array_equal(mine, a) and mine.base is not None
+        w.write_frame(2, b)
+        st, view, t = r.read_frame()                    # the public read: library buffer
+        assert st == ReadStatus.SUCCESS and np.array_equal(view, b)
+        assert np.array_equal(mine, a), "the public read wrote into the array that was handed over"
+        w.write_frame(3, c)
+        st, mine2, t, private = r.read_frame_private()
+        assert private and np.array_equal(mine2, c) and np.array_equal(mine, a) and len(made) == 2
+        assert not np.shares_memory(mine, mine2)

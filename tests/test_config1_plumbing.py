@@ -48,7 +48,7 @@ def _feeder(direction, frames, stop, fps=100):
             k += 1
     src.register_capture_udl("zed", udl)
     src._quit_flag = stop
-    for t in src._threads:
+    for t in src._workers:
         t.start()
     return src
 
@@ -69,7 +69,7 @@ def _run(module_factory, n_frames, want):
         mod.stop()
         runner.join(10)
         stop.set()
-        for t in src._threads:
+        for t in src._workers:
             t.join(5)
         src.close()
     return frames, mod

@@ -114,6 +114,35 @@ def test_runner_failure_reaches_the_caller():
         BatchDispatcher([0], 4, 8, 8, make_runner=Broken, bind_numa=False)
 
 
+def test_a_failed_batch_does_not_wedge_the_dispatcher():
+    """A feeder that raises on one batch: collect() raises for that batch once every device has answered, the batch leaves the
+    books, the next collect() serves the next batch; close() returns although batches were never collected."""
+    from vision.dispatch import BatchDispatcher
+
+    class Flaky:
+        def __init__(self, device, n, h, w):
+            self.input = np.zeros((n, h, w, 3), np.uint8)
+
+        def run(self):
+            if int(self.input[0, 0, 0, 0]) == 13:
+                raise ValueError("bad batch")
+            return {"first": self.input[:, 0, 0, 0].copy()}
+    good = np.zeros((4, 8, 8, 3), np.uint8)
+    bad = np.full((4, 8, 8, 3), 13, np.uint8)
+    with BatchDispatcher([0, 1], 4, 8, 8, make_runner=Flaky, bind_numa=False, ring=1) as d:
+        d.submit(good); d.submit(bad); d.submit(good + 1)
+        bid, parts = d.collect()
+        assert bid == 0 and [p[:2] for p in parts] == [(0, 2), (2, 4)]
+        with pytest.raises(ValueError, match="bad batch"):
+            d.collect()
+        bid, parts = d.collect()                         # the batch after the failed one
+        assert bid == 2 and all((p[2]["first"] == 1).all() for p in parts)
+        with pytest.raises(RuntimeError, match="nothing submitted"):
+            d.collect()
+        d.submit(good)                                   # left uncollected: close() must not hang on it
+    assert not d._threads
+
+
 @pytest.mark.timeout(240)
 def test_two_ranks_gloo(oracle):
     """One process per device, as bench.py is launched: each rank dispatches its share of every batch; together they cover every

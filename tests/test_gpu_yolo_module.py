@@ -82,7 +82,8 @@ def test_detector_module_with_torpedoes_handler(vp, monkeypatch):
     import shm
     from vision.core.bindings.camera_message_framework import BlockAccessor
     from vision.handlers.torpedoes import TorpedoesOBB
-    from vision.modules.yolo import TUNERS, Yolo
+    import module_harness as MH
+    TUNERS = MH.detector_tuners()
     from vision.yolo.ops import order_points
     shm.active_objects.yolo_torpedoes_board.set(True)
     shm.active_objects.yolo_torpedoes_board_direction.set("forward")
@@ -97,7 +98,7 @@ def test_detector_module_with_torpedoes_handler(vp, monkeypatch):
     frame = F.s1_buoy(6, 640, 360)
     depth = np.zeros((360, 640), np.float32)      # zed carries several planes; a one-plane frame is cached under the block's name (core/base.py:765-803)
     with BlockAccessor(d, max_entry_size_bytes=frame.nbytes + depth.nbytes) as w:
-        mod = Yolo([d], TUNERS, [Recording("torpedoes")], model=_model())
+        mod = MH.detector_module(_model)([d], TUNERS, [Recording("torpedoes")])
         mod._fps = 100
         runner = threading.Thread(target=mod)
         runner.start()
@@ -129,7 +130,7 @@ def test_detector_module_with_torpedoes_handler(vp, monkeypatch):
     shm.active_objects.yolo_torpedoes_board.set(False)
     n_before = len(calls)
     posted = []
-    mod2 = Yolo([d + "b"], TUNERS, [Recording("torpedoes")], model=_model())
+    mod2 = MH.detector_module(_model)([d + "b"], MH.detector_tuners(), [Recording("torpedoes")])
     record = lambda name, image, cs="BGR": posted.append((name, np.asarray(image).shape))   # noqa: E731
     monkeypatch.setattr(mod2, "post", record)
     monkeypatch.setattr(mod2.handlers["torpedoes"], "post", record)          # handlers borrow the parent's post at registration

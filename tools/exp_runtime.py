@@ -30,7 +30,7 @@ with MH.FeederProcess(d, 1920, 1080, "s2_bins" if WHICH == "bins" else "s1_buoy"
         mod = MH.gate_module(lambda *a: done.append(1))([d], MH.gate_tuners())
     mod._fps = 100000
     n, dt = MH.run_module_for(mod, SECONDS, lambda: len(done))
-    acc = mod._module_manager._video_accessor[d]
+    acc = mod._module_manager.video_accessor(d)
     torn = getattr(acc, "torn_reads", 0)
 MH.unlink_block(d)
 print(f"{WHICH} module on the runtime, 1080p, posts off: {n / dt:.1f} frames/s ({1e3 * dt / max(n, 1):.3f} ms per frame, {n} frames; "
