@@ -33,6 +33,7 @@
 #include "vp_internal.h"
 #include "vp_ccl_dev.h"
 #include <limits.h>
+#include <cstdio>
 #include <string.h>
 #include <cstdlib>
 #include <algorithm>
@@ -60,6 +61,8 @@ size_t vp_ccl_nids(int w, int h)
 
 // strips of the strip-local pass never exceed h / 8 + 1 (ccl_make_geom picks 8, 16 or 32 rows)
 static size_t c2_strips_max(int h) { return (size_t)(h + 7) / 8; }
+static size_t c3_strips_cap(int h) { return (size_t)(h + 1) / 2 + 2; }   // vp_ccl3.inl: strips of at least 2 rows, + 1 boundary slot
+#define C3_STATE_BYTES 48
 
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
 {
@@ -68,7 +71,8 @@ size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
     return vp_align(nids * 4 * n) * 2 + vp_align(nids / 8 * n) * 2 + vp_align(sizeof(ccl_acc) * (size_t)max_labels * n) +
            vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) +
            vp_align(ns * 4) + vp_align(ns * C2_RC * sizeof(contrib)) + vp_align(ns * sizeof(c2_box)) + vp_align(ns * C2_RC * 4) +
-           vp_align((size_t)n * 4) + 4096;
+           vp_align((size_t)n * 4) + 2 * vp_align(nids / 8 * n) + vp_align((size_t)n * 4) + 256 + vp_align((size_t)n * C3_STATE_BYTES) +
+           vp_align((size_t)n * c3_strips_cap(h) * 12) + 4096;
 }
 
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out)
@@ -87,12 +91,18 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->c2_bgbox = vp_ws_take(ctx, ns * sizeof(c2_box));
     out->c2_label = (u32*)vp_ws_take(ctx, ns * C2_RC * 4);
     out->c2_crowded = (u32*)vp_ws_take(ctx, (size_t)n * 4);
+    out->c3_child = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    out->c3_lroot = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    out->c3_clist = (u32*)vp_ws_take(ctx, (size_t)n * 4);
+    out->c3_ncrowded = (u32*)vp_ws_take(ctx, 4);
+    out->c3_state = vp_ws_take(ctx, (size_t)n * C3_STATE_BYTES);
+    out->c3_barr = (u32*)vp_ws_take(ctx, (size_t)n * c3_strips_cap(h) * 12);   // per frame: boundary arrivals | boundaries done per strip | roots per strip
 }
 
 bool vp_ccl_ws_ok(const vp_ccl_ws& ws)
 {
     return ws.parent && ws.seglabel && ws.flags && ws.prefix && ws.acc && ws.wordlabel && ws.bgpart && ws.c2_ncomp && ws.c2_recs &&
-           ws.c2_bgbox && ws.c2_label && ws.c2_crowded;
+           ws.c2_bgbox && ws.c2_label && ws.c2_crowded && ws.c3_child && ws.c3_lroot && ws.c3_clist && ws.c3_ncrowded && ws.c3_state && ws.c3_barr;
 }
 
 // ---- whole-image global-memory path (fallback for images too wide for the LDS strip kernel) ---------------
@@ -597,6 +607,7 @@ static void ccl_make_geom(ccl_geom& G, int w, int h, int numbering, int invert, 
     if (const char* e = getenv("VP_CL_ROWS")) { const int r = atoi(e); if ((r == 8 || r == 16 || r == 32) && ((u32)r * (u32)G.wb) % 32u == 0) G.rows = r; }
 }
 
+#include "vp_ccl3.inl"
 #include "vp_ccl2.inl"
 
 // LDS of the strip-local kernels: lbits | wbase | lparent | lgid (| lmin when it cannot share wbase's words)
@@ -681,25 +692,75 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
                            (G.rows % WR_ROWS) == 0 && (G.rows % 8) == 0 && (size_t)strips <= c2_strips_max(h);
     if (two_level) {
         const int mcap = (ctx->ccl_mcap >= 0 && ctx->ccl_mcap < C2_MCAP) ? ctx->ccl_mcap : C2_MCAP;
+        // frames the merge hands over go to the crowded-frame kernels of vp_ccl3.inl when the geometry suits them (it does for every
+        // frame up to 8192 px wide), otherwise to the one-level kernels
+        c3_plan P3 = c3_make_plan(G);
+        static const bool c3_off = getenv("VP_CCL3") && atoi(getenv("VP_CCL3")) == 0;
+        size_t lds3a = 0, lds3b = 0;
+        if (P3.ok && !c3_off && (size_t)P3.strips + 1 <= c3_strips_cap(h) && sizeof(c3_state) == C3_STATE_BYTES) {
+            lds3a = c3_link_lds(G, P3);
+            lds3b = c3_label_lds(G, P3);
+            static size_t attr_a = 0, attr_b = 0;      // (grow-only; kernels accept more dynamic LDS than the 64 KB default once told so)
+            if (lds3a > attr_a) { if (hipFuncSetAttribute((const void*)k_ccl3_link, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3a) == hipSuccess) attr_a = lds3a; else { (void)hipGetLastError(); P3.ok = 0; } }
+            if (P3.ok && lds3b > attr_b) { if (hipFuncSetAttribute((const void*)k_ccl3_label, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3b) == hipSuccess) attr_b = lds3b; else { (void)hipGetLastError(); P3.ok = 0; } }
+        } else {
+            P3.ok = 0;
+        }
+        const int c3_strips = P3.ok ? P3.strips : 0;
+        if (P3.ok && getenv("VP_CCL3_OCC")) {   // diagnosis: blocks per CU the runtime grants the crowded-frame kernels
+            int oa = 0, ob = 0;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link, C3_LINK_THREADS, lds3a);
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label, C3_LABEL_THREADS, lds3b);
+            hipFuncAttributes fa, fb2;
+            hipFuncGetAttributes(&fa, (const void*)k_ccl3_link); hipFuncGetAttributes(&fb2, (const void*)k_ccl3_label);
+            fprintf(stderr, "ccl3 occupancy: link %d blocks/CU (LDS %zu + %zu static, %d regs), label %d blocks/CU (LDS %zu + %zu static, %d regs), CUs %d\n", oa, lds3a, fa.sharedSizeBytes, fa.numRegs, ob, lds3b, fb2.sharedSizeBytes, fb2.numRegs, ctx->num_cu);
+        }
         { vp_prof_scope ps(ctx, VPK_CCL2_LOCAL);
           hipLaunchKernelGGL(k_ccl2_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds2, s, d_bits, G, strips, (int)cap2, (int)rc, (int)tail_words, ws.c2_ncomp,
-                             (contrib*)ws.c2_recs, (c2_box*)ws.c2_bgbox, ws.wordlabel, ws.seglabel); }
+                             (contrib*)ws.c2_recs, (c2_box*)ws.c2_bgbox, ws.wordlabel, ws.seglabel, ws.c3_ncrowded); }
         { vp_prof_scope ps(ctx, VPK_CCL2_MERGE);
           hipLaunchKernelGGL(k_ccl2_merge, dim3((unsigned)n), dim3(C2_THREADS), 0, s, d_bits, G, strips, mcap, ws.c2_ncomp, (const contrib*)ws.c2_recs,
-                             (const c2_box*)ws.c2_bgbox, ws.wordlabel, ws.seglabel, ws.c2_label, ws.c2_crowded, d_nlabels, d_stats, d_centroids, max_labels); }
+                             (const c2_box*)ws.c2_bgbox, ws.wordlabel, ws.seglabel, ws.c2_label, ws.c2_crowded, d_nlabels, d_stats, d_centroids, max_labels,
+                             ws.c3_ncrowded, ws.c3_clist, (c3_state*)ws.c3_state, ws.c3_barr, c3_strips); }
         VP_HIP(ctx, hipGetLastError());
-        // Crowded frames: the one-level kernels.  They are launched whatever the frames hold (the flags live on the device) and leave
-        // at once for frames the merge resolved: five launches of about 2.5 us each.  (On a side stream beside the label write they
-        // cost more, not less: their blocks compete with the write's for dispatch - 647 against 638 us per step of 128 frames.)
-        int rc2 = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags, ws.c2_crowded);
-        if (rc2 == VP_OK) rc2 = ccl_one_level_tail(ctx, d_bits, G, n, ws, d_stats, d_centroids, max_labels, d_nlabels, ws.c2_crowded);
-        if (rc2 != VP_OK) return rc2;
+        static const int c3_dbg = getenv("VP_CCL3_DBG") ? atoi(getenv("VP_CCL3_DBG")) : 0;   // timing experiments only: parts of the kernels skipped
+        static const int c3_dry = getenv("VP_CCL3_DRY") ? atoi(getenv("VP_CCL3_DRY")) : 0;   // experiments: 1 no launches, 2 no link, 3 no label
+        if (P3.ok && c3_dry != 1) {
+            // two launches that read the list of handed-over frames and leave at once when it is empty (the usual case)
+            if (c3_dry != 2) { vp_prof_scope ps(ctx, VPK_CCL_LOCAL);
+              hipLaunchKernelGGL(k_ccl3_link, dim3((unsigned)(ctx->num_cu * 4)), dim3(C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, ws.c3_barr, (ccl_acc*)ws.acc, max_labels, c3_dbg); }
+            { vp_prof_scope ps(ctx, VPK_CCL_RANK);
+              hipLaunchKernelGGL(k_ccl3_rank, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.prefix, ws.c3_barr, ws.c3_lroot, ws.parent); }
+            if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
+              hipLaunchKernelGGL(k_ccl3_label, dim3((unsigned)(ctx->num_cu * 2)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+                                 ws.flags, ws.c3_child, ws.prefix, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
+                                 d_centroids, c3_dbg); }
+            if (d_stats || d_centroids) {
+                vp_prof_scope ps(ctx, VPK_CCL_FINAL);
+                hipLaunchKernelGGL(k_ccl3_rows, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.c3_child, ws.prefix,
+                                   ws.c3_barr, (const c3_state*)ws.c3_state, (const ccl_acc*)ws.acc, max_labels, d_stats, d_centroids);
+            }
+            VP_HIP(ctx, hipGetLastError());
+        } else if (!P3.ok) {
+            // the one-level kernels, launched whatever the frames hold (the flags live on the device); they leave at once for frames the merge resolved
+            int rc2 = ccl_roots(ctx, d_bits, G, n, ws.parent, ws.flags, ws.c2_crowded);
+            if (rc2 == VP_OK) rc2 = ccl_one_level_tail(ctx, d_bits, G, n, ws, d_stats, d_centroids, max_labels, d_nlabels, ws.c2_crowded);
+            if (rc2 != VP_OK) return rc2;
+        }
+        if (c3_dry == 4) {   // diagnosis: which frames were handed over, and why
+            std::vector<u32> cr(n), nc((size_t)n * strips);
+            hipStreamSynchronize(s);
+            hipMemcpy(cr.data(), ws.c2_crowded, (size_t)n * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(nc.data(), ws.c2_ncomp, (size_t)n * strips * 4, hipMemcpyDeviceToHost);
+            for (int f = 0; f < n; f++)
+                if (cr[f]) { fprintf(stderr, "crowded frame %d of %d:", f, n); for (int k = 0; k < strips; k++) fprintf(stderr, " %u", nc[(size_t)f * strips + k]); fprintf(stderr, "\n"); }
+        }
         if (d_labels) {
             vp_prof_scope ps(ctx, VPK_CCL2_WRITE);
             const dim3 wr_grid((unsigned)((h + WR_ROWS - 1) / WR_ROWS), (unsigned)n);
-            static const int wv = getenv("VP_WR_VARIANT") ? atoi(getenv("VP_WR_VARIANT")) : 0;
-            if (wv == 3) hipLaunchKernelGGL(k_ccl2_write<3>, wr_grid, dim3(256), 0, s, d_bits, G, strips, (int)rc, ws.seglabel, ws.wordlabel, ws.c2_label, ws.c2_crowded, d_labels, gpr, magic);
-            else hipLaunchKernelGGL(k_ccl2_write<0>, wr_grid, dim3(256), 0, s, d_bits, G, strips, (int)rc, ws.seglabel, ws.wordlabel, ws.c2_label, ws.c2_crowded, d_labels, gpr, magic);
+            hipLaunchKernelGGL(k_ccl2_write<0>, wr_grid, dim3(256), 0, s, d_bits, G, strips, (int)rc, ws.seglabel, ws.wordlabel, ws.c2_label, ws.c2_crowded, d_labels, gpr, magic,
+                               P3.ok ? 1 : 0);
         }
         VP_HIP(ctx, hipGetLastError());
         return VP_OK;
@@ -737,6 +798,25 @@ extern "C" int vp_debug_probe(double* out32)
         }
     std::fill(h.begin(), h.end(), 0u);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_c2_probe), h.data(), h.size() * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef VP_PROBE
+// crowded-frame kernels: out[k * 16 + i] = ticks (10 ns) of phase i summed over blocks and items, out[k * 16 + 15] = blocks that ran
+extern "C" int vp_debug_probe3(double* out32)
+{
+    static std::vector<unsigned long long> h((size_t)2 * 2048 * 16);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_c3_probe), h.size() * 8) != hipSuccess) return -1;
+    for (int i = 0; i < 32; i++) out32[i] = 0;
+    for (int k = 0; k < 2; k++)
+        for (int b = 0; b < 2048; b++) {
+            const unsigned long long* r = &h[((size_t)k * 2048 + b) * 16];
+            unsigned long long t = 0;
+            for (int i = 0; i < 15; i++) { out32[k * 16 + i] += (double)r[i]; t += r[i]; }
+            if (t) out32[k * 16 + 15] += 1;
+        }
+    std::fill(h.begin(), h.end(), 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_c3_probe), h.data(), h.size() * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -48,10 +48,11 @@ __device__ unsigned int g_c2_probe[2][C2_PROBE_BLOCKS][16];
 // accumulators of rc components (44 B each)
 __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits, ccl_geom G, int strips, int cap, int rc, int tail_words,
                                                     u32* __restrict__ ncomp, contrib* __restrict__ recs, c2_box* __restrict__ bgbox,
-                                                    u32* __restrict__ wordcomp, u32* __restrict__ segcomp)
+                                                    u32* __restrict__ wordcomp, u32* __restrict__ segcomp, u32* __restrict__ c3_ncrowded)
 {
     extern __shared__ __attribute__((aligned(16))) u64 cl_lds[];
     __shared__ u64 m_nz[CL_ROWS], m_ones[CL_ROWS], m_b63[CL_ROWS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *c3_ncrowded = 0u;   // the list k_ccl2_merge appends the frames it hands over to (vp_ccl3.inl)
     __shared__ u32 rowoff[CL_ROWS + 1];
     __shared__ u32 wsum[4];
     __shared__ u32 nroots_s, nqueue_s;
@@ -442,7 +443,9 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
                                                            const c2_box* __restrict__ bgbox, const u32* __restrict__ wordcomp,
                                                            const u32* __restrict__ segcomp, u32* __restrict__ complabel,
                                                            u32* __restrict__ crowded, int32_t* __restrict__ nlabels,
-                                                           int32_t* __restrict__ stats, double* __restrict__ cent, int max_labels)
+                                                           int32_t* __restrict__ stats, double* __restrict__ cent, int max_labels,
+                                                           u32* __restrict__ c3_ncrowded, u32* __restrict__ c3_clist, c3_state* __restrict__ c3_st,
+                                                           u32* __restrict__ c3_barr, int c3_strips)
 {
     __shared__ u32 sbase[C2_MAXSTRIPS + 1];
     __shared__ u32 wtot[C2_THREADS / 64];
@@ -487,7 +490,20 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     if (tid == 0) { tot_sx = 0; tot_sy = 0; tot_area = 0; bgs.minx = INT_MAX; bgs.maxx = INT_MIN; bgs.miny = INT_MAX; bgs.maxy = INT_MIN; }
     const bool any_dense = __syncthreads_or(dense);
     if (any_dense || C > (u32)mcap) {
-        if (tid == 0) crowded[f] = 1u;
+        // handed over: to the crowded-frame kernels (c3_strips > 0: their per-frame counters start from zero, the frame joins their
+        // list) or to the one-level kernels
+        if (c3_strips > 0)
+            for (int k = tid; k < 2 * (c3_strips + 1); k += C2_THREADS) c3_barr[(size_t)f * 3 * (c3_strips + 1) + k] = 0u;   // arrivals per boundary, boundaries done per strip
+        if (tid == 0) {
+            crowded[f] = 1u;
+            if (c3_strips > 0) {
+                c3_state z;
+                z.bdone = 0; z.ddone = 0; z.fg_area = 0; z.pad = 0; z.fg_sx = 0; z.fg_sy = 0;
+                z.bg_minx = INT_MAX; z.bg_maxx = INT_MIN; z.bg_miny = INT_MAX; z.bg_maxy = INT_MIN;
+                c3_st[f] = z;
+                c3_clist[atomicAdd(c3_ncrowded, 1u)] = (u32)f;
+            }
+        }
         return;
     }
     if (tid == 0) crowded[f] = 0u;
@@ -705,9 +721,11 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
 template <int VARIANT>
 __global__ __launch_bounds__(256, 8) void k_ccl2_write(const u64* __restrict__ bits, ccl_geom G, int strips, int rc, const u32* __restrict__ segcomp,
                                                     const u32* __restrict__ wordcomp, const u32* __restrict__ complabel,
-                                                    const u32* __restrict__ crowded, int32_t* __restrict__ labels, u32 gpr, u32 gpr_magic)
+                                                    const u32* __restrict__ crowded, int32_t* __restrict__ labels, u32 gpr, u32 gpr_magic,
+                                                    int crowded_elsewhere)
 {
     __shared__ u32 ltab[C2_RC];
+    if (crowded_elsewhere && crowded[blockIdx.y]) return;   // block-uniform: the crowded-frame kernels wrote this frame's labels themselves
     const u32 f = blockIdx.y;
     const u32 y0 = blockIdx.x * WR_ROWS;
     const u32 nrows = min((u32)WR_ROWS, (u32)G.h - y0);

@@ -1,0 +1,809 @@
+// Labelling of CROWDED frames (included by vp_ccl.hip): masks the two-level path of vp_ccl2.inl hands over - speckle, raw noise, a
+// threshold mask nobody cleaned (modules/red_buoy.py:38 runs its contour stage on the un-cleaned mask).
+//
+// Round 1's one-level kernels resolved such frames with arrays indexed by segment id in global memory: strips with more segments
+// than a 962-entry LDS union-find fell back to compare-and-swap unions in global memory (5.9 ms per 128 frames of 50 % noise), and
+// every segment paid four dependent uncoalesced reads plus seven global atomics for its statistics (1.9 - 3.5 ms).  Here:
+//
+//   * strips are R rows with R * ceil(w/2) <= 8192 segment ids (1080p: 8 rows), so a strip's union-find ALWAYS fits in LDS - it is
+//     indexed by the strip-relative segment id itself, no compaction, no capacity fallback; links point at the smaller id, so a
+//     strip-local root is its component's smallest id (cv2's numbering key, section 4.3 of DESIGN.md);
+//   * what leaves the strip is one contiguous block of u16 "root of every segment id" (15 KB) and the bits of its local roots;
+//   * strips meet at their boundaries through a global union-find over LOCAL ROOTS only (a few per boundary once repeated pairs are
+//     dropped); a root that absorbs another is marked "has members elsewhere";
+//   * ranks (= labels) come from the root bitmap + popcount prefix as before;
+//   * a second pass per strip reloads the strip's u16 block into LDS and does everything else there: labels of the local roots
+//     (from the strip's own slice of bitmap + prefix; only absorbed roots walk global memory), statistics accumulated in LDS per
+//     local component, rows of components that are complete within the strip written straight to the output (no atomics), the rest
+//     added to per-label accumulators, and the strip's part of the label image stored from LDS.
+//
+// No block ever waits for another: a boundary is processed by whichever of its two strips finishes second (an arrival counter),
+// the ranks of a frame by the block that finishes its last boundary, the rows of multi-strip components by the block that finishes
+// the frame's last strip.  Two launches (k_ccl3_link, k_ccl3_label) replace the five one-level ones; both read the list of crowded
+// frames k_ccl2_merge made and leave at once when it is empty (grid = a fixed number of blocks that loop over the work).
+#define C3_IDS 8192            // segment ids per strip = entries of the LDS union-find
+#define C3_LINK_THREADS 256
+#define C3_LABEL_THREADS 512
+#define C3_ACC 512             // local components whose statistics are accumulated per pass over the strip (= C3_LABEL_THREADS)
+#define C3_TAB 128             // entries of a strip's table of partial components (beyond it: straight to global memory)
+static_assert(C3_ACC == C3_LABEL_THREADS, "the emission step of k_ccl3_label maps one thread to one local root of a pass");
+#define C3_MAX_STRIPS 1024     // per-strip root counts of a frame are scanned in LDS by every block of the later launches
+
+#ifdef VP_PROBE   // measurement builds only: time per phase (100 MHz wall clock ticks), summed over a block's items
+__device__ unsigned long long g_c3_probe[2][2048][16];
+#define C3_PROBE_DECL __shared__ unsigned long long pr_acc[16]; unsigned long long pr_t = 0; if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; q_++) pr_acc[q_] = 0; pr_t = wall_clock64(); }
+#define C3_PROBE(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); pr_acc[i] += n_ - pr_t; pr_t = n_; } } while (0)
+#define C3_PROBE_END(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) for (int q_ = 0; q_ < 16; q_++) g_c3_probe[k][blockIdx.x][q_] = pr_acc[q_]; } while (0)
+#else
+#define C3_PROBE_DECL do { } while (0)
+#define C3_PROBE(i) do { } while (0)
+#define C3_PROBE_END(k) do { } while (0)
+#endif
+
+struct c3_state {              // per frame; zeroed by k_ccl2_merge when it hands the frame over
+    u32 bdone, ddone;          // boundaries processed / strips labelled
+    u32 fg_area, pad;
+    u64 fg_sx, fg_sy;
+    int bg_minx, bg_maxx, bg_miny, bg_maxy;
+};
+
+struct c3_plan {
+    int R, strips;             // rows per strip (even), strips per frame
+    u32 ids;                   // R * wb: multiple of 32, <= C3_IDS
+    int ok;
+};
+
+static c3_plan c3_make_plan(const ccl_geom& G)
+{
+    c3_plan P = {0, 0, 0, 0};
+    for (int R = 32; R >= 2; R >>= 1) {
+        const u32 ids = (u32)R * (u32)G.wb;
+        if (ids <= C3_IDS && (ids % 32u) == 0 && R * G.ww <= 512) { P.R = R; P.ids = ids; break; }
+    }
+    if (!P.R || G.ww > 64) return P;
+    P.strips = (G.h + P.R - 1) / P.R;
+    P.ok = P.strips <= C3_MAX_STRIPS ? 1 : 0;
+    return P;
+}
+static size_t c3_max_strips(int h) { return (size_t)(h + 1) / 2 + 1; }
+
+// strip-relative segment id of the segment starting at pixel x of strip row r (strips start at even rows, so r and y have the same parity)
+__device__ __forceinline__ u32 c3_rel(const ccl_geom& G, int r, int x)
+{
+    if (G.numbering == VP_CCL_BLOCK2X2) return (((u32)(r >> 1) * (u32)G.wb + (u32)(x >> 1)) << 1) | (u32)(r & 1);
+    return (u32)r * (u32)G.wb + (u32)(x >> 1);
+}
+
+// Data one workgroup hands to another inside a launch (cdna_hip_programming.md Guideline 16): it is stored write-through
+// (agent-scope relaxed atomic stores = `sc1` stores: they do not linger in the writer's XCD-local L2) and read with agent-scope
+// relaxed atomic loads (`sc1` loads: they do not hit a stale line), so neither side needs a release / acquire fence - a fence at
+// agent scope writes back or invalidates a whole L2, and with a thousand workgroups doing that per strip it was 2.5 ms of a 3 ms
+// launch.  What remains of "publish": every wave waits for its stores, the workgroup meets, then one lane bumps the counter.
+__device__ __forceinline__ void c3_publish()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+__device__ __forceinline__ unsigned short c3_ld16(const u32* words, u32 idx)   // entry idx of a u16 array kept as u32 pairs
+{
+    return (unsigned short)(ld_rlx(words + (idx >> 1)) >> ((idx & 1u) * 16u));
+}
+
+// links the larger root under the smaller (global memory, device-scope CAS): the absorbed root loses its bit in the root bitmap,
+// the absorbing one is marked as having members outside its own strip-local component
+__device__ __forceinline__ void c3_unite(u32* p, u32* flags, u32* child, u32 a, u32 b)
+{
+    for (;;) {
+        a = uf_find_halve(p, a);
+        b = uf_find_halve(p, b);
+        if (a == b) return;
+        if (a < b) { const u32 t = a; a = b; b = t; }
+        const u32 old = atomicCAS(p + a, a, b);
+        if (old == a) {
+            atomicAnd(flags + (a >> 5), ~(1u << (a & 31)));
+            atomicOr(child + (b >> 5), 1u << (b & 31));
+            return;
+        }
+        a = old;
+    }
+}
+
+// adds a partial component to the strip's table (LDS), keyed by label; a full table sends it straight to the frame's accumulators
+__device__ __forceinline__ void c3_table_add(u32* t_label, contrib* t_rec, u32 label, const contrib& c, ccl_acc* facc)
+{
+    u32 slot = (label * 2654435761u) >> 25;                   // 7 bits
+    for (int probe = 0; probe < 8; probe++, slot = (slot + 1) & (C3_TAB - 1)) {
+        const u32 cur = atomicCAS(t_label + slot, 0u, label);
+        if (cur == 0u || cur == label) {
+            contrib* t = t_rec + slot;
+            atomicAdd(&t->area, c.area);
+            atomicAdd((unsigned long long*)&t->sx, (unsigned long long)c.sx);
+            atomicAdd((unsigned long long*)&t->sy, (unsigned long long)c.sy);
+            atomicMin(&t->minx, c.minx); atomicMax(&t->maxx, c.maxx);
+            atomicMin(&t->miny, c.miny); atomicMax(&t->maxy, c.maxy);
+            return;
+        }
+    }
+    acc_commit(facc + label, c);
+}
+
+// every (row, word) of the strip, one word per thread and pass
+#define C3_FOR_WORDS(r, j, i, NT)                                                                  \
+    for (int i = threadIdx.x, r = i / ww, j = i - r * ww; i < nrows * ww; i += NT, r = i / ww, j = i - r * ww)
+
+// ---- ranks without a pass over the frame ---------------------------------------------------------------------------------------
+// A strip's slice of the root bitmap is final once the boundaries above and below it have been processed; the block that completes
+// the second of them counts the slice's roots (scount) and stores the exclusive popcount prefix of its words RELATIVE to the slice.
+// A label is then  1 + (roots in the strips before) + (relative prefix of the word) + (roots below in the word):  the first term is
+// a scan over at most a few hundred per-strip counts, which every block of the later launches does for itself.
+template <int NT>
+__device__ void c3_finish_slice(const ccl_geom& G, const c3_plan& P, int strip, const u32* __restrict__ ffl, u32* __restrict__ fpf,
+                                u32* __restrict__ scount, u32* red /* LDS, NT / 64 + 1 words */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 k0 = (u32)strip * (P.ids / 32), k1 = (strip == P.strips - 1) ? G.nw32 : min(k0 + P.ids / 32, G.nw32);
+    u32 run = 0;
+    for (u32 kb = k0; kb < k1; kb += NT) {                   // one pass for every supported geometry (a slice is at most 256 words)
+        const u32 k = kb + tid;
+        const u32 c = k < k1 ? (u32)__popc(ld_rlx(ffl + k)) : 0u;
+        u32 inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        __syncthreads();
+        if (lane == 63) red[wv] = inc;
+        __syncthreads();
+        u32 off = 0, tot = 0;
+        for (int q = 0; q < NT / 64; q++) { const u32 t = red[q]; if (q < wv) off += t; tot += t; }
+        if (k < k1) fpf[k] = run + off + inc - c;
+        run += tot;
+    }
+    if (tid == 0) scount[strip] = run;
+}
+
+// exclusive prefix of the frame's per-strip root counts into LDS (sb[0 .. strips], sb[strips] = all roots of the frame)
+template <int NT>
+__device__ void c3_strip_bases(const c3_plan& P, const u32* __restrict__ scount, u32* sb, u32* red)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    u32 run = 0;
+    for (int kb = 0; kb < P.strips; kb += NT) {
+        const int k = kb + tid;
+        const u32 c = k < P.strips ? scount[k] : 0u;
+        u32 inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        __syncthreads();
+        if (lane == 63) red[wv] = inc;
+        __syncthreads();
+        u32 off = 0, tot = 0;
+        for (int q = 0; q < NT / 64; q++) { const u32 t = red[q]; if (q < wv) off += t; tot += t; }
+        if (k < P.strips) sb[k] = run + off + inc - c;
+        run += tot;
+    }
+    if (tid == 0) sb[P.strips] = run;
+    __syncthreads();
+}
+
+// ---- K1: strip-local union-find, boundaries, ranks --------------------------------------------------------------------------------
+// dynamic LDS: lbits[R * ww] u64 | lpar[ids] u32 | lroots[ids / 32] u32
+__global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
+                                                               const u32* __restrict__ clist, u32* __restrict__ parent, u32* __restrict__ flags,
+                                                               u32* __restrict__ child, u32* __restrict__ lrootbits, u32* __restrict__ root16,
+                                                               u32* __restrict__ barr, ccl_acc* __restrict__ acc, int max_labels, int dbg)
+{
+    const u32 nc = *ncrowded;
+    if (nc == 0) return;                                      // the common case: nothing was handed over
+    extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
+    __shared__ int s_up, s_dn;
+    __shared__ u32 pairs[512];                                 // 256 recently united (lower root, upper root) pairs of the boundary at hand
+    const int NT = C3_LINK_THREADS;
+    const int ww = G.ww, tid = threadIdx.x;
+    const int nwmax = P.R * ww;
+    u64* lbits = c3_lds;
+    u32* lpar = reinterpret_cast<u32*>(c3_lds + nwmax);
+    u32* lroots = lpar + P.ids;
+    const u32 total = nc * (u32)P.strips;
+    C3_PROBE_DECL;
+    for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+        const u32 f = clist[item / (u32)P.strips];
+        const int s = (int)(item % (u32)P.strips);
+        const int y0 = s * P.R;
+        const int nrows = min(P.R, G.h - y0);
+        const u64* fb = bits + (size_t)f * G.h * ww;
+        u32* fpar = parent + (size_t)f * G.nids;
+        u32* ffl = flags + (size_t)f * G.nw32;
+        u32* fch = child + (size_t)f * G.nw32;
+        u32* flr = lrootbits + (size_t)f * G.nw32;
+        u32* f16 = root16 + (size_t)f * G.nids;               // the frame's own slot of the u32 segment array, used as two u16 per word
+        const u32 base = (u32)s * P.ids;
+        __syncthreads();                                      // the previous item's LDS is done with
+        C3_FOR_WORDS(r, j, i, NT) lbits[i] = fb[(size_t)(y0 + r) * ww + j];
+        for (u32 k = tid; k < P.ids / 32; k += NT) lroots[k] = 0u;
+        __syncthreads();
+        C3_PROBE(0);   // bits staged
+        // every segment its own parent
+        C3_FOR_WORDS(r, j, i, NT) {
+            u64 st = lbits[i] & ~(lbits[i] << 1);
+            while (st) {
+                const int sb = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                const u32 id = c3_rel(G, r, 64 * j + sb);
+                lpar[id] = id;
+            }
+        }
+        __syncthreads();
+        C3_PROBE(1);   // parents set
+        // unions: with the segment that ends the previous word of the row, and with the 8-connected segments of the row above
+        C3_FOR_WORDS(r, j, i, NT) {
+            const u64 w = lbits[i];
+            if (!w) continue;
+            if ((w & 1ull) && j > 0 && (lbits[i - 1] >> 63))
+                lds_unite(lpar, c3_rel(G, r, 64 * j), c3_rel(G, r, 64 * (j - 1) + run_start(lbits[i - 1], 63)));
+            if (r == 0) continue;
+            const u64 um = lbits[i - ww];
+            const u64 ul = j > 0 ? lbits[i - ww - 1] : 0ull;
+            const u64 ur = j + 1 < ww ? lbits[i - ww + 1] : 0ull;
+            if (!(um | (ul >> 63) | (ur & 1ull))) continue;
+            u64 rem = w;
+            while (rem) {
+                const int sb = __ffsll((long long)rem) - 1;
+                const int eb = run_end(rem, sb);
+                const u64 Sg = bit_range(sb, eb);
+                rem &= ~Sg;
+                const u32 me = c3_rel(G, r, 64 * j + sb);
+                u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
+                while (c) {
+                    const int b = __ffsll((long long)c) - 1;
+                    const int st = run_start(um, b), en = run_end(um, b);
+                    lds_unite(lpar, me, c3_rel(G, r - 1, 64 * j + st));
+                    c &= ~bit_range(st, en);
+                }
+                if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) lds_unite(lpar, me, c3_rel(G, r - 1, 64 * (j - 1) + run_start(ul, 63)));
+                if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) lds_unite(lpar, me, c3_rel(G, r - 1, 64 * (j + 1)));
+            }
+        }
+        __syncthreads();
+        C3_PROBE(2);   // unions
+        // flatten (read-only walks; every thread stores the root over its OWN entries), note the local roots
+        C3_FOR_WORDS(r, j, i, NT) {
+            u64 st = lbits[i] & ~(lbits[i] << 1);
+            while (st) {
+                const int sb = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                const u32 id = c3_rel(G, r, 64 * j + sb);
+                const u32 root = lds_root(lpar, id);
+                lpar[id] = root;
+                if (root == id) {
+                    atomicOr(lroots + (id >> 5), 1u << (id & 31));
+                    st_rlx(fpar + base + id, base + id);
+                }
+            }
+        }
+        __syncthreads();
+        C3_PROBE(3);   // flatten + roots
+        // what leaves the strip: the root of every segment id (u16, contiguous), its slice of the root bitmap, a clean "has members" slice
+        {
+            const u32 lim = min(P.ids, G.nids - base);        // (the last strip may reach past the frame's id range)
+            for (u32 k = tid; k < lim / 2; k += NT) st_rlx(f16 + base / 2 + k, (lpar[2 * k] & 0xffffu) | (lpar[2 * k + 1] << 16));
+            for (u32 k = tid; k < lim / 32; k += NT) { st_rlx(ffl + base / 32 + k, lroots[k]); st_rlx(fch + base / 32 + k, 0u); flr[base / 32 + k] = lroots[k]; }
+            if (s == P.strips - 1)                            // ids past the last strip (the frame's id range is rounded up): no roots there
+                for (u32 k = (base + lim) / 32 + tid; k < G.nw32; k += NT) { st_rlx(ffl + k, 0u); st_rlx(fch + k, 0u); flr[k] = 0u; }
+        }
+        C3_PROBE(4);   // dump issued
+        // this strip's share of the frame's accumulators, cleared for the labelling launch (only components that span strips use one,
+        // but which labels those are is not known before the ranks are)
+        {
+            const u32 wpe = (u32)(sizeof(ccl_acc) / 4);       // words per entry: area, minx, miny, maxx, maxy, pad, sx, sy
+            const u64 words = (u64)max_labels * wpe;
+            const u64 per = (words + (u64)P.strips - 1) / (u64)P.strips;
+            const u64 w0 = min((u64)s * per, words), w1 = min(w0 + per, words);
+            u32* aw = reinterpret_cast<u32*>(acc + (size_t)f * max_labels);
+            for (u64 q = w0 + tid; q < w1; q += NT) {
+                const u32 e = (u32)(q % wpe);
+                aw[q] = (e == 1u || e == 2u) ? (u32)INT_MAX : (e == 3u || e == 4u) ? (u32)INT_MIN : 0u;
+            }
+        }
+        c3_publish();
+        C3_PROBE(5);   // accumulators cleared, stores drained
+        if (tid == 0) {
+            u32* ar = barr + (size_t)f * 3 * (P.strips + 1);                      // arrivals per boundary | (unused) | roots per strip
+            s_up = (s > 0) ? (int)atomicAdd(ar + s, 1u) : -1;                       // boundary s lies between strips s - 1 and s
+            s_dn = (s + 1 < P.strips) ? (int)atomicAdd(ar + s + 1, 1u) : -1;
+        }
+        __syncthreads();
+        const int take[2] = {s_up == 1 ? s : -1, s_dn == 1 ? s + 1 : -1};           // boundaries this block is the second arriver of
+        for (int t = 0; t < 2; t++) {
+            const int b = take[t];
+            if (b < 0) continue;                                                    // block-uniform
+            const int y = b * P.R;
+            const u32 blo = (u32)b * P.ids, bup = blo - P.ids;
+            // The roots of the two rows that meet, out of the neighbours' u16 blocks into LDS (coalesced write-through reads; lpar is free
+            // by now): the ids of a row and of its partner in the 2x2 numbering interleave, so a row pair is one contiguous range of
+            // 2 * wb ids - the first of the lower strip, the last of the upper one.  (Pixel numbering: one row = wb ids.)
+            const u32 span = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;
+            const u32 up0 = P.ids - span;                                           // first id of the upper strip's last row (pair)
+            const u32 upoff = (bup + up0) & 1u;                                     // (an odd first id: the pair loads start one entry early)
+            const u32 nlo = (span + 1) / 2, nup = (span + upoff + 1) / 2;           // words: two u16 each
+            u32* s_lo = lpar;
+            u32* s_up16 = lpar + nlo;                                               // nlo + nup <= ids: lpar holds both
+            __syncthreads();
+            for (u32 k = tid; k < nlo; k += NT) s_lo[k] = ld_rlx(f16 + blo / 2 + k);
+            for (u32 k = tid; k < nup; k += NT) s_up16[k] = ld_rlx(f16 + (bup + up0 - upoff) / 2 + k);
+            for (u32 k = tid; k < 512; k += NT) pairs[k] = 0xffffffffu;
+            __syncthreads();
+            C3_PROBE(6);   // boundary rows staged
+            const unsigned short* lo16 = reinterpret_cast<const unsigned short*>(s_lo);
+            const unsigned short* up16 = reinterpret_cast<const unsigned short*>(s_up16) + upoff;
+            // eight threads share a word of the boundary row and take its segments in turn
+            for (int j = tid >> 3; j < ww && !(dbg & 1); j += NT / 8) {
+                const size_t idx = (size_t)y * ww + j;
+                const u64 w = fb[idx];
+                if (!w) continue;
+                const u64 um = fb[idx - ww];
+                const u64 ul = j > 0 ? fb[idx - ww - 1] : 0ull;
+                const u64 ur = j + 1 < ww ? fb[idx - ww + 1] : 0ull;
+                if (!(um | (ul >> 63) | (ur & 1ull))) continue;
+                u64 rem = w;
+                int ord = 0;
+                while (rem) {
+                    const int sb = __ffsll((long long)rem) - 1;
+                    const int eb = run_end(rem, sb);
+                    const u64 Sg = bit_range(sb, eb);
+                    rem &= ~Sg;
+                    if ((ord++ & 7) != (tid & 7)) continue;
+                    const u32 a = blo + (u32)lo16[c3_rel(G, 0, 64 * j + sb)];
+                    auto meet = [&](int xup) {
+                        const u32 bb = bup + (u32)up16[c3_rel(G, P.R - 1, xup) - up0];
+                        // a pair some thread of the block has already united (the big component, over and over) is not united again
+                        const u32 slot = ((a * 2654435761u) ^ (bb * 40503u)) >> 24;
+                        if (pairs[2 * slot] == a && pairs[2 * slot + 1] == bb) return;
+                        pairs[2 * slot] = a; pairs[2 * slot + 1] = bb;             // (a torn entry only costs a repeated union)
+                        c3_unite(fpar, ffl, fch, a, bb);
+                    };
+                    u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
+                    while (c) {
+                        const int bt = __ffsll((long long)c) - 1;
+                        const int st = run_start(um, bt), en = run_end(um, bt);
+                        meet(64 * j + st);
+                        c &= ~bit_range(st, en);
+                    }
+                    if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) meet(64 * (j - 1) + run_start(ul, 63));
+                    if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) meet(64 * (j + 1));
+                }
+            }
+            __syncthreads();
+            C3_PROBE(7);   // boundary unions
+        }
+    }
+    C3_PROBE_END(0);
+}
+
+// ---- ranks: one item per (handed-over frame, strip) once every boundary of the launch above is through ---------------------------------
+// ... and every local root that was absorbed gets the frame's root as its parent (the unions are complete, so that is final): the
+// labelling launch then finds the label of such a component's pieces with one look-up instead of a walk.
+__global__ __launch_bounds__(256) void k_ccl3_rank(ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded, const u32* __restrict__ clist,
+                                                   const u32* __restrict__ flags, u32* __restrict__ prefix, u32* __restrict__ barr,
+                                                   const u32* __restrict__ lrootbits, u32* __restrict__ parent)
+{
+    const u32 nc = *ncrowded;
+    if (nc == 0) return;
+    __shared__ u32 red[256 / 64 + 1];
+    const u32 total = nc * (u32)P.strips;
+    for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+        const u32 f = clist[item / (u32)P.strips];
+        const int s = (int)(item % (u32)P.strips);
+        c3_finish_slice<256>(G, P, s, flags + (size_t)f * G.nw32, prefix + (size_t)f * G.nw32, barr + (size_t)f * 3 * (P.strips + 1) + 2 * (P.strips + 1), red);
+        {
+            const u32* ffl = flags + (size_t)f * G.nw32;
+            const u32* flr = lrootbits + (size_t)f * G.nw32;
+            u32* fpar = parent + (size_t)f * G.nids;
+            const u32 k0 = (u32)s * (P.ids / 32), k1 = (s == P.strips - 1) ? G.nw32 : min(k0 + P.ids / 32, G.nw32);
+            for (u32 k = k0 + threadIdx.x; k < k1; k += 256) {
+                u32 m = flr[k] & ~ffl[k];                    // local roots of the strip that are no longer roots of the frame
+                while (m) {
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const u32 g0 = (k << 5) + (u32)b;
+                    u32 g = g0;
+                    for (u32 q = fpar[g]; q != g; q = fpar[g]) g = q;   // (entries along the way may already hold the root: still an ancestor)
+                    fpar[g0] = g;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- K2: labels, statistics, label image ------------------------------------------------------------------------------------------
+// dynamic LDS: lbits[R * ww] u64 | lab[ids] u32 | lr16[ids] u16 | lrb, lrp, gfl, gpf, gch [ids / 32] u32 each | accumulators 6 x C3_ACC u32
+__global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
+                                                                 const u32* __restrict__ clist, const u32* __restrict__ parent,
+                                                                 const u32* __restrict__ flags, const u32* __restrict__ child,
+                                                                 const u32* __restrict__ prefix, const u32* __restrict__ root16,
+                                                                 const u32* __restrict__ barr, c3_state* __restrict__ state, int32_t* __restrict__ nlabels,
+                                                                 ccl_acc* __restrict__ acc, int max_labels, int32_t* __restrict__ labels,
+                                                                 int32_t* __restrict__ stats, double* __restrict__ cent, int dbg)
+{
+    const u32 nc = *ncrowded;
+    if (nc == 0) return;
+    extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
+    __shared__ u32 red[C3_LABEL_THREADS / 64 + 1];
+    __shared__ contrib part[C3_LABEL_THREADS / 64];
+    __shared__ u32 sbase[C3_MAX_STRIPS + 2];                   // roots in the strips before each strip
+    __shared__ u32 s_nroots;
+    __shared__ u32 t_label[C3_TAB];                            // labels of the components this strip only holds a part of ...
+    __shared__ contrib t_rec[C3_TAB];
+    __shared__ unsigned short rlist[C3_ACC];                   // ids of the local roots of the pass, by local rank                          // ... and what the strip adds to them
+    const int NT = C3_LABEL_THREADS;
+    const int ww = G.ww, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nwmax = P.R * ww;
+    const u32 nsl = P.ids / 32;
+    u64* lbits = c3_lds;
+    u32* lab = reinterpret_cast<u32*>(c3_lds + nwmax);
+    unsigned short* lr16 = reinterpret_cast<unsigned short*>(lab + P.ids);
+    u32* lrb = reinterpret_cast<u32*>(lr16 + P.ids);
+    u32* lrp = lrb + nsl;
+    u32* gfl = lrp + nsl;
+    u32* gpf = gfl + nsl;
+    u32* gch = gpf + nsl;
+    u32* a_area = gch + nsl;
+    u32* a_sx = a_area + C3_ACC;
+    u32* a_sy = a_sx + C3_ACC;
+    u32* a_minx = a_sy + C3_ACC;
+    u32* a_maxx = a_minx + C3_ACC;
+    u32* a_rows = a_maxx + C3_ACC;
+    const u64 lastmask = (G.w & 63) ? ((1ull << (G.w & 63)) - 1ull) : ~0ull;
+    const u32 gpr = (u32)((G.w + 3) / 4);
+    const u32 total = nc * (u32)P.strips;
+    C3_PROBE_DECL;
+    for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+        const u32 f = clist[item / (u32)P.strips];
+        const int s = (int)(item % (u32)P.strips);
+        const int y0 = s * P.R;
+        const int nrows = min(P.R, G.h - y0);
+        const u64* fb = bits + (size_t)f * G.h * ww;
+        const u32* fpar = parent + (size_t)f * G.nids;
+        const u32* ffl = flags + (size_t)f * G.nw32;
+        const u32* fpf = prefix + (size_t)f * G.nw32;
+        const u32* fch = child + (size_t)f * G.nw32;
+        const u32* f16 = root16 + (size_t)f * G.nids;
+        ccl_acc* facc = acc + (size_t)f * max_labels;
+        const u32 base = (u32)s * P.ids;
+        const u32 lim = min(P.ids, G.nids - base);
+        __syncthreads();
+        c3_strip_bases<C3_LABEL_THREADS>(P, barr + (size_t)f * 3 * (P.strips + 1) + 2 * (P.strips + 1), sbase, red);
+        if (s == 0 && tid == 0) {                             // the frame's label count: background + every root
+            const u32 nl = sbase[P.strips] + 1u;
+            if (nlabels) nlabels[f] = (int32_t)nl;
+            state[f].pad = nl;
+        }
+        C3_FOR_WORDS(r, j, i, NT) lbits[i] = fb[(size_t)(y0 + r) * ww + j];
+        for (u32 k = tid; k < lim / 2; k += NT) reinterpret_cast<u32*>(lr16)[k] = f16[base / 2 + k];
+        for (u32 k = tid; k < nsl; k += NT) {
+            const bool in = k < lim / 32;
+            gfl[k] = in ? ffl[base / 32 + k] : 0u;
+            gpf[k] = in ? fpf[base / 32 + k] : 0u;
+            gch[k] = in ? fch[base / 32 + k] : 0u;
+            lrb[k] = 0u;
+        }
+        for (int k = tid; k < C3_TAB; k += NT) { t_label[k] = 0u; contrib_zero(t_rec[k]); }
+        __syncthreads();
+        C3_PROBE(0);   // strip bases, everything staged
+        // local roots (a segment that is its own root), their ranks within the strip
+        C3_FOR_WORDS(r, j, i, NT) {
+            u64 st = lbits[i] & ~(lbits[i] << 1);
+            while (st) {
+                const int sb = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                const u32 id = c3_rel(G, r, 64 * j + sb);
+                if ((u32)lr16[id] == id) atomicOr(lrb + (id >> 5), 1u << (id & 31));
+            }
+        }
+        __syncthreads();
+        {
+            u32 c = 0;
+            const u32 per = (nsl + NT - 1) / NT;                // 1 for every supported geometry (ids <= 8192 -> 256 words)
+            const u32 lo = min((u32)tid * per, nsl), hi = min(lo + per, nsl);
+            for (u32 k = lo; k < hi; k++) c += (u32)__popc(lrb[k]);
+            u32 inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+            if (lane == 63) red[wv] = inc;
+            __syncthreads();
+            u32 off = 0, tot = 0;
+            for (int k = 0; k < NT / 64; k++) { const u32 t = red[k]; if (k < wv) off += t; tot += t; }
+            u32 run = off + inc - c;
+            for (u32 k = lo; k < hi; k++) { lrp[k] = run; run += (u32)__popc(lrb[k]); }
+            if (tid == 0) s_nroots = tot;
+        }
+        __syncthreads();
+        const u32 nroots = s_nroots;
+        C3_PROBE(1);   // local roots ranked
+        // label of every local root: still a root of the frame -> its rank, from the strip's own slice; absorbed -> walk to the root
+        C3_FOR_WORDS(r, j, i, NT) {
+            u64 st = lbits[i] & ~(lbits[i] << 1);
+            while (st) {
+                const int sb = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                const u32 id = c3_rel(G, r, 64 * j + sb);
+                if ((u32)lr16[id] != id) continue;
+                const u32 bit = 1u << (id & 31);
+                u32 label;
+                if (gfl[id >> 5] & bit) {
+                    label = sbase[s] + gpf[id >> 5] + (u32)__popc(gfl[id >> 5] & (bit - 1u)) + 1u;
+                } else if (dbg & 32) {
+                    label = 1;
+                } else {
+                    u32 g = base + id;
+                    for (u32 q = fpar[g]; q != g; q = fpar[g]) g = q;
+                    label = sbase[g / P.ids] + fpf[g >> 5] + (u32)__popc(ffl[g >> 5] & ((1u << (g & 31)) - 1u)) + 1u;
+                }
+                lab[id] = label;
+            }
+        }
+        __syncthreads();
+        C3_PROBE(2);   // labels of the local roots
+        // statistics per local component, C3_ACC components per pass
+        contrib tot_c;
+        contrib_zero(tot_c);
+        for (u32 c0 = 0; c0 < nroots && !(dbg & 8); c0 += C3_ACC) {
+            for (u32 k = tid; k < C3_ACC; k += NT) { a_area[k] = 0; a_sx[k] = 0; a_sy[k] = 0; a_minx[k] = 0xffffffffu; a_maxx[k] = 0; a_rows[k] = 0; }
+            __syncthreads();
+            // Every segment adds to its component's accumulators.  A wave's lanes mostly name the same component when one is large (half
+            // the pixels of 50 % noise belong to one): 64 LDS atomics on one word take 64 turns, so the lanes that agree with the first
+            // active lane are combined with shuffles first and added once (6 ms -> 1 ms per 128 frames of such noise).
+            for (int i0 = 0; i0 < nrows * ww; i0 += NT) {
+                const int i = i0 + tid;
+                const bool valid = i < nrows * ww;
+                const int r = valid ? i / ww : 0, j = valid ? i - r * ww : 0;
+                u64 rem = valid ? lbits[i] : 0ull;
+                while (__any(rem != 0ull)) {
+                    bool act = rem != 0ull;
+                    u32 k = 0xffffffffu, len = 0, sxv = 0, syv = 0, xs = 0xffffffffu, xe = 0, rowbit = 0;
+                    if (act) {
+                        const int sb = __ffsll((long long)rem) - 1;
+                        const int eb = run_end(rem, sb);
+                        rem &= ~bit_range(sb, eb);
+                        const u32 me = c3_rel(G, r, 64 * j + sb);
+                        const u32 root = lr16[me];
+                        k = lrp[root >> 5] + (u32)__popc(lrb[root >> 5] & ((1u << (root & 31)) - 1u)) - c0;
+                        act = k < (u32)C3_ACC;
+                        if (act && root == me) rlist[k] = (unsigned short)me;
+                        len = (u32)(eb - sb + 1);
+                        xs = (u32)(64 * j + sb); xe = (u32)(64 * j + eb);
+                        sxv = len * (xs + xe) / 2u; syv = len * (u32)r; rowbit = 1u << r;
+                    }
+                    const unsigned long long am = __ballot(act);
+                    if (!am) continue;
+                    const int lead = __ffsll((long long)am) - 1;
+                    const u32 kd = __shfl(k, lead);
+                    const bool same = act && k == kd;
+                    if (__popcll(__ballot(same)) >= 8) {
+                        u32 t_len = same ? len : 0u, t_sx = same ? sxv : 0u, t_sy = same ? syv : 0u, t_xs = same ? xs : 0xffffffffu,
+                            t_xe = same ? xe : 0u, t_rb = same ? rowbit : 0u;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            t_len += __shfl_xor(t_len, d); t_sx += __shfl_xor(t_sx, d); t_sy += __shfl_xor(t_sy, d);
+                            t_xs = min(t_xs, (u32)__shfl_xor(t_xs, d)); t_xe = max(t_xe, (u32)__shfl_xor(t_xe, d)); t_rb |= __shfl_xor(t_rb, d);
+                        }
+                        if (lane == lead) {
+                            atomicAdd(a_area + kd, t_len); atomicAdd(a_sx + kd, t_sx); atomicAdd(a_sy + kd, t_sy);
+                            atomicMin(a_minx + kd, t_xs); atomicMax(a_maxx + kd, t_xe); atomicOr(a_rows + kd, t_rb);
+                        }
+                        act = act && !same;
+                    }
+                    if (act) {
+                        atomicAdd(a_area + k, len); atomicAdd(a_sx + k, sxv); atomicAdd(a_sy + k, syv);
+                        atomicMin(a_minx + k, xs); atomicMax(a_maxx + k, xe); atomicOr(a_rows + k, rowbit);
+                    }
+                }
+            }
+            __syncthreads();
+            C3_PROBE(3);   // accumulate
+            // One lane per local root of this pass.  Complete within the strip (still a root of the frame, no members elsewhere): its row
+            // goes straight out.  Otherwise its sums join its label's entry of a small LDS table, lanes of a wave that carry the same label
+            // combined with shuffles first (at 50 % noise a strip holds about a thousand fragments of the one big component), and the table
+            // goes to the frame's accumulators once per strip - not once per fragment (54 M global atomics per 128 frames before).
+            {
+                // lanes in the order of the local ranks = in the order of the labels: neighbouring lanes write neighbouring rows
+                const u32 k = (u32)tid;                                             // (C3_ACC == the block's thread count)
+                bool commit = false;
+                u32 label = 0;
+                contrib c;
+                contrib_zero(c);
+                if (k < min((u32)C3_ACC, nroots - c0)) {
+                    const u32 id = rlist[k];
+                    const u32 bit = 1u << (id & 31);
+                    c.area = a_area[k];
+                    c.sx = (u64)a_sx[k];
+                    c.sy = (u64)a_sy[k] + (u64)c.area * (u64)y0;
+                    c.minx = (int)a_minx[k]; c.maxx = (int)a_maxx[k];
+                    c.miny = y0 + (__ffs((int)a_rows[k]) - 1); c.maxy = y0 + (31 - __clz((int)a_rows[k]));
+                    tot_c.area += c.area; tot_c.sx += c.sx; tot_c.sy += c.sy;
+                    label = lab[id];
+                    if (label < (u32)max_labels) {
+                        if ((gfl[id >> 5] & bit) && !(gch[id >> 5] & bit)) {
+                            const size_t o = (size_t)f * max_labels + label;
+                            if (stats) {
+                                int32_t* sp = stats + o * 5;
+                                sp[0] = c.minx; sp[1] = c.miny; sp[2] = c.maxx - c.minx + 1; sp[3] = c.maxy - c.miny + 1; sp[4] = (int32_t)c.area;
+                            }
+                            if (cent) {
+                                const double area = (double)c.area;
+                                cent[o * 2] = (double)c.sx / area;
+                                cent[o * 2 + 1] = (double)c.sy / area;
+                            }
+                        } else {
+                            commit = true;
+                        }
+                    }
+                }
+                unsigned long long cm = __ballot(commit);
+                while (cm) {                                                        // wave-uniform: one turn per distinct label among the lanes
+                    const int lead = __ffsll((long long)cm) - 1;
+                    const u32 ld = __shfl(label, lead);
+                    const bool same = commit && label == ld;
+                    const unsigned long long sm = __ballot(same);
+                    if (__popcll(sm) >= 4) {
+                        contrib g = c;
+                        if (!same) contrib_zero(g);
+                        wave_combine(g);
+                        if (lane == lead) c3_table_add(t_label, t_rec, ld, g, facc);
+                    } else if (same) {
+                        c3_table_add(t_label, t_rec, label, c, facc);
+                    }
+                    commit = commit && !same;
+                    cm &= ~sm;
+                }
+            }
+            __syncthreads();
+            C3_PROBE(4);   // emit rows / table
+        }
+        // the table of this strip -> the frame's accumulators
+        for (int k = tid; k < C3_TAB; k += NT)
+            if (t_label[k]) acc_commit(facc + t_label[k], t_rec[k]);
+        C3_PROBE(5);   // table flushed
+        // the strip's part of the label image: one lane = 4 px = one 16-byte store, labels from LDS
+        if (labels && !(dbg & 16)) {
+            int32_t* lrow0 = labels + ((size_t)f * G.h + y0) * G.w;
+            const bool vec = (G.w & 3) == 0 && ((((uintptr_t)lrow0) & 15) == 0);
+            const u32 ngroups = (u32)nrows * gpr;
+            for (u32 q = tid; q < ngroups; q += NT) {
+                const u32 r = q / gpr, g = q - r * gpr;
+                const int x0 = (int)g * 4, j = x0 >> 6, sub = x0 & 63;
+                const u64 w = lbits[r * ww + j];
+                const u32 nib = (u32)(w >> sub) & 0xfu;
+                int vv[4] = {0, 0, 0, 0};
+                if (nib) {
+                    const int tz = __ffs((int)nib) - 1;
+                    const u32 t = nib >> tz;
+                    const int runlen = __ffs((int)~t) - 1;
+                    const u32 m1 = ((1u << runlen) - 1u) << tz, m2 = nib & ~m1;
+                    const u32 la = lab[lr16[c3_rel(G, (int)r, 64 * j + run_start(w, sub + tz))]];
+                    const u32 lb = m2 ? lab[lr16[c3_rel(G, (int)r, x0 + (__ffs((int)m2) - 1))]] : 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) vv[b] = ((m1 >> b) & 1u) ? (int)la : (((m2 >> b) & 1u) ? (int)lb : 0);
+                }
+                int32_t* d = lrow0 + (size_t)r * G.w + x0;
+                if (vec && x0 + 4 <= G.w) {
+                    vp_store16(d, (u32)vv[0], (u32)vv[1], (u32)vv[2], (u32)vv[3]);
+                } else {
+                    for (int b = 0; b < 4; b++)
+                        if (x0 + b < G.w) d[b] = vv[b];
+                }
+            }
+        }
+        C3_PROBE(6);   // label stores issued
+        // totals of the strip for the frame's background row: foreground sums, bounding box of the zero pixels
+        C3_FOR_WORDS(r, j, i, NT) {
+            const u64 z = ~lbits[i] & (j == ww - 1 ? lastmask : ~0ull);
+            if (!z) continue;
+            tot_c.minx = min(tot_c.minx, 64 * j + (__ffsll((long long)z) - 1));
+            tot_c.maxx = max(tot_c.maxx, 64 * j + 63 - __clzll(z));
+            tot_c.miny = min(tot_c.miny, y0 + r);
+            tot_c.maxy = max(tot_c.maxy, y0 + r);
+        }
+        wave_combine(tot_c);
+        if (lane == 0) part[wv] = tot_c;
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < NT / 64; k++) contrib_merge(tot_c, part[k]);
+            c3_state* st = state + f;
+            if (tot_c.area) {
+                atomicAdd(&st->fg_area, tot_c.area);
+                atomicAdd((unsigned long long*)&st->fg_sx, (unsigned long long)tot_c.sx);
+                atomicAdd((unsigned long long*)&st->fg_sy, (unsigned long long)tot_c.sy);
+            }
+            if (tot_c.minx != INT_MAX) {
+                atomicMin(&st->bg_minx, tot_c.minx); atomicMax(&st->bg_maxx, tot_c.maxx);
+                atomicMin(&st->bg_miny, tot_c.miny); atomicMax(&st->bg_maxy, tot_c.maxy);
+            }
+        }
+        C3_PROBE(7);   // totals
+    }
+    C3_PROBE_END(1);
+}
+
+// ---- K3: rows of the components that span strips, the background row, zeros past the last label -----------------------------------
+// one item per (handed-over frame, strip): the roots of the strip's slice that gathered members elsewhere have their sums in the
+// accumulators by now (the labelling launch is complete)
+__global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded, const u32* __restrict__ clist,
+                                                   const u32* __restrict__ flags, const u32* __restrict__ child, const u32* __restrict__ prefix,
+                                                   const u32* __restrict__ barr, const c3_state* __restrict__ state, const ccl_acc* __restrict__ acc,
+                                                   int max_labels, int32_t* __restrict__ stats, double* __restrict__ cent)
+{
+    const u32 nc = *ncrowded;
+    if (nc == 0 || (!stats && !cent)) return;
+    __shared__ u32 sbase[C3_MAX_STRIPS + 2];
+    __shared__ u32 red[256 / 64 + 1];
+    const int NT = 256, tid = threadIdx.x;
+    const u32 total = nc * (u32)P.strips;
+    for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+        const u32 f = clist[item / (u32)P.strips];
+        const int s = (int)(item % (u32)P.strips);
+        const u32* ffl = flags + (size_t)f * G.nw32;
+        const u32* fch = child + (size_t)f * G.nw32;
+        const u32* fpf = prefix + (size_t)f * G.nw32;
+        const ccl_acc* facc = acc + (size_t)f * max_labels;
+        __syncthreads();
+        c3_strip_bases<256>(P, barr + (size_t)f * 3 * (P.strips + 1) + 2 * (P.strips + 1), sbase, red);
+        const u32 k0 = (u32)s * (P.ids / 32), k1 = (s == P.strips - 1) ? G.nw32 : min(k0 + P.ids / 32, G.nw32);
+        for (u32 k = k0 + tid; k < k1; k += NT) {
+            const u32 fl = ffl[k];
+            u32 m = fl & fch[k];
+            while (m) {
+                const int b = __ffs((int)m) - 1;
+                m &= m - 1;
+                const u32 label = sbase[s] + fpf[k] + (u32)__popc(fl & ((1u << b) - 1u)) + 1u;
+                if (label >= (u32)max_labels) continue;
+                const ccl_acc a = facc[label];
+                const size_t o = (size_t)f * max_labels + label;
+                if (stats) {
+                    int32_t* sp = stats + o * 5;
+                    sp[0] = a.minx; sp[1] = a.miny; sp[2] = a.maxx - a.minx + 1; sp[3] = a.maxy - a.miny + 1; sp[4] = (int32_t)a.area;
+                }
+                if (cent) {
+                    const double area = (double)a.area;
+                    cent[o * 2] = (double)a.sx / area;
+                    cent[o * 2 + 1] = (double)a.sy / area;
+                }
+            }
+        }
+        // this strip's share of the rows past the last label
+        const c3_state st = state[f];
+        const int nl = max((int)st.pad, 1);
+        if (nl < max_labels) {
+            const long long span = (long long)max_labels - nl, per = (span + P.strips - 1) / P.strips;
+            const long long l0 = nl + (long long)s * per, l1 = min(l0 + per, (long long)max_labels);
+            for (long long l = l0 + tid; l < l1; l += NT) {
+                const size_t o = (size_t)f * max_labels + (size_t)l;
+                if (stats) { int32_t* sp = stats + o * 5; sp[0] = sp[1] = sp[2] = sp[3] = sp[4] = 0; }
+                if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
+            }
+        }
+        if (s == 0 && tid == 0) {                             // the background row: the frame's totals minus the foreground's
+            const u64 W = (u64)G.w, H = (u64)G.h;
+            const u32 area = (u32)(W * H) - st.fg_area;
+            const u64 sx = H * (W * (W - 1ull) / 2ull) - st.fg_sx;
+            const u64 sy = W * (H * (H - 1ull) / 2ull) - st.fg_sy;
+            const size_t o = (size_t)f * max_labels;
+            if (stats) {
+                int32_t* sp = stats + o * 5;
+                sp[0] = st.bg_minx; sp[1] = st.bg_miny;
+                sp[2] = (int32_t)((u32)st.bg_maxx - (u32)st.bg_minx + 1u);
+                sp[3] = (int32_t)((u32)st.bg_maxy - (u32)st.bg_miny + 1u);
+                sp[4] = (int32_t)area;
+            }
+            if (cent) {
+                cent[o * 2] = (double)sx / (double)area;
+                cent[o * 2 + 1] = (double)sy / (double)area;
+            }
+        }
+    }
+}
+
+static size_t c3_link_lds(const ccl_geom& G, const c3_plan& P) { return (size_t)P.R * G.ww * 8 + (size_t)P.ids * 4 + (size_t)P.ids / 32 * 4; }
+static size_t c3_label_lds(const ccl_geom& G, const c3_plan& P)
+{
+    return (size_t)P.R * G.ww * 8 + (size_t)P.ids * 4 + (size_t)P.ids * 2 + (size_t)P.ids / 32 * 4 * 5 + (size_t)C3_ACC * 4 * 6;
+}

@@ -160,7 +160,14 @@ struct vp_ccl_ws {           // per-batch scratch, all device pointers
     void* c2_recs;           // [n][strips][C2_RC]     component records (statistics + numbering key)
     void* c2_bgbox;          // [n][strips]            bounding box of the strip's zero pixels
     u32* c2_label;           // [n][strips][C2_RC]     (strip, component) -> label
-    u32* c2_crowded;         // [n]                    1: frame left to the one-level kernels
+    u32* c2_crowded;         // [n]                    1: frame handed over to the crowded-frame path
+    // crowded-frame path (vp_ccl3.inl); parent / flags / prefix / acc are shared with the one-level kernels, seglabel holds its u16 roots
+    u32* c3_child;           // [n][nids/32]           roots that absorbed a root of another strip
+    u32* c3_lroot;           // [n][nids/32]           the strip-local roots (the root bitmap before the boundary unions)
+    u32* c3_clist;           // [n]                    the frames handed over, in no particular order
+    u32* c3_ncrowded;        // [1]                    their number
+    void* c3_state;          // [n]                    per-frame counters and totals
+    u32* c3_barr;            // [n][strips + 1]        arrivals at every strip boundary
 };
 bool vp_ccl_ws_ok(const vp_ccl_ws& ws);
 size_t vp_ccl_nids(int w, int h);   // multiple of 32

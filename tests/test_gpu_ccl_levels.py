@@ -150,3 +150,34 @@ def test_1080p_frame(ccl_ctx, oracle):
     assert np.array_equal(out["labels"][0], olab)
     assert np.array_equal(out["stats"][0][:on], ost)
     assert np.array_equal(out["centroids"][0][:on].view(np.uint64), oce.view(np.uint64))
+
+
+_NOISE_REF = {}
+
+
+def _noise_ref(oracle, lo, numbering):
+    key = (lo, numbering)
+    if key not in _NOISE_REF:
+        frames = [F.s3_noise(i) for i in range(2)]
+        _NOISE_REF[key] = (frames, [oracle.ccl(oracle.inrange(oracle.bgr2gray(fr), lo, 255), block=numbering) for fr in frames])
+    return _NOISE_REF[key]
+
+
+@pytest.mark.parametrize("lo,numbering", [(230, 2), (190, 1), (128, 2)], ids=["2pc", "10pc", "50pc"])
+def test_1080p_noise_frames(ccl_ctx, oracle, lo, numbering):
+    """Raw noise at 2 % / 10 % / 50 % density straight into the labelling at 1080p (17k / 143k / 7k components per frame, every strip
+    crowded), several copies in one batch next to an ordinary frame: labels, statistics and centroids of every copy equal the oracle's."""
+    from vision import _vp
+    from vision.utils import chain
+    frames, refs = _noise_ref(oracle, lo, numbering)
+    batch = np.stack([frames[0], frames[1], F.s4_flat(0), frames[0], frames[1]])
+    ml = 1 << 18
+    out = chain.run_chain(batch, _vp.BGR2GRAY, (lo, 0, 0), (255, 255, 255), [], ccl=1, numbering=numbering, max_labels=ml)
+    for f, k in ((0, 0), (1, 1), (3, 0), (4, 1)):
+        on, olab, ost, oce = refs[k]
+        assert int(out["nlabels"][f]) == on, (f, int(out["nlabels"][f]), on)
+        assert np.array_equal(out["labels"][f], olab), f
+        assert np.array_equal(out["stats"][f][:on], ost), f
+        assert np.array_equal(out["centroids"][f][:on].view(np.uint64), oce.view(np.uint64)), f
+        assert not out["stats"][f][on:].any()
+    assert int(out["nlabels"][2]) == 1 and not out["labels"][2].any()
