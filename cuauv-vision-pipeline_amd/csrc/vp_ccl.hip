@@ -729,7 +729,11 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
             // two launches that read the list of handed-over frames and leave at once when it is empty (the usual case)
             if (c3_dry != 2) { vp_prof_scope ps(ctx, VPK_CCL_LOCAL);
               hipLaunchKernelGGL(k_ccl3_link, dim3((unsigned)(ctx->num_cu * 4)), dim3(C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, ws.c3_barr, (ccl_acc*)ws.acc, max_labels, c3_dbg); }
+                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, (ccl_acc*)ws.acc, max_labels, c3_dbg); }
+            { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY);
+              const size_t span = (size_t)2 * G.wb + 4;     // u16 roots of the two rows (row pairs) that meet: span entries each
+              hipLaunchKernelGGL(k_ccl3_bound, dim3((unsigned)(ctx->num_cu * 8)), dim3(256), span * 4 + 16, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent, ws.flags,
+                                 ws.c3_child, ws.seglabel, c3_dbg); }
             { vp_prof_scope ps(ctx, VPK_CCL_RANK);
               hipLaunchKernelGGL(k_ccl3_rank, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.prefix, ws.c3_barr, ws.c3_lroot, ws.parent); }
             if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
@@ -802,13 +806,13 @@ extern "C" int vp_debug_probe(double* out32)
 #endif
 
 #ifdef VP_PROBE
-// crowded-frame kernels: out[k * 16 + i] = ticks (10 ns) of phase i summed over blocks and items, out[k * 16 + 15] = blocks that ran
-extern "C" int vp_debug_probe3(double* out32)
+// crowded-frame kernels (link, bound, label): out[k * 16 + i] = ticks (10 ns) of phase i summed over blocks and items, out[k * 16 + 15] = blocks that ran
+extern "C" int vp_debug_probe3(double* out32 /* 48 */)
 {
-    static std::vector<unsigned long long> h((size_t)2 * 2048 * 16);
+    static std::vector<unsigned long long> h((size_t)3 * 2048 * 16);
     if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_c3_probe), h.size() * 8) != hipSuccess) return -1;
-    for (int i = 0; i < 32; i++) out32[i] = 0;
-    for (int k = 0; k < 2; k++)
+    for (int i = 0; i < 48; i++) out32[i] = 0;
+    for (int k = 0; k < 3; k++)
         for (int b = 0; b < 2048; b++) {
             const unsigned long long* r = &h[((size_t)k * 2048 + b) * 16];
             unsigned long long t = 0;

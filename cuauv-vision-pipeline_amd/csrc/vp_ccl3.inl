@@ -17,10 +17,13 @@
 //     local component, rows of components that are complete within the strip written straight to the output (no atomics), the rest
 //     added to per-label accumulators, and the strip's part of the label image stored from LDS.
 //
-// No block ever waits for another: a boundary is processed by whichever of its two strips finishes second (an arrival counter),
-// the ranks of a frame by the block that finishes its last boundary, the rows of multi-strip components by the block that finishes
-// the frame's last strip.  Two launches (k_ccl3_link, k_ccl3_label) replace the five one-level ones; both read the list of crowded
-// frames k_ccl2_merge made and leave at once when it is empty (grid = a fixed number of blocks that loop over the work).
+// Five short launches, each a fixed number of blocks that loop over (frame, strip) items of the frames k_ccl2_merge handed over and
+// leave at once when there are none: k_ccl3_link (strips), k_ccl3_bound (boundaries), k_ccl3_rank (root counts and prefixes per slice,
+// absorbed roots flattened), k_ccl3_label (labels, statistics, label image), k_ccl3_rows (rows of components that span strips).  A
+// first form chained the stages inside two launches with arrival counters ("the strip that finishes second does the boundary, the
+// block that finishes a frame's last boundary ranks the frame"): every per-frame stage then ran on ONE block (ranks 3 ms, rows 6 ms
+// per 128 frames), agent-scope fences around every hand-over cost another 2.5 ms, and second arrivers were 1.7 x busier than the
+// average block.  Kernel boundaries are the cheaper seam here.
 #define C3_IDS 8192            // segment ids per strip = entries of the LDS union-find
 #define C3_LINK_THREADS 256
 #define C3_LABEL_THREADS 512
@@ -30,7 +33,7 @@ static_assert(C3_ACC == C3_LABEL_THREADS, "the emission step of k_ccl3_label map
 #define C3_MAX_STRIPS 1024     // per-strip root counts of a frame are scanned in LDS by every block of the later launches
 
 #ifdef VP_PROBE   // measurement builds only: time per phase (100 MHz wall clock ticks), summed over a block's items
-__device__ unsigned long long g_c3_probe[2][2048][16];
+__device__ unsigned long long g_c3_probe[3][2048][16];
 #define C3_PROBE_DECL __shared__ unsigned long long pr_acc[16]; unsigned long long pr_t = 0; if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; q_++) pr_acc[q_] = 0; pr_t = wall_clock64(); }
 #define C3_PROBE(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); pr_acc[i] += n_ - pr_t; pr_t = n_; } } while (0)
 #define C3_PROBE_END(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) for (int q_ = 0; q_ < 16; q_++) g_c3_probe[k][blockIdx.x][q_] = pr_acc[q_]; } while (0)
@@ -74,21 +77,6 @@ __device__ __forceinline__ u32 c3_rel(const ccl_geom& G, int r, int x)
     return (u32)r * (u32)G.wb + (u32)(x >> 1);
 }
 
-// Data one workgroup hands to another inside a launch (cdna_hip_programming.md Guideline 16): it is stored write-through
-// (agent-scope relaxed atomic stores = `sc1` stores: they do not linger in the writer's XCD-local L2) and read with agent-scope
-// relaxed atomic loads (`sc1` loads: they do not hit a stale line), so neither side needs a release / acquire fence - a fence at
-// agent scope writes back or invalidates a whole L2, and with a thousand workgroups doing that per strip it was 2.5 ms of a 3 ms
-// launch.  What remains of "publish": every wave waits for its stores, the workgroup meets, then one lane bumps the counter.
-__device__ __forceinline__ void c3_publish()
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-__device__ __forceinline__ unsigned short c3_ld16(const u32* words, u32 idx)   // entry idx of a u16 array kept as u32 pairs
-{
-    return (unsigned short)(ld_rlx(words + (idx >> 1)) >> ((idx & 1u) * 16u));
-}
-
 // links the larger root under the smaller (global memory, device-scope CAS): the absorbed root loses its bit in the root bitmap,
 // the absorbing one is marked as having members outside its own strip-local component
 __device__ __forceinline__ void c3_unite(u32* p, u32* flags, u32* child, u32 a, u32 b)
@@ -101,7 +89,9 @@ __device__ __forceinline__ void c3_unite(u32* p, u32* flags, u32* child, u32 a, 
         const u32 old = atomicCAS(p + a, a, b);
         if (old == a) {
             atomicAnd(flags + (a >> 5), ~(1u << (a & 31)));
-            atomicOr(child + (b >> 5), 1u << (b & 31));
+            // (the big component's root takes a link from every fragment of every strip: set its mark once - read-modify-writes of one
+            // address queue up in L2, reads of it do not)
+            if (!(ld_rlx(child + (b >> 5)) & (1u << (b & 31)))) atomicOr(child + (b >> 5), 1u << (b & 31));
             return;
         }
         a = old;
@@ -189,13 +179,11 @@ __device__ void c3_strip_bases(const c3_plan& P, const u32* __restrict__ scount,
 __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
                                                                const u32* __restrict__ clist, u32* __restrict__ parent, u32* __restrict__ flags,
                                                                u32* __restrict__ child, u32* __restrict__ lrootbits, u32* __restrict__ root16,
-                                                               u32* __restrict__ barr, ccl_acc* __restrict__ acc, int max_labels, int dbg)
+                                                               ccl_acc* __restrict__ acc, int max_labels, int dbg)
 {
     const u32 nc = *ncrowded;
     if (nc == 0) return;                                      // the common case: nothing was handed over
     extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
-    __shared__ int s_up, s_dn;
-    __shared__ u32 pairs[512];                                 // 256 recently united (lower root, upper root) pairs of the boundary at hand
     const int NT = C3_LINK_THREADS;
     const int ww = G.ww, tid = threadIdx.x;
     const int nwmax = P.R * ww;
@@ -275,7 +263,7 @@ __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __rest
                 lpar[id] = root;
                 if (root == id) {
                     atomicOr(lroots + (id >> 5), 1u << (id & 31));
-                    st_rlx(fpar + base + id, base + id);
+                    fpar[base + id] = base + id;
                 }
             }
         }
@@ -284,10 +272,10 @@ __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __rest
         // what leaves the strip: the root of every segment id (u16, contiguous), its slice of the root bitmap, a clean "has members" slice
         {
             const u32 lim = min(P.ids, G.nids - base);        // (the last strip may reach past the frame's id range)
-            for (u32 k = tid; k < lim / 2; k += NT) st_rlx(f16 + base / 2 + k, (lpar[2 * k] & 0xffffu) | (lpar[2 * k + 1] << 16));
-            for (u32 k = tid; k < lim / 32; k += NT) { st_rlx(ffl + base / 32 + k, lroots[k]); st_rlx(fch + base / 32 + k, 0u); flr[base / 32 + k] = lroots[k]; }
+            for (u32 k = tid; k < lim / 2; k += NT) f16[base / 2 + k] = (lpar[2 * k] & 0xffffu) | (lpar[2 * k + 1] << 16);
+            for (u32 k = tid; k < lim / 32; k += NT) { ffl[base / 32 + k] = lroots[k]; fch[base / 32 + k] = 0u; flr[base / 32 + k] = lroots[k]; }
             if (s == P.strips - 1)                            // ids past the last strip (the frame's id range is rounded up): no roots there
-                for (u32 k = (base + lim) / 32 + tid; k < G.nw32; k += NT) { st_rlx(ffl + k, 0u); st_rlx(fch + k, 0u); flr[k] = 0u; }
+                for (u32 k = (base + lim) / 32 + tid; k < G.nw32; k += NT) { ffl[k] = 0u; fch[k] = 0u; flr[k] = 0u; }
         }
         C3_PROBE(4);   // dump issued
         // this strip's share of the frame's accumulators, cleared for the labelling launch (only components that span strips use one,
@@ -303,79 +291,95 @@ __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __rest
                 aw[q] = (e == 1u || e == 2u) ? (u32)INT_MAX : (e == 3u || e == 4u) ? (u32)INT_MIN : 0u;
             }
         }
-        c3_publish();
-        C3_PROBE(5);   // accumulators cleared, stores drained
-        if (tid == 0) {
-            u32* ar = barr + (size_t)f * 3 * (P.strips + 1);                      // arrivals per boundary | (unused) | roots per strip
-            s_up = (s > 0) ? (int)atomicAdd(ar + s, 1u) : -1;                       // boundary s lies between strips s - 1 and s
-            s_dn = (s + 1 < P.strips) ? (int)atomicAdd(ar + s + 1, 1u) : -1;
-        }
-        __syncthreads();
-        const int take[2] = {s_up == 1 ? s : -1, s_dn == 1 ? s + 1 : -1};           // boundaries this block is the second arriver of
-        for (int t = 0; t < 2; t++) {
-            const int b = take[t];
-            if (b < 0) continue;                                                    // block-uniform
-            const int y = b * P.R;
-            const u32 blo = (u32)b * P.ids, bup = blo - P.ids;
-            // The roots of the two rows that meet, out of the neighbours' u16 blocks into LDS (coalesced write-through reads; lpar is free
-            // by now): the ids of a row and of its partner in the 2x2 numbering interleave, so a row pair is one contiguous range of
-            // 2 * wb ids - the first of the lower strip, the last of the upper one.  (Pixel numbering: one row = wb ids.)
-            const u32 span = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;
-            const u32 up0 = P.ids - span;                                           // first id of the upper strip's last row (pair)
-            const u32 upoff = (bup + up0) & 1u;                                     // (an odd first id: the pair loads start one entry early)
-            const u32 nlo = (span + 1) / 2, nup = (span + upoff + 1) / 2;           // words: two u16 each
-            u32* s_lo = lpar;
-            u32* s_up16 = lpar + nlo;                                               // nlo + nup <= ids: lpar holds both
-            __syncthreads();
-            for (u32 k = tid; k < nlo; k += NT) s_lo[k] = ld_rlx(f16 + blo / 2 + k);
-            for (u32 k = tid; k < nup; k += NT) s_up16[k] = ld_rlx(f16 + (bup + up0 - upoff) / 2 + k);
-            for (u32 k = tid; k < 512; k += NT) pairs[k] = 0xffffffffu;
-            __syncthreads();
-            C3_PROBE(6);   // boundary rows staged
-            const unsigned short* lo16 = reinterpret_cast<const unsigned short*>(s_lo);
-            const unsigned short* up16 = reinterpret_cast<const unsigned short*>(s_up16) + upoff;
-            // eight threads share a word of the boundary row and take its segments in turn
-            for (int j = tid >> 3; j < ww && !(dbg & 1); j += NT / 8) {
-                const size_t idx = (size_t)y * ww + j;
-                const u64 w = fb[idx];
-                if (!w) continue;
-                const u64 um = fb[idx - ww];
-                const u64 ul = j > 0 ? fb[idx - ww - 1] : 0ull;
-                const u64 ur = j + 1 < ww ? fb[idx - ww + 1] : 0ull;
-                if (!(um | (ul >> 63) | (ur & 1ull))) continue;
-                u64 rem = w;
-                int ord = 0;
-                while (rem) {
-                    const int sb = __ffsll((long long)rem) - 1;
-                    const int eb = run_end(rem, sb);
-                    const u64 Sg = bit_range(sb, eb);
-                    rem &= ~Sg;
-                    if ((ord++ & 7) != (tid & 7)) continue;
-                    const u32 a = blo + (u32)lo16[c3_rel(G, 0, 64 * j + sb)];
-                    auto meet = [&](int xup) {
-                        const u32 bb = bup + (u32)up16[c3_rel(G, P.R - 1, xup) - up0];
-                        // a pair some thread of the block has already united (the big component, over and over) is not united again
-                        const u32 slot = ((a * 2654435761u) ^ (bb * 40503u)) >> 24;
-                        if (pairs[2 * slot] == a && pairs[2 * slot + 1] == bb) return;
-                        pairs[2 * slot] = a; pairs[2 * slot + 1] = bb;             // (a torn entry only costs a repeated union)
-                        c3_unite(fpar, ffl, fch, a, bb);
-                    };
-                    u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
-                    while (c) {
-                        const int bt = __ffsll((long long)c) - 1;
-                        const int st = run_start(um, bt), en = run_end(um, bt);
-                        meet(64 * j + st);
-                        c &= ~bit_range(st, en);
-                    }
-                    if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) meet(64 * (j - 1) + run_start(ul, 63));
-                    if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) meet(64 * (j + 1));
-                }
-            }
-            __syncthreads();
-            C3_PROBE(7);   // boundary unions
-        }
+        C3_PROBE(5);   // accumulators cleared
     }
     C3_PROBE_END(0);
+}
+
+// ---- K1b: the strips of a frame meet.  One item per (handed-over frame, boundary): a launch of its own, so that every boundary finds
+// both its strips complete without anybody waiting, the work is spread evenly (handled by whichever strip finished second it was not:
+// 1.7 x between the busiest and the average block) and plain cached loads serve. ------------------------------------------------------
+// dynamic LDS: the u16 roots of the two rows that meet, two per word
+__global__ __launch_bounds__(256) void k_ccl3_bound(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
+                                                    const u32* __restrict__ clist, u32* __restrict__ parent, u32* __restrict__ flags,
+                                                    u32* __restrict__ child, const u32* __restrict__ root16, int dbg)
+{
+    const u32 nc = *ncrowded;
+    if (nc == 0 || P.strips < 2) return;
+    extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
+    __shared__ u32 pairs[512];                                // 256 recently united (lower root, upper root) pairs of the boundary at hand
+    const int NT = 256, tid = threadIdx.x, ww = G.ww;
+    u32* stage = reinterpret_cast<u32*>(c3_lds);
+    const u32 nb = (u32)(P.strips - 1);
+    const u32 total = nc * nb;
+    C3_PROBE_DECL;
+    for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+        const u32 f = clist[item / nb];
+        const int b = (int)(item % nb) + 1;                   // the boundary between strips b - 1 and b
+        const u64* fb = bits + (size_t)f * G.h * ww;
+        u32* fpar = parent + (size_t)f * G.nids;
+        u32* ffl = flags + (size_t)f * G.nw32;
+        u32* fch = child + (size_t)f * G.nw32;
+        const u32* f16 = root16 + (size_t)f * G.nids;
+        const int y = b * P.R;
+        const u32 blo = (u32)b * P.ids, bup = blo - P.ids;
+        // The ids of a row and of its partner in the 2x2 numbering interleave, so a row pair is one contiguous range of 2 * wb ids:
+        // the first of the lower strip, the last of the upper one.  (Pixel numbering: one row = wb ids.)
+        const u32 span = (G.numbering == VP_CCL_BLOCK2X2) ? 2u * (u32)G.wb : (u32)G.wb;
+        const u32 up0 = P.ids - span;                         // first id of the upper strip's last row (pair)
+        const u32 upoff = (bup + up0) & 1u;                   // (an odd first id: the pair loads start one entry early)
+        const u32 nlo = (span + 1) / 2, nup = (span + upoff + 1) / 2;
+        u32* s_lo = stage;
+        u32* s_up16 = stage + nlo;
+        __syncthreads();
+        for (u32 k = tid; k < nlo; k += NT) s_lo[k] = f16[blo / 2 + k];
+        for (u32 k = tid; k < nup; k += NT) s_up16[k] = f16[(bup + up0 - upoff) / 2 + k];
+        for (u32 k = tid; k < 512; k += NT) pairs[k] = 0xffffffffu;
+        __syncthreads();
+        C3_PROBE(6);   // boundary rows staged
+        const unsigned short* lo16 = reinterpret_cast<const unsigned short*>(s_lo);
+        const unsigned short* up16 = reinterpret_cast<const unsigned short*>(s_up16) + upoff;
+        // eight threads share a word of the boundary row and take its segments in turn
+        for (int j = tid >> 3; j < ww && !(dbg & 1); j += NT / 8) {
+            const size_t idx = (size_t)y * ww + j;
+            const u64 w = fb[idx];
+            if (!w) continue;
+            const u64 um = fb[idx - ww];
+            const u64 ul = j > 0 ? fb[idx - ww - 1] : 0ull;
+            const u64 ur = j + 1 < ww ? fb[idx - ww + 1] : 0ull;
+            if (!(um | (ul >> 63) | (ur & 1ull))) continue;
+            u64 rem = w;
+            int ord = 0;
+            while (rem) {
+                const int sb = __ffsll((long long)rem) - 1;
+                const int eb = run_end(rem, sb);
+                const u64 Sg = bit_range(sb, eb);
+                rem &= ~Sg;
+                if ((ord++ & 7) != (tid & 7)) continue;
+                const u32 a = blo + (u32)lo16[c3_rel(G, 0, 64 * j + sb)];
+                auto meet = [&](int xup) {
+                    const u32 bb = bup + (u32)up16[c3_rel(G, P.R - 1, xup) - up0];
+                    // a pair some thread of the block has already united (the big component, over and over) is not united again
+                    const u32 slot = ((a * 2654435761u) ^ (bb * 40503u)) >> 24;
+                    if (pairs[2 * slot] == a && pairs[2 * slot + 1] == bb) return;
+                    pairs[2 * slot] = a; pairs[2 * slot + 1] = bb;                 // (a torn entry only costs a repeated union)
+                    c3_unite(fpar, ffl, fch, a, bb);
+                };
+                u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
+                while (c) {
+                    const int bt = __ffsll((long long)c) - 1;
+                    const int st = run_start(um, bt), en = run_end(um, bt);
+                    meet(64 * j + st);
+                    c &= ~bit_range(st, en);
+                }
+                if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) meet(64 * (j - 1) + run_start(ul, 63));
+                if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) meet(64 * (j + 1));
+            }
+        }
+        __syncthreads();
+        C3_PROBE(7);   // boundary unions
+    }
+    C3_PROBE_END(1);
 }
 
 // ---- ranks: one item per (handed-over frame, strip) once every boundary of the launch above is through ---------------------------------
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
         }
         C3_PROBE(7);   // totals
     }
-    C3_PROBE_END(1);
+    C3_PROBE_END(2);
 }
 
 // ---- K3: rows of the components that span strips, the background row, zeros past the last label -----------------------------------

@@ -19,7 +19,7 @@ t = {"thr": torch.empty((B, H, W), dtype=torch.uint8, device="cuda"), "lab": tor
 b = _vp.ChainBuffers(); b.bgr = d.data_ptr(); b.threshed = t["thr"].data_ptr(); b.labels = t["lab"].data_ptr()
 b.stats, b.centroids, b.nlabels = t["st"].data_ptr(), t["ce"].data_ptr(), t["nl"].data_ptr()
 desc = _vp.make_chain_desc(W, H, _vp.BGR2GRAY, (lo, 0, 0), (255, 255, 255), [], ccl=1, max_labels=ML)
-out = np.zeros(32)
+out = np.zeros(48)
 for _ in range(2): ctx.chain_run(desc, b, B)
 ctx.synchronize(); L.vp_debug_probe3(out.ctypes.data)
 ctx.profile_begin(24)
@@ -27,11 +27,13 @@ ctx.chain_run(desc, b, B)
 pr = ctx.profile_end()
 L.vp_debug_probe3(out.ctypes.data)
 print({k: round(1e3 * v[0] / v[1], 1) for k, v in pr.items()})
-names = [["bits staged", "parents set", "unions", "flatten + roots", "dump issued", "acc cleared + drained", "boundary rows staged", "boundary unions"],
+names = [["bits staged", "parents set", "unions", "flatten + roots", "dump issued", "acc cleared"],
+         ["", "", "", "", "", "", "boundary rows staged", "boundary unions"],
          ["bases + staged", "local roots ranked", "root labels", "accumulate", "emit rows / table", "table flushed", "label stores", "totals"]]
 for k, nm in enumerate(names):
     blocks = max(out[16 * k + 15], 1)
     tot = out[16 * k:16 * k + 15].sum()
-    print(["k_ccl3_link", "k_ccl3_label"][k], f"us per block over {int(blocks)} blocks: total {tot / blocks / 100:.1f}")
+    print(["k_ccl3_link", "k_ccl3_bound", "k_ccl3_label"][k], f"us per block over {int(blocks)} blocks: total {tot / blocks / 100:.1f}")
     for i, n in enumerate(nm):
+        if not n: continue
         print(f"   {n:24s} {out[16 * k + i] / blocks / 100:9.1f}  {100 * out[16 * k + i] / max(tot, 1):5.1f} %")
