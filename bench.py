@@ -252,7 +252,7 @@ def main():
             extras["runtime_e2e_bins"] = MH.runtime_rate("bins", seconds=2.0)
             up = MH.pcie_upload_rate(ctx)
             for tag, (fw, fh, nb) in (("host_fed_1080p", (1920, 1080, 10)), ("host_fed_4k", (3840, 2160, 4))):
-                r = MH.host_fed_rate(fw, fh, batch=32, batches=nb, ring=3)
+                r = MH.host_fed_rate(fw, fh, batch=32, batches=nb, ring=4)
                 r["pcie_upload_GBps_measured_now"] = round(up, 2)
                 r["frac_of_pcie"] = round(r["pcie_GBps"] / up, 3)
                 extras[tag] = r

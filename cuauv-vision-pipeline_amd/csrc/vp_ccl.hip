@@ -728,16 +728,19 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
         if (P3.ok && c3_dry != 1) {
             // two launches that read the list of handed-over frames and leave at once when it is empty (the usual case)
             if (c3_dry != 2) { vp_prof_scope ps(ctx, VPK_CCL_LOCAL);
-              hipLaunchKernelGGL(k_ccl3_link, dim3((unsigned)(ctx->num_cu * 4)), dim3(C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+              static const int lgrid = getenv("VP_C3_LGRID") ? atoi(getenv("VP_C3_LGRID")) : 16;
+              hipLaunchKernelGGL(k_ccl3_link, dim3((unsigned)(ctx->num_cu * lgrid)), dim3(C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
                                  ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, (ccl_acc*)ws.acc, max_labels, c3_dbg); }
             { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY);
               const size_t span = (size_t)2 * G.wb + 4;     // u16 roots of the two rows (row pairs) that meet: span entries each
-              hipLaunchKernelGGL(k_ccl3_bound, dim3((unsigned)(ctx->num_cu * 8)), dim3(256), span * 4 + 16, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent, ws.flags,
+              static const int bgrid = getenv("VP_C3_BGRID") ? atoi(getenv("VP_C3_BGRID")) : 64;   // blocks per CU in the grid: items differ a lot in cost, the dispatcher balances
+              hipLaunchKernelGGL(k_ccl3_bound, dim3((unsigned)(ctx->num_cu * bgrid)), dim3(256), span * 4 + 16, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent, ws.flags,
                                  ws.c3_child, ws.seglabel, c3_dbg); }
             { vp_prof_scope ps(ctx, VPK_CCL_RANK);
               hipLaunchKernelGGL(k_ccl3_rank, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.prefix, ws.c3_barr, ws.c3_lroot, ws.parent); }
             if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
-              hipLaunchKernelGGL(k_ccl3_label, dim3((unsigned)(ctx->num_cu * 2)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+              static const int agrid = getenv("VP_C3_AGRID") ? atoi(getenv("VP_C3_AGRID")) : 2;
+              hipLaunchKernelGGL(k_ccl3_label, dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
                                  ws.flags, ws.c3_child, ws.prefix, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
                                  d_centroids, c3_dbg); }
             if (d_stats || d_centroids) {

@@ -120,7 +120,7 @@ class BatchDispatcher:
     """
 
     def __init__(self, devices, batch, height, width, chain=None, rank=0, world=1, ring=2, bind_numa=True, make_runner=None,
-                 sysfs="/sys", pci_lookup=None):
+                 sysfs="/sys", pci_lookup=None, copy_threads=4):
         self.devices = list(devices)
         self.batch, self.h, self.w = int(batch), int(height), int(width)
         n_shards = int(world) * len(self.devices)
@@ -131,6 +131,7 @@ class BatchDispatcher:
         self._pending = collections.OrderedDict()
         self._next_id = 0
         self._errors = []
+        self.copy_threads = max(1, int(copy_threads))                             # staging copy of a slot: this many threads per feeder
         self.bound_cpus = {}                                                      # device -> CPUs its feeders run on (empty: not bound)
         self._threads = []
         started = threading.Barrier(len(self.devices) * max(1, ring) + 1)
@@ -160,6 +161,27 @@ class BatchDispatcher:
         started.wait()
         if self._errors:
             return
+        # The staging copy (frames -> page-locked slot) is the one touch of the frames on the host and what bounds the host-fed rate:
+        # one thread moves about 10 GB/s, the link takes 50, so a slot's frames are copied in slices by a few threads of the feeder's
+        # own (numpy releases the interpreter for the copy; the threads inherit the feeder's CPU binding).
+        pool = None
+        if self.copy_threads > 1 and hi - lo > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(min(self.copy_threads, hi - lo), thread_name_prefix=f"vp-copy-d{dev}")
+        try:
+            self._feed(di, lo, hi, runner, pool)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=False)
+
+    def _feed(self, di, lo, hi, runner, pool):
+        def stage(frames):
+            if pool is None:
+                np.copyto(runner.input, frames[lo:hi])
+                return
+            k = pool._max_workers
+            cuts = [lo + (hi - lo) * i // k for i in range(k + 1)]
+            list(pool.map(lambda ab: np.copyto(runner.input[ab[0] - lo:ab[1] - lo], frames[ab[0]:ab[1]]), zip(cuts, cuts[1:])))
         while True:
             item = self._in[di].get()
             if item is None:
@@ -169,7 +191,7 @@ class BatchDispatcher:
                 if runner is None:
                     res = {}
                 else:
-                    np.copyto(runner.input, frames[lo:hi])                       # staging copy: the only touch of the frames on the host
+                    stage(frames)
                     out = runner.run()
                     res = {k: np.array(v, copy=True) for k, v in out.items() if isinstance(v, np.ndarray)}
                     for k, v in out.items():

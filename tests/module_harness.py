@@ -436,7 +436,7 @@ def pcie_upload_rate(ctx, nbytes=256 << 20, reps=4):
     return reps * nbytes / dt / 1e9
 
 
-def host_fed_rate(w, h, batch=32, batches=8, ring=3, share=1):
+def host_fed_rate(w, h, batch=32, batches=8, ring=4, share=1):
     """Frames per second of vision.dispatch.BatchDispatcher on this box's device: `batch`-deep batches of host frames through pinned
     staging, the red_buoy chain, statistics back (BASELINE config 4 at 4K).  Beside it the PCIe rate it amounts to."""
     import frames as F

@@ -114,6 +114,58 @@ def test_runner_failure_reaches_the_caller():
         BatchDispatcher([0], 4, 8, 8, make_runner=Broken, bind_numa=False)
 
 
+def test_video_capture_source_feeds_the_dispatcher(oracle, tmp_path):
+    """BASELINE config 4's wiring end to end on the CPU: a frame stack played by vision.capture_sources.video (one frame per tick into a
+    shared-memory block, capture_sources/video.py:9-29) is read back, gathered into batches and sharded over three stand-in devices by
+    BatchDispatcher; every frame's result equals the oracle's and comes back in capture order."""
+    import time
+    from vision.capture_sources.video import Video
+    from vision.core.bindings.camera_message_framework import BlockAccessor, ReadStatus
+    from vision.dispatch import BatchDispatcher
+    n, h, w, batch = 12, 36, 64, 6
+    stack = np.stack([F.s1_buoy(i, w, h) for i in range(n)])
+    path = tmp_path / "clip.npy"
+    np.save(path, stack)
+    d = f"pytv4{os.getpid()}"
+    src = Video(str(path), [d], fps=100, loop=True)          # (the clip repeats: the reader attaches whenever it does)
+    t = threading.Thread(target=src.run_event_loop)
+    got = []
+    with BatchDispatcher([0, 1, 2], batch, h, w, make_runner=OracleRunner, bind_numa=False, ring=2) as disp:
+        t.start()
+        try:
+            with BlockAccessor(d) as r:
+                pending, submitted, t0 = [], 0, time.time()
+                while len(got) < n // batch and time.time() - t0 < 30:
+                    st, frame, stamp = r.read_frame()
+                    if st == ReadStatus.SUCCESS and frame is not None:
+                        pending.append(np.array(frame, copy=True))
+                    elif st == ReadStatus.FRAMEWORK_DELETED:
+                        break
+                    if len(pending) == batch:
+                        disp.submit(np.stack(pending)); submitted += 1
+                        got.append((np.stack(pending), disp.collect()))
+                        pending = []
+                    time.sleep(0.001)
+        finally:
+            src._quit_flag.set()
+            t.join(5)
+            src.close()
+    assert got, "no batch made it through"
+    for frames, (bid, parts) in got:
+        assert [p[:2] for p in parts] == [(0, 2), (2, 4), (4, 6)]
+        for lo, hi, res in parts:
+            for k in range(lo, hi):
+                ref = oracle.chain(frames[k], oracle.MODE_LAB, (0, 150, 0), (255, 255, 255), [oracle.OPEN, oracle.CLOSE], 5, 5, 2, 64, want_labels=False)
+                assert int(res["nlabels"][k - lo]) == ref["nlabels"]
+                assert np.array_equal(res["stats"][k - lo][:ref["nlabels"]], ref["stats"])
+    # the latest-wins ring may drop frames when the reader is slow; what was read is in capture order and from the clip
+    flat = [fr for frames, _ in got for fr in frames]
+    seen = [int(np.argmax([np.array_equal(fr, s) for s in stack])) for fr in flat]
+    assert all(np.array_equal(stack[i], fr) for i, fr in zip(seen, flat))
+    steps = [(b - a) % n for a, b in zip(seen, seen[1:])]
+    assert all(1 <= st < n for st in steps) and sum(steps) < 3 * n, seen        # forwards through the (repeating) clip, never backwards
+
+
 def test_a_failed_batch_does_not_wedge_the_dispatcher():
     """A feeder that raises on one batch: collect() raises for that batch once every device has answered, the batch leaves the
     books, the next collect() serves the next batch; close() returns although batches were never collected."""
