@@ -741,7 +741,7 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
             if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
               static const int agrid = getenv("VP_C3_AGRID") ? atoi(getenv("VP_C3_AGRID")) : 2;
               hipLaunchKernelGGL(k_ccl3_label, dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.prefix, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
+                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
                                  d_centroids, c3_dbg); }
             if (d_stats || d_centroids) {
                 vp_prof_scope ps(ctx, VPK_CCL_FINAL);

@@ -27,10 +27,9 @@
 #define C3_IDS 8192            // segment ids per strip = entries of the LDS union-find
 #define C3_LINK_THREADS 256
 #define C3_LABEL_THREADS 512
-#define C3_ACC 512             // local components whose statistics are accumulated per pass over the strip (= C3_LABEL_THREADS)
+#define C3_ACC 1024            // local components whose statistics are accumulated per pass over the strip
 #define C3_TAB 128             // entries of a strip's table of partial components (beyond it: straight to global memory)
-static_assert(C3_ACC == C3_LABEL_THREADS, "the emission step of k_ccl3_label maps one thread to one local root of a pass");
-#define C3_MAX_STRIPS 1024     // per-strip root counts of a frame are scanned in LDS by every block of the later launches
+#define C3_MAX_STRIPS 512      // per-strip root counts of a frame are scanned in LDS by every block of the later launches
 
 #ifdef VP_PROBE   // measurement builds only: time per phase (100 MHz wall clock ticks), summed over a block's items
 __device__ unsigned long long g_c3_probe[3][2048][16];
@@ -419,12 +418,16 @@ __global__ __launch_bounds__(256) void k_ccl3_rank(ccl_geom G, c3_plan P, const 
 }
 
 // ---- K2: labels, statistics, label image ------------------------------------------------------------------------------------------
-// dynamic LDS: lbits[R * ww] u64 | lab[ids] u32 | lr16[ids] u16 | lrb, lrp, gfl, gpf, gch [ids / 32] u32 each | accumulators 6 x C3_ACC u32
+// One item per (handed-over frame, strip).  Everything about the strip is in LDS: its bits, the local rank of every segment's root
+// (u16; the link launch left root ids, rewritten here once the roots are ranked), the label and the id of every local root by rank,
+// the strip's slices of the bitmaps, statistics accumulators for C3_ACC components at a time, a small table of partial components.
+// dynamic LDS: lbits[R * ww] u64 | lab[ids / 2] u32 | lr16[ids] u16 | rid[ids / 2] u16 | lrb, lrp, gfl, gpf, gch [ids / 32] u32 | 6 x C3_ACC u32
 __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
                                                                  const u32* __restrict__ clist, const u32* __restrict__ parent,
                                                                  const u32* __restrict__ flags, const u32* __restrict__ child,
-                                                                 const u32* __restrict__ prefix, const u32* __restrict__ root16,
-                                                                 const u32* __restrict__ barr, c3_state* __restrict__ state, int32_t* __restrict__ nlabels,
+                                                                 const u32* __restrict__ prefix, const u32* __restrict__ lrootbits,
+                                                                 const u32* __restrict__ root16, const u32* __restrict__ barr,
+                                                                 c3_state* __restrict__ state, int32_t* __restrict__ nlabels,
                                                                  ccl_acc* __restrict__ acc, int max_labels, int32_t* __restrict__ labels,
                                                                  int32_t* __restrict__ stats, double* __restrict__ cent, int dbg)
 {
@@ -432,20 +435,18 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
     if (nc == 0) return;
     extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
     __shared__ u32 red[C3_LABEL_THREADS / 64 + 1];
-    __shared__ contrib part[C3_LABEL_THREADS / 64];
     __shared__ u32 sbase[C3_MAX_STRIPS + 2];                   // roots in the strips before each strip
-    __shared__ u32 s_nroots;
     __shared__ u32 t_label[C3_TAB];                            // labels of the components this strip only holds a part of ...
-    __shared__ contrib t_rec[C3_TAB];
-    __shared__ unsigned short rlist[C3_ACC];                   // ids of the local roots of the pass, by local rank                          // ... and what the strip adds to them
+    __shared__ contrib t_rec[C3_TAB];                          // ... and what the strip adds to them
     const int NT = C3_LABEL_THREADS;
     const int ww = G.ww, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwmax = P.R * ww;
-    const u32 nsl = P.ids / 32;
+    const u32 nsl = P.ids / 32, nrmax = P.ids / 2;
     u64* lbits = c3_lds;
     u32* lab = reinterpret_cast<u32*>(c3_lds + nwmax);
-    unsigned short* lr16 = reinterpret_cast<unsigned short*>(lab + P.ids);
-    u32* lrb = reinterpret_cast<u32*>(lr16 + P.ids);
+    unsigned short* lr16 = reinterpret_cast<unsigned short*>(lab + nrmax);
+    unsigned short* rid = lr16 + P.ids;
+    u32* lrb = reinterpret_cast<u32*>(rid + nrmax);
     u32* lrp = lrb + nsl;
     u32* gfl = lrp + nsl;
     u32* gpf = gfl + nsl;
@@ -470,17 +471,17 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
         const u32* ffl = flags + (size_t)f * G.nw32;
         const u32* fpf = prefix + (size_t)f * G.nw32;
         const u32* fch = child + (size_t)f * G.nw32;
+        const u32* flr = lrootbits + (size_t)f * G.nw32;
         const u32* f16 = root16 + (size_t)f * G.nids;
+        const u32* scount = barr + (size_t)f * 3 * (P.strips + 1) + 2 * (P.strips + 1);
         ccl_acc* facc = acc + (size_t)f * max_labels;
         const u32 base = (u32)s * P.ids;
         const u32 lim = min(P.ids, G.nids - base);
-        __syncthreads();
-        c3_strip_bases<C3_LABEL_THREADS>(P, barr + (size_t)f * 3 * (P.strips + 1) + 2 * (P.strips + 1), sbase, red);
-        if (s == 0 && tid == 0) {                             // the frame's label count: background + every root
-            const u32 nl = sbase[P.strips] + 1u;
-            if (nlabels) nlabels[f] = (int32_t)nl;
-            state[f].pad = nl;
-        }
+        __syncthreads();                                      // the previous item's LDS is done with
+        // ---- everything the strip needs from global memory, requested together --------------------------------------------------------
+        u32 sc[(C3_MAX_STRIPS + C3_LABEL_THREADS - 1) / C3_LABEL_THREADS];
+#pragma unroll
+        for (int q = 0; q < (C3_MAX_STRIPS + C3_LABEL_THREADS - 1) / C3_LABEL_THREADS; q++) sc[q] = (q * NT + tid < P.strips) ? scount[q * NT + tid] : 0u;
         C3_FOR_WORDS(r, j, i, NT) lbits[i] = fb[(size_t)(y0 + r) * ww + j];
         for (u32 k = tid; k < lim / 2; k += NT) reinterpret_cast<u32*>(lr16)[k] = f16[base / 2 + k];
         for (u32 k = tid; k < nsl; k += NT) {
@@ -488,27 +489,41 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
             gfl[k] = in ? ffl[base / 32 + k] : 0u;
             gpf[k] = in ? fpf[base / 32 + k] : 0u;
             gch[k] = in ? fch[base / 32 + k] : 0u;
-            lrb[k] = 0u;
+            lrb[k] = in ? flr[base / 32 + k] : 0u;
         }
         for (int k = tid; k < C3_TAB; k += NT) { t_label[k] = 0u; contrib_zero(t_rec[k]); }
-        __syncthreads();
-        C3_PROBE(0);   // strip bases, everything staged
-        // local roots (a segment that is its own root), their ranks within the strip
-        C3_FOR_WORDS(r, j, i, NT) {
-            u64 st = lbits[i] & ~(lbits[i] << 1);
-            while (st) {
-                const int sb = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                const u32 id = c3_rel(G, r, 64 * j + sb);
-                if ((u32)lr16[id] == id) atomicOr(lrb + (id >> 5), 1u << (id & 31));
+        // roots in the strips before each strip: exclusive scan of the per-strip counts (the same in every block of the frame)
+        {
+            u32 run = 0;
+#pragma unroll
+            for (int q = 0; q < (C3_MAX_STRIPS + C3_LABEL_THREADS - 1) / C3_LABEL_THREADS; q++) {
+                if (q * NT >= P.strips) break;                // block-uniform
+                const u32 c = sc[q];
+                u32 inc = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+                __syncthreads();
+                if (lane == 63) red[wv] = inc;
+                __syncthreads();
+                u32 off = 0, tot = 0;
+                for (int k = 0; k < NT / 64; k++) { const u32 t = red[k]; if (k < wv) off += t; tot += t; }
+                if (q * NT + tid < P.strips) sbase[q * NT + tid] = run + off + inc - c;
+                run += tot;
+            }
+            if (tid == 0) {
+                sbase[P.strips] = run;
+                if (s == 0) {                                 // the frame's label count: background + every root
+                    if (nlabels) nlabels[f] = (int32_t)(run + 1u);
+                    state[f].pad = run + 1u;
+                }
             }
         }
         __syncthreads();
+        C3_PROBE(0);   // strip bases, everything staged
+        // ---- local ranks of the local roots (prefix of the local-root bitmap), their ids by rank --------------------------------------
+        u32 nroots;
         {
-            u32 c = 0;
-            const u32 per = (nsl + NT - 1) / NT;                // 1 for every supported geometry (ids <= 8192 -> 256 words)
-            const u32 lo = min((u32)tid * per, nsl), hi = min(lo + per, nsl);
-            for (u32 k = lo; k < hi; k++) c += (u32)__popc(lrb[k]);
+            const u32 c = tid < nsl ? (u32)__popc(lrb[tid]) : 0u;      // a slice is at most 256 words: one per thread
             u32 inc = c;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
@@ -516,38 +531,53 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
             __syncthreads();
             u32 off = 0, tot = 0;
             for (int k = 0; k < NT / 64; k++) { const u32 t = red[k]; if (k < wv) off += t; tot += t; }
-            u32 run = off + inc - c;
-            for (u32 k = lo; k < hi; k++) { lrp[k] = run; run += (u32)__popc(lrb[k]); }
-            if (tid == 0) s_nroots = tot;
-        }
-        __syncthreads();
-        const u32 nroots = s_nroots;
-        C3_PROBE(1);   // local roots ranked
-        // label of every local root: still a root of the frame -> its rank, from the strip's own slice; absorbed -> walk to the root
-        C3_FOR_WORDS(r, j, i, NT) {
-            u64 st = lbits[i] & ~(lbits[i] << 1);
-            while (st) {
-                const int sb = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                const u32 id = c3_rel(G, r, 64 * j + sb);
-                if ((u32)lr16[id] != id) continue;
-                const u32 bit = 1u << (id & 31);
-                u32 label;
-                if (gfl[id >> 5] & bit) {
-                    label = sbase[s] + gpf[id >> 5] + (u32)__popc(gfl[id >> 5] & (bit - 1u)) + 1u;
-                } else if (dbg & 32) {
-                    label = 1;
-                } else {
-                    u32 g = base + id;
-                    for (u32 q = fpar[g]; q != g; q = fpar[g]) g = q;
-                    label = sbase[g / P.ids] + fpf[g >> 5] + (u32)__popc(ffl[g >> 5] & ((1u << (g & 31)) - 1u)) + 1u;
+            nroots = tot;
+            if (tid < nsl) {
+                u32 rk = off + inc - c;
+                lrp[tid] = rk;
+                u32 m = lrb[tid];
+                while (m) {                                   // labels of the local roots, while their ids are at hand
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const u32 id = ((u32)tid << 5) + (u32)b;
+                    const u32 bit = 1u << b;
+                    rid[rk] = (unsigned short)id;
+                    u32 label;
+                    if (gfl[tid] & bit) {                     // still a root of the frame: its rank, from the strip's own slice
+                        label = sbase[s] + gpf[tid] + (u32)__popc(gfl[tid] & (bit - 1u)) + 1u;
+                    } else {                                  // absorbed: the ranking launch left the frame's root in its parent entry
+                        u32 g = base + id;
+                        for (u32 q = fpar[g]; q != g; q = fpar[g]) g = q;
+                        label = sbase[g / P.ids] + fpf[g >> 5] + (u32)__popc(ffl[g >> 5] & ((1u << (g & 31)) - 1u)) + 1u;
+                    }
+                    lab[rk] = label;
+                    rk++;
                 }
-                lab[id] = label;
             }
         }
         __syncthreads();
-        C3_PROBE(2);   // labels of the local roots
-        // statistics per local component, C3_ACC components per pass
+        C3_PROBE(1);   // local roots ranked and labelled
+        // every segment's entry: the id of its root -> the local rank of its root
+        C3_FOR_WORDS(r, j, i, NT) {
+            u64 st = lbits[i] & ~(lbits[i] << 1);
+            u32 ids_[4], rk_[4];                              // (reads first, writes after: a root's own entry is somebody's read)
+            while (st) {
+                int cnt = 0;
+                while (st && cnt < 4) {
+                    const int sb = __ffsll((long long)st) - 1;
+                    st &= st - 1;
+                    const u32 id = c3_rel(G, r, 64 * j + sb);
+                    const u32 root = lr16[id];
+                    ids_[cnt] = id;
+                    rk_[cnt] = lrp[root >> 5] + (u32)__popc(lrb[root >> 5] & ((1u << (root & 31)) - 1u));
+                    cnt++;
+                }
+                for (int q = 0; q < cnt; q++) lr16[ids_[q]] = (unsigned short)rk_[q];
+            }
+        }
+        __syncthreads();
+        C3_PROBE(2);   // ranks in place of root ids
+        // ---- statistics per local component, C3_ACC components per pass ---------------------------------------------------------------
         contrib tot_c;
         contrib_zero(tot_c);
         for (u32 c0 = 0; c0 < nroots && !(dbg & 8); c0 += C3_ACC) {
@@ -555,7 +585,7 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
             __syncthreads();
             // Every segment adds to its component's accumulators.  A wave's lanes mostly name the same component when one is large (half
             // the pixels of 50 % noise belong to one): 64 LDS atomics on one word take 64 turns, so the lanes that agree with the first
-            // active lane are combined with shuffles first and added once (6 ms -> 1 ms per 128 frames of such noise).
+            // active lane are combined with shuffles first and added once.
             for (int i0 = 0; i0 < nrows * ww; i0 += NT) {
                 const int i = i0 + tid;
                 const bool valid = i < nrows * ww;
@@ -568,11 +598,8 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
                         const int sb = __ffsll((long long)rem) - 1;
                         const int eb = run_end(rem, sb);
                         rem &= ~bit_range(sb, eb);
-                        const u32 me = c3_rel(G, r, 64 * j + sb);
-                        const u32 root = lr16[me];
-                        k = lrp[root >> 5] + (u32)__popc(lrb[root >> 5] & ((1u << (root & 31)) - 1u)) - c0;
+                        k = (u32)lr16[c3_rel(G, r, 64 * j + sb)] - c0;
                         act = k < (u32)C3_ACC;
-                        if (act && root == me) rlist[k] = (unsigned short)me;
                         len = (u32)(eb - sb + 1);
                         xs = (u32)(64 * j + sb); xe = (u32)(64 * j + eb);
                         sxv = len * (xs + xe) / 2u; syv = len * (u32)r; rowbit = 1u << r;
@@ -604,19 +631,19 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
             }
             __syncthreads();
             C3_PROBE(3);   // accumulate
-            // One lane per local root of this pass.  Complete within the strip (still a root of the frame, no members elsewhere): its row
-            // goes straight out.  Otherwise its sums join its label's entry of a small LDS table, lanes of a wave that carry the same label
-            // combined with shuffles first (at 50 % noise a strip holds about a thousand fragments of the one big component), and the table
-            // goes to the frame's accumulators once per strip - not once per fragment (54 M global atomics per 128 frames before).
-            {
-                // lanes in the order of the local ranks = in the order of the labels: neighbouring lanes write neighbouring rows
-                const u32 k = (u32)tid;                                             // (C3_ACC == the block's thread count)
+            // One lane per local root of this pass, in the order of the ranks = of the labels: neighbouring lanes write neighbouring rows.
+            // Complete within the strip (still a root of the frame, no members elsewhere): its row goes straight out.  Otherwise its sums
+            // join its label's entry of the strip's table, lanes of a wave that carry the same label combined with shuffles first (at
+            // 50 % noise a strip holds about a thousand fragments of the one big component); the table goes to the frame's accumulators
+            // once per strip, not once per fragment.
+            for (u32 kb = 0; kb < (u32)C3_ACC; kb += NT) {
+                const u32 k = kb + (u32)tid;
                 bool commit = false;
                 u32 label = 0;
                 contrib c;
                 contrib_zero(c);
-                if (k < min((u32)C3_ACC, nroots - c0)) {
-                    const u32 id = rlist[k];
+                if (k < (u32)C3_ACC && c0 + k < nroots) {
+                    const u32 id = rid[c0 + k];
                     const u32 bit = 1u << (id & 31);
                     c.area = a_area[k];
                     c.sx = (u64)a_sx[k];
@@ -624,7 +651,7 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
                     c.minx = (int)a_minx[k]; c.maxx = (int)a_maxx[k];
                     c.miny = y0 + (__ffs((int)a_rows[k]) - 1); c.maxy = y0 + (31 - __clz((int)a_rows[k]));
                     tot_c.area += c.area; tot_c.sx += c.sx; tot_c.sy += c.sy;
-                    label = lab[id];
+                    label = lab[c0 + k];
                     if (label < (u32)max_labels) {
                         if ((gfl[id >> 5] & bit) && !(gch[id >> 5] & bit)) {
                             const size_t o = (size_t)f * max_labels + label;
@@ -667,7 +694,7 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
         for (int k = tid; k < C3_TAB; k += NT)
             if (t_label[k]) acc_commit(facc + t_label[k], t_rec[k]);
         C3_PROBE(5);   // table flushed
-        // the strip's part of the label image: one lane = 4 px = one 16-byte store, labels from LDS
+        // ---- the strip's part of the label image: one lane = 4 px = one 16-byte store, labels from LDS --------------------------------
         if (labels && !(dbg & 16)) {
             int32_t* lrow0 = labels + ((size_t)f * G.h + y0) * G.w;
             const bool vec = (G.w & 3) == 0 && ((((uintptr_t)lrow0) & 15) == 0);
@@ -698,7 +725,7 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
             }
         }
         C3_PROBE(6);   // label stores issued
-        // totals of the strip for the frame's background row: foreground sums, bounding box of the zero pixels
+        // ---- totals of the strip for the frame's background row: foreground sums, bounding box of the zero pixels; one set of atomics per wave
         C3_FOR_WORDS(r, j, i, NT) {
             const u64 z = ~lbits[i] & (j == ww - 1 ? lastmask : ~0ull);
             if (!z) continue;
@@ -708,10 +735,7 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
             tot_c.maxy = max(tot_c.maxy, y0 + r);
         }
         wave_combine(tot_c);
-        if (lane == 0) part[wv] = tot_c;
-        __syncthreads();
-        if (tid == 0) {
-            for (int k = 1; k < NT / 64; k++) contrib_merge(tot_c, part[k]);
+        if (lane == 0) {
             c3_state* st = state + f;
             if (tot_c.area) {
                 atomicAdd(&st->fg_area, tot_c.area);
@@ -809,5 +833,5 @@ __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const 
 static size_t c3_link_lds(const ccl_geom& G, const c3_plan& P) { return (size_t)P.R * G.ww * 8 + (size_t)P.ids * 4 + (size_t)P.ids / 32 * 4; }
 static size_t c3_label_lds(const ccl_geom& G, const c3_plan& P)
 {
-    return (size_t)P.R * G.ww * 8 + (size_t)P.ids * 4 + (size_t)P.ids * 2 + (size_t)P.ids / 32 * 4 * 5 + (size_t)C3_ACC * 4 * 6;
+    return (size_t)P.R * G.ww * 8 + (size_t)P.ids / 2 * 4 + (size_t)P.ids * 2 + (size_t)P.ids / 2 * 2 + (size_t)P.ids / 32 * 4 * 5 + (size_t)C3_ACC * 4 * 6;
 }

@@ -138,11 +138,17 @@ class YOLO:
         """frame -> ((1, 3, H, W) float tensor on the model's device, (scale, left, top)); the letterbox runs as a HIP kernel when the
         model is on the GPU."""
         import torch
-        from vision.devmat import to_host_readonly
-        image = to_host_readonly(image)
+        from vision.devmat import DeviceMat, to_host_readonly
         shape = letterbox_shape(image.shape[0], image.shape[1], self.imgsz)
         if self.device.type == "cuda":
-            t, geom = ops.letterbox(torch.from_numpy(np.ascontiguousarray(image)).to(self.device), shape)
+            if isinstance(image, DeviceMat) and image._host is None:
+                t, geom = ops.letterbox(image, shape)        # already in HBM (the runtime's frames are): no host hop
+                if not hasattr(t, "is_cuda"):
+                    t = torch.from_numpy(t)
+                t = t.to(self.device)
+            else:
+                host = np.array(to_host_readonly(image), copy=True) if isinstance(image, DeviceMat) else np.ascontiguousarray(image)
+                t, geom = ops.letterbox(torch.from_numpy(host).to(self.device), shape)
         else:
             raise RuntimeError("the detector's pre- and post-processing run on the GPU: move the model there with .to('cuda')")
         return t.unsqueeze(0), geom

@@ -42,6 +42,17 @@ def letterbox(image, new_shape=(640, 640), pad_value=114):
         _on_torch_stream(ctx, lambda: _vp.check(_vp.lib().vp_letterbox_dev(ctx.handle, image.data_ptr(), image.shape[1], image.shape[0], W, H,
                                                                             int(pad_value), out.data_ptr(), geom), ctx.handle))
         return out, tuple(float(g) for g in geom)
+    from vision.devmat import DeviceMat
+    if isinstance(image, DeviceMat) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3 and image._host is None \
+            and image.device_valid_for(ctx):
+        # a frame the runtime put into HBM (or an operator's result): letterboxed where it lies, the result is a tensor on that device
+        import torch
+        src = image.dev_ptr                              # (launches whatever still has to produce the image, on the context's stream)
+        ctx.synchronize()                                # ... which must be through before torch's stream reads it
+        out = torch.empty((3, H, W), dtype=torch.float32, device=torch.device("cuda", ctx.device))
+        _on_torch_stream(ctx, lambda: _vp.check(_vp.lib().vp_letterbox_dev(ctx.handle, src, image.shape[1], image.shape[0], W, H,
+                                                                            int(pad_value), out.data_ptr(), geom), ctx.handle))
+        return out, tuple(float(g) for g in geom)
     image = np.ascontiguousarray(image, dtype=np.uint8)
     if image.ndim != 3 or image.shape[2] != 3 or image.size == 0:
         raise ValueError("expected a non-empty (h, w, 3) uint8 image")
