@@ -26,6 +26,7 @@
 // average block.  Kernel boundaries are the cheaper seam here.
 #define C3_IDS 8192            // segment ids per strip = entries of the LDS union-find
 #define C3_LINK_THREADS 256
+#define C3_SPLIT 1               // threads per word of a strip in the union and flatten passes of k_ccl3_link (2 with 512 threads: 12 % slower, more CAS contention)
 #define C3_LABEL_THREADS 512
 #define C3_ACC 1024            // local components whose statistics are accumulated per pass over the strip
 #define C3_TAB 128             // entries of a strip's table of partial components (beyond it: straight to global memory)
@@ -220,11 +221,14 @@ __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __rest
         }
         __syncthreads();
         C3_PROBE(1);   // parents set
-        // unions: with the segment that ends the previous word of the row, and with the 8-connected segments of the row above
-        C3_FOR_WORDS(r, j, i, NT) {
+        // unions: with the segment that ends the previous word of the row, and with the 8-connected segments of the row above.
+        // C3_SPLIT threads share a word and take its segments in turn (a word of noise holds sixteen: a chain of LDS round trips each)
+        for (int i2 = tid; i2 < nrows * ww * C3_SPLIT; i2 += NT) {
+            const int i = i2 / C3_SPLIT, part = i2 - i * C3_SPLIT;
+            const int r = i / ww, j = i - r * ww;
             const u64 w = lbits[i];
             if (!w) continue;
-            if ((w & 1ull) && j > 0 && (lbits[i - 1] >> 63))
+            if (part == 0 && (w & 1ull) && j > 0 && (lbits[i - 1] >> 63))
                 lds_unite(lpar, c3_rel(G, r, 64 * j), c3_rel(G, r, 64 * (j - 1) + run_start(lbits[i - 1], 63)));
             if (r == 0) continue;
             const u64 um = lbits[i - ww];
@@ -232,11 +236,13 @@ __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __rest
             const u64 ur = j + 1 < ww ? lbits[i - ww + 1] : 0ull;
             if (!(um | (ul >> 63) | (ur & 1ull))) continue;
             u64 rem = w;
+            int ord = 0;
             while (rem) {
                 const int sb = __ffsll((long long)rem) - 1;
                 const int eb = run_end(rem, sb);
                 const u64 Sg = bit_range(sb, eb);
                 rem &= ~Sg;
+                if ((ord++ % C3_SPLIT) != part) continue;
                 const u32 me = c3_rel(G, r, 64 * j + sb);
                 u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
                 while (c) {
@@ -252,11 +258,15 @@ __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __rest
         __syncthreads();
         C3_PROBE(2);   // unions
         // flatten (read-only walks; every thread stores the root over its OWN entries), note the local roots
-        C3_FOR_WORDS(r, j, i, NT) {
+        for (int i2 = tid; i2 < nrows * ww * C3_SPLIT; i2 += NT) {
+            const int i = i2 / C3_SPLIT, part = i2 - i * C3_SPLIT;
+            const int r = i / ww, j = i - r * ww;
             u64 st = lbits[i] & ~(lbits[i] << 1);
+            int ord = 0;
             while (st) {
                 const int sb = __ffsll((long long)st) - 1;
                 st &= st - 1;
+                if ((ord++ % C3_SPLIT) != part) continue;
                 const u32 id = c3_rel(G, r, 64 * j + sb);
                 const u32 root = lds_root(lpar, id);
                 lpar[id] = root;
