@@ -694,25 +694,31 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
         const int mcap = (ctx->ccl_mcap >= 0 && ctx->ccl_mcap < C2_MCAP) ? ctx->ccl_mcap : C2_MCAP;
         // frames the merge hands over go to the crowded-frame kernels of vp_ccl3.inl when the geometry suits them (it does for every
         // frame up to 8192 px wide), otherwise to the one-level kernels
-        c3_plan P3 = c3_make_plan(G);
+        static const u32 c3_max_ids = getenv("VP_C3_IDS") ? (u32)atoi(getenv("VP_C3_IDS")) : (u32)C3_IDS;
+        c3_plan P3 = c3_make_plan(G, std::min<u32>(c3_max_ids, C3_IDS));
+        const bool c3_tall = P3.ids > 8192;           // taller strips: twice the threads per block (one word per thread still)
         static const bool c3_off = getenv("VP_CCL3") && atoi(getenv("VP_CCL3")) == 0;
         size_t lds3a = 0, lds3b = 0;
         if (P3.ok && !c3_off && (size_t)P3.strips + 1 <= c3_strips_cap(h) && sizeof(c3_state) == C3_STATE_BYTES) {
             lds3a = c3_link_lds(G, P3);
             lds3b = c3_label_lds(G, P3);
             static size_t attr_a = 0, attr_b = 0;      // (grow-only; kernels accept more dynamic LDS than the 64 KB default once told so)
-            if (lds3a > attr_a) { if (hipFuncSetAttribute((const void*)k_ccl3_link, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3a) == hipSuccess) attr_a = lds3a; else { (void)hipGetLastError(); P3.ok = 0; } }
-            if (P3.ok && lds3b > attr_b) { if (hipFuncSetAttribute((const void*)k_ccl3_label, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3b) == hipSuccess) attr_b = lds3b; else { (void)hipGetLastError(); P3.ok = 0; } }
+            const void* fa_ = c3_tall ? (const void*)k_ccl3_link<2 * C3_LINK_THREADS> : (const void*)k_ccl3_link<C3_LINK_THREADS>;
+            const void* fb_ = c3_tall ? (const void*)k_ccl3_label<2 * C3_LABEL_THREADS> : (const void*)k_ccl3_label<C3_LABEL_THREADS>;
+            static size_t attr_a2 = 0, attr_b2 = 0;
+            size_t& ra = c3_tall ? attr_a2 : attr_a; size_t& rb = c3_tall ? attr_b2 : attr_b;
+            if (lds3a > ra) { if (hipFuncSetAttribute(fa_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3a) == hipSuccess) ra = lds3a; else { (void)hipGetLastError(); P3.ok = 0; } }
+            if (P3.ok && lds3b > rb) { if (hipFuncSetAttribute(fb_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3b) == hipSuccess) rb = lds3b; else { (void)hipGetLastError(); P3.ok = 0; } }
         } else {
             P3.ok = 0;
         }
         const int c3_strips = P3.ok ? P3.strips : 0;
         if (P3.ok && getenv("VP_CCL3_OCC")) {   // diagnosis: blocks per CU the runtime grants the crowded-frame kernels
             int oa = 0, ob = 0;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link, C3_LINK_THREADS, lds3a);
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label, C3_LABEL_THREADS, lds3b);
+            if (c3_tall) { hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link<2 * C3_LINK_THREADS>, 2 * C3_LINK_THREADS, lds3a); hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label<2 * C3_LABEL_THREADS>, 2 * C3_LABEL_THREADS, lds3b); }
+            else { hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link<C3_LINK_THREADS>, C3_LINK_THREADS, lds3a); hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label<C3_LABEL_THREADS>, C3_LABEL_THREADS, lds3b); }
             hipFuncAttributes fa, fb2;
-            hipFuncGetAttributes(&fa, (const void*)k_ccl3_link); hipFuncGetAttributes(&fb2, (const void*)k_ccl3_label);
+            hipFuncGetAttributes(&fa, c3_tall ? (const void*)k_ccl3_link<2 * C3_LINK_THREADS> : (const void*)k_ccl3_link<C3_LINK_THREADS>); hipFuncGetAttributes(&fb2, c3_tall ? (const void*)k_ccl3_label<2 * C3_LABEL_THREADS> : (const void*)k_ccl3_label<C3_LABEL_THREADS>);
             fprintf(stderr, "ccl3 occupancy: link %d blocks/CU (LDS %zu + %zu static, %d regs), label %d blocks/CU (LDS %zu + %zu static, %d regs), CUs %d\n", oa, lds3a, fa.sharedSizeBytes, fa.numRegs, ob, lds3b, fb2.sharedSizeBytes, fb2.numRegs, ctx->num_cu);
         }
         { vp_prof_scope ps(ctx, VPK_CCL2_LOCAL);
@@ -729,7 +735,9 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
             // two launches that read the list of handed-over frames and leave at once when it is empty (the usual case)
             if (c3_dry != 2) { vp_prof_scope ps(ctx, VPK_CCL_LOCAL);
               static const int lgrid = getenv("VP_C3_LGRID") ? atoi(getenv("VP_C3_LGRID")) : 16;
-              hipLaunchKernelGGL(k_ccl3_link, dim3((unsigned)(ctx->num_cu * lgrid)), dim3(C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+              if (c3_tall) hipLaunchKernelGGL(k_ccl3_link<2 * C3_LINK_THREADS>, dim3((unsigned)(ctx->num_cu * lgrid)), dim3(2 * C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, (ccl_acc*)ws.acc, max_labels, c3_dbg);
+              else hipLaunchKernelGGL(k_ccl3_link<C3_LINK_THREADS>, dim3((unsigned)(ctx->num_cu * lgrid)), dim3(C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
                                  ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, (ccl_acc*)ws.acc, max_labels, c3_dbg); }
             { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY);
               const size_t span = (size_t)2 * G.wb + 4;     // u16 roots of the two rows (row pairs) that meet: span entries each
@@ -740,7 +748,10 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
               hipLaunchKernelGGL(k_ccl3_rank, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.prefix, ws.c3_barr, ws.c3_lroot, ws.parent); }
             if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
               static const int agrid = getenv("VP_C3_AGRID") ? atoi(getenv("VP_C3_AGRID")) : 2;
-              hipLaunchKernelGGL(k_ccl3_label, dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+              if (c3_tall) hipLaunchKernelGGL(k_ccl3_label<2 * C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(2 * C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
+                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
+                                 d_centroids, c3_dbg);
+              else hipLaunchKernelGGL(k_ccl3_label<C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
                                  ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
                                  d_centroids, c3_dbg); }
             if (d_stats || d_centroids) {

@@ -24,10 +24,10 @@
 // block that finishes a frame's last boundary ranks the frame"): every per-frame stage then ran on ONE block (ranks 3 ms, rows 6 ms
 // per 128 frames), agent-scope fences around every hand-over cost another 2.5 ms, and second arrivers were 1.7 x busier than the
 // average block.  Kernel boundaries are the cheaper seam here.
-#define C3_IDS 8192            // segment ids per strip = entries of the LDS union-find
-#define C3_LINK_THREADS 256
+#define C3_IDS 16384           // most segment ids per strip = entries of the LDS union-find (1080p: 16 rows = 15,360; VP_C3_IDS=8192: 8 rows)
+#define C3_LINK_THREADS 256    // k_ccl3_link, strips of up to 8192 ids; twice that for taller ones
 #define C3_SPLIT 1               // threads per word of a strip in the union and flatten passes of k_ccl3_link (2 with 512 threads: 12 % slower, more CAS contention)
-#define C3_LABEL_THREADS 512
+#define C3_LABEL_THREADS 512   // k_ccl3_label, likewise
 #define C3_ACC 1024            // local components whose statistics are accumulated per pass over the strip
 #define C3_TAB 128             // entries of a strip's table of partial components (beyond it: straight to global memory)
 #define C3_MAX_STRIPS 512      // per-strip root counts of a frame are scanned in LDS by every block of the later launches
@@ -56,12 +56,12 @@ struct c3_plan {
     int ok;
 };
 
-static c3_plan c3_make_plan(const ccl_geom& G)
+static c3_plan c3_make_plan(const ccl_geom& G, u32 max_ids)
 {
     c3_plan P = {0, 0, 0, 0};
     for (int R = 32; R >= 2; R >>= 1) {
         const u32 ids = (u32)R * (u32)G.wb;
-        if (ids <= C3_IDS && (ids % 32u) == 0 && R * G.ww <= 512) { P.R = R; P.ids = ids; break; }
+        if (ids <= max_ids && (ids % 32u) == 0 && R * G.ww <= 512) { P.R = R; P.ids = ids; break; }
     }
     if (!P.R || G.ww > 64) return P;
     P.strips = (G.h + P.R - 1) / P.R;
@@ -176,7 +176,8 @@ __device__ void c3_strip_bases(const c3_plan& P, const u32* __restrict__ scount,
 
 // ---- K1: strip-local union-find, boundaries, ranks --------------------------------------------------------------------------------
 // dynamic LDS: lbits[R * ww] u64 | lpar[ids] u32 | lroots[ids / 32] u32
-__global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
+template <int LT>
+__global__ __launch_bounds__(LT) void k_ccl3_link(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
                                                                const u32* __restrict__ clist, u32* __restrict__ parent, u32* __restrict__ flags,
                                                                u32* __restrict__ child, u32* __restrict__ lrootbits, u32* __restrict__ root16,
                                                                ccl_acc* __restrict__ acc, int max_labels, int dbg)
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(C3_LINK_THREADS) void k_ccl3_link(const u64* __rest
     const u32 nc = *ncrowded;
     if (nc == 0) return;                                      // the common case: nothing was handed over
     extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
-    const int NT = C3_LINK_THREADS;
+    const int NT = LT;
     const int ww = G.ww, tid = threadIdx.x;
     const int nwmax = P.R * ww;
     u64* lbits = c3_lds;
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(256) void k_ccl3_rank(ccl_geom G, c3_plan P, const 
 // (u16; the link launch left root ids, rewritten here once the roots are ranked), the label and the id of every local root by rank,
 // the strip's slices of the bitmaps, statistics accumulators for C3_ACC components at a time, a small table of partial components.
 // dynamic LDS: lbits[R * ww] u64 | lab[ids / 2] u32 | lr16[ids] u16 | rid[ids / 2] u16 | lrb, lrp, gfl, gpf, gch [ids / 32] u32 | 6 x C3_ACC u32
-__global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
+template <int AT>
+__global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
                                                                  const u32* __restrict__ clist, const u32* __restrict__ parent,
                                                                  const u32* __restrict__ flags, const u32* __restrict__ child,
                                                                  const u32* __restrict__ prefix, const u32* __restrict__ lrootbits,
@@ -444,11 +446,11 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
     const u32 nc = *ncrowded;
     if (nc == 0) return;
     extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
-    __shared__ u32 red[C3_LABEL_THREADS / 64 + 1];
+    __shared__ u32 red[AT / 64 + 1];
     __shared__ u32 sbase[C3_MAX_STRIPS + 2];                   // roots in the strips before each strip
     __shared__ u32 t_label[C3_TAB];                            // labels of the components this strip only holds a part of ...
     __shared__ contrib t_rec[C3_TAB];                          // ... and what the strip adds to them
-    const int NT = C3_LABEL_THREADS;
+    const int NT = AT;
     const int ww = G.ww, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwmax = P.R * ww;
     const u32 nsl = P.ids / 32, nrmax = P.ids / 2;
@@ -489,9 +491,9 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
         const u32 lim = min(P.ids, G.nids - base);
         __syncthreads();                                      // the previous item's LDS is done with
         // ---- everything the strip needs from global memory, requested together --------------------------------------------------------
-        u32 sc[(C3_MAX_STRIPS + C3_LABEL_THREADS - 1) / C3_LABEL_THREADS];
+        u32 sc[(C3_MAX_STRIPS + AT - 1) / AT];
 #pragma unroll
-        for (int q = 0; q < (C3_MAX_STRIPS + C3_LABEL_THREADS - 1) / C3_LABEL_THREADS; q++) sc[q] = (q * NT + tid < P.strips) ? scount[q * NT + tid] : 0u;
+        for (int q = 0; q < (C3_MAX_STRIPS + AT - 1) / AT; q++) sc[q] = (q * NT + tid < P.strips) ? scount[q * NT + tid] : 0u;
         C3_FOR_WORDS(r, j, i, NT) lbits[i] = fb[(size_t)(y0 + r) * ww + j];
         for (u32 k = tid; k < lim / 2; k += NT) reinterpret_cast<u32*>(lr16)[k] = f16[base / 2 + k];
         for (u32 k = tid; k < nsl; k += NT) {
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(C3_LABEL_THREADS, 4) void k_ccl3_label(const u64* _
         {
             u32 run = 0;
 #pragma unroll
-            for (int q = 0; q < (C3_MAX_STRIPS + C3_LABEL_THREADS - 1) / C3_LABEL_THREADS; q++) {
+            for (int q = 0; q < (C3_MAX_STRIPS + AT - 1) / AT; q++) {
                 if (q * NT >= P.strips) break;                // block-uniform
                 const u32 c = sc[q];
                 u32 inc = c;
