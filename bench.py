@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--regions", type=int, default=5,
                     help="timed regions of exactly --steps steps each (every one bracketed by barrier + synchronize, MAX over ranks); "
                          "`value` comes from the median region (SURVEY 8d: median of 5)")
-    ap.add_argument("--traffic-file", default=os.path.join("profiles", "r02", "traffic.json"),
+    ap.add_argument("--traffic-file", default=os.path.join("profiles", "r03", "traffic.json"),
                     help="rocprofv3 --pmc summary (tools/pmc_traffic.py) to take roofline.traffic from; used only when its recorded "
                          "source digest equals the running build and it holds the exact kernel instantiation that was timed")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
