@@ -433,6 +433,27 @@ int cmf_peek_validate(Block* block, uint64_t uid, uint64_t ticket)
     return load_acq(&s.seq_begin) == ticket ? 1 : 0;
 }
 
+int cmf_wait_for_frame(Block* block, uint64_t have_uid, uint32_t timeout_us)
+{
+    if (!block || !block->shm) { set_err("null block"); return CMF_ERR_INVALID; }
+    ShmHeader* h = block->shm;
+    if (load_acq(&h->uid) > have_uid || __atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return 1;
+    int rc = pthread_mutex_lock(&h->mutex);
+    if (rc == EOWNERDEAD) { pthread_mutex_consistent(&h->mutex); rc = 0; }
+    if (rc != 0) return 0;
+    if (!(load_acq(&h->uid) > have_uid) && !__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) {
+        struct timeval now;
+        gettimeofday(&now, nullptr);
+        struct timespec until;
+        const uint64_t ns = (uint64_t)now.tv_usec * 1000ull + (uint64_t)timeout_us * 1000ull;
+        until.tv_sec = now.tv_sec + (time_t)(ns / 1000000000ull);
+        until.tv_nsec = (long)(ns % 1000000000ull);
+        pthread_cond_timedwait(&h->cond, &h->mutex, &until);
+    }
+    pthread_mutex_unlock(&h->mutex);
+    return (load_acq(&h->uid) > have_uid || __atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) ? 1 : 0;
+}
+
 int cmf_block_mapping(Block* block, void** base, uint64_t* bytes)
 {
     if (!block || !block->shm || !base || !bytes) { set_err("null block or result pointer"); return CMF_ERR_INVALID; }

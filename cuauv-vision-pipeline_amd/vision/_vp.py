@@ -124,6 +124,12 @@ _SIGS = {
     "vp_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "vp_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vp_feeder_start": (C.c_void_p, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vp_feeder_take": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "vp_feeder_release": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vp_feeder_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "vp_feeder_stop": (C.c_int, [C.c_void_p]),
+    "vp_feeder_destroy": (C.c_int, [C.c_void_p]),
     "vp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vp_draw_polylines_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "vp_add_weighted_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_size_t, C.c_void_p]),

@@ -70,12 +70,15 @@ def _load():
     lib.cmf_peek_validate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     lib.cmf_block_mapping.restype = C.c_int
     lib.cmf_block_mapping.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.cmf_wait_for_frame.restype = C.c_int
+    lib.cmf_wait_for_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
     return lib
 
 
 _dllib = _load()
 _PRIVATE_READS = os.environ.get("VP_PRIVATE_READS", "1") != "0"
 _DEVICE_FRAMES = os.environ.get("VP_DEVICE_FRAMES", "1") != "0"
+_FEEDER = os.environ.get("VP_FEEDER", "1") != "0"          # device frames fetched ahead by a thread of libvp's own (vp_feeder_*)
 _registered = {}            # mapping base address -> [reference count, bytes]: block mappings page-locked for the copy engine
 _registered_lock = threading.Lock()
 _device_frames_broken = False   # no device / hipHostRegister refused shared-memory mappings: decided once per process
@@ -93,6 +96,62 @@ def _register_mapping(ctx, base, nbytes):
             return False
         _registered[base] = [1, nbytes]
         return True
+
+
+class _Feeder:
+    """libvp's frame feeder for one block (include/vp.h vp_feeder_*): a native thread that keeps the block's newest frame in HBM.
+    The device buffers live as long as this object, i.e. as long as any image handed out still refers to it."""
+
+    def __init__(self, device, block_ptr, entry_bytes):
+        from vision import _vp
+        fn = lambda name: C.cast(getattr(_dllib, name), C.c_void_p)      # noqa: E731 - the block library's entry points, by address
+        self.handle = _vp.lib().vp_feeder_start(int(device), block_ptr, int(entry_bytes), fn("cmf_wait_for_frame"), fn("cmf_peek_frame"),
+                                                fn("cmf_peek_validate"), fn("create_frame"), fn("delete_frame"))
+        if not self.handle:
+            raise RuntimeError("vp_feeder_start failed")
+
+    def take(self):
+        """-> (status 0 / 1 / 2, _Frame or None, device pointer or None)"""
+        from vision import _vp
+        meta, dev = _Frame(), C.c_void_p()
+        rc = _vp.lib().vp_feeder_take(self.handle, C.byref(meta), C.byref(dev))
+        return rc, (meta if rc == 0 else None), dev.value
+
+    def counts(self):
+        from vision import _vp
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        _vp.lib().vp_feeder_counts(self.handle, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
+    def stop(self):
+        from vision import _vp
+        if self.handle:
+            _vp.lib().vp_feeder_stop(self.handle)
+
+    def __del__(self):
+        try:
+            from vision import _vp
+            if self.handle:
+                _vp.lib().vp_feeder_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _SlotBuf:
+    """One of a feeder's device buffers while a module holds the frame in it (what DeviceMat keeps as its allocation)."""
+    __slots__ = ("ptr", "_feeder", "_ctx", "__weakref__")
+
+    def __init__(self, feeder, ctx, ptr):
+        self.ptr, self._feeder, self._ctx = ptr, feeder, ctx
+
+    def __del__(self):
+        try:
+            from vision import _vp
+            if self._feeder.handle:
+                _vp.lib().vp_feeder_release(self._feeder.handle, self._ctx.handle if self._ctx is not None and self._ctx.handle else None, self.ptr)
+        except Exception:
+            pass
 
 
 def _unregister_mapping(base):
@@ -357,6 +416,19 @@ class BlockAccessor:
             return self.read_frame_private()
         from vision import _vp
         from vision.devmat import DeviceMat, _DevBuf
+        if _FEEDER and self._feeder is None and self._feeder_ok:
+            try:
+                self._feeder = _Feeder(ctx.device, self._block_ptr, int(_dllib.cmf_block_entry_size(self._block_ptr)))
+            except Exception:
+                self._feeder_ok = False                         # this accessor copies in the loop instead
+        if self._feeder is not None:
+            rc, fr, dev = self._feeder.take()
+            if rc == 2:
+                return ReadStatus.FRAMEWORK_DELETED, self._frame_data, self._acquisition_time, True
+            if rc != 0:
+                return ReadStatus.NO_NEW_FRAME, self._frame_data, self._acquisition_time, True
+            self.torn_reads = self._feeder.counts()[1]
+            return self._planes_on_device(ctx, fr, _SlotBuf(self._feeder, ctx, dev))
         lib = _vp.lib()
         payload, ticket = C.c_void_p(), C.c_uint64()
         while True:
@@ -378,7 +450,16 @@ class BlockAccessor:
             if _dllib.cmf_peek_validate(self._block_ptr, fr.uid, ticket.value) == 1:
                 break
             self.torn_reads += 1                                # lapped by the writer during the copy: a newer frame is there
+        return self._planes_on_device(ctx, fr, buf)
+
+    def _planes_on_device(self, ctx, fr, buf):
+        """The planes of the frame `fr` describes, as device images over the one allocation `buf` that holds its payload."""
+        from vision.devmat import DeviceMat
+        total, count = int(fr.total_size), int(fr.plane_count)
         self._acquisition_time = int(fr.acquisition_time)
+        if count == 0 or total == 0:
+            self._frame_data, self._last_plane_names = None, tuple()
+            return ReadStatus.SUCCESS, None, self._acquisition_time, True
         planes, names = [], []
         for idx in range(count):
             m = fr.planes[idx]
@@ -392,7 +473,7 @@ class BlockAccessor:
             names.append(m.name.decode())
         self._last_plane_names = tuple(names)
         self._frame_data = planes[0] if count == 1 else tuple(planes)
-        return status, self._frame_data, self._acquisition_time, True
+        return ReadStatus.SUCCESS, self._frame_data, self._acquisition_time, True
 
     # -- lifetime --------------------------------------------------------------------------------
     def __enter__(self):
@@ -417,10 +498,14 @@ class BlockAccessor:
         self._acquisition_time, self._frame_data = 0, None
         self._private_buf, self._private_installed = None, False
         self._dev_state, self._dev_base, self.torn_reads = None, None, 0
+        self._feeder, self._feeder_ok = None, True
         self._inside_ctx_manager = True
         return self
 
     def __exit__(self, exc_type, exc_val, exc_tb):
+        if getattr(self, "_feeder", None) is not None:
+            self._feeder.stop()                                 # its thread reads the block: gone before the block is
+            self._feeder = None                                 # (images handed out keep the device buffers alive)
         if getattr(self, "_dev_state", None) and self._dev_base is not None:
             _unregister_mapping(self._dev_base)                 # before the mapping can go away
             self._dev_state, self._dev_base = None, None

@@ -102,6 +102,10 @@ uint64_t cmf_block_entry_size(Block* block);
 int cmf_peek_frame(Block* block, Frame* frame, const void** payload, uint64_t* ticket);
 int cmf_peek_validate(Block* block, uint64_t uid, uint64_t ticket);
 int cmf_block_mapping(Block* block, void** base, uint64_t* bytes);
+/* cmf_wait_for_frame(block, have_uid, timeout_us): returns 1 as soon as the block holds a frame newer than `have_uid` (or has been
+ * deleted), 0 after `timeout_us` without one; waits on the block's condition variable the way read_frame(block_thread = true) does
+ * (lib/camera_message_framework.cpp:395-410), with a caller-chosen bound.  For a feeder thread that must not poll. */
+int cmf_wait_for_frame(Block* block, uint64_t have_uid, uint32_t timeout_us);
 
 #ifdef __cplusplus
 }

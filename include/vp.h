@@ -346,6 +346,25 @@ int vp_host_free(vp_ctx* ctx, void* host_ptr);   /* ctx may be NULL */
  * (the caller keeps its copying path); unregister before the memory is unmapped. */
 int vp_host_register(vp_ctx* ctx, void* host_ptr, size_t bytes);
 int vp_host_unregister(vp_ctx* ctx, void* host_ptr);   /* ctx may be NULL */
+/* ---- frame feeder: the newest frame of a camera_message_framework block kept in HBM by a thread of the library's own ----------
+ * Replaces, for a module on the runtime, the per-iteration sequence read_frame (seqlock memcpy, lib/camera_message_framework.cpp:
+ * 379-455) -> np.array(copy) (core/base.py:765-768) -> upload: the feeder waits on the block's condition variable, copies every new
+ * frame out of its ring slot into one of four device buffers on its own stream (the block's mapping must be page-locked:
+ * vp_host_register), checks the slot's sequence number after the copy and publishes the buffer; vp_feeder_take hands the newest one
+ * over without waiting for anything.  The block library is not linked: its five entry points (cmf_wait_for_frame, cmf_peek_frame,
+ * cmf_peek_validate, create_frame, delete_frame of include/camera_message_framework_c.h) are passed as addresses.
+ * take -> 0: meta_out (sizeof(Frame) = 360 bytes) + *dev_out; 1: nothing newer than the last frame taken; 2: block deleted.
+ * release: the buffer may be overwritten once the work queued so far on `consumer`'s stream has passed (consumer may be NULL).
+ * stop ends the thread (buffers handed out stay valid); destroy frees everything. */
+typedef struct vp_feeder vp_feeder;
+vp_feeder* vp_feeder_start(int device, void* block, size_t entry_bytes, void* fn_wait_for_frame, void* fn_peek_frame, void* fn_peek_validate,
+                           void* fn_create_frame, void* fn_delete_frame);
+int vp_feeder_take(vp_feeder* f, void* meta_out, void** dev_out);
+int vp_feeder_release(vp_feeder* f, vp_ctx* consumer, void* dev);
+int vp_feeder_counts(vp_feeder* f, unsigned long long* fetched, unsigned long long* dropped_as_lapped);
+int vp_feeder_stop(vp_feeder* f);
+int vp_feeder_destroy(vp_feeder* f);
+
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
 /* The same copy enqueued on the context's stream: src_host must stay unchanged until vp_wait_uploads (or vp_synchronize) returns.
  * vp_wait_uploads waits for the copies only, not for kernels enqueued behind them: an operator enqueues the copy of its input,

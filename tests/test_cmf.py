@@ -6,6 +6,7 @@ import multiprocessing as mp
 import os
 import re
 import struct
+import threading
 import time
 
 import numpy as np
@@ -280,3 +281,28 @@ def test_private_and_public_reads_mixed(monkeypatch):
         st, mine2, t, private = r.read_frame_private()
         assert private and np.array_equal(mine2, c) and np.array_equal(mine, a) and len(made) == 2
         assert not np.shares_memory(mine, mine2)
+
+
+def test_wait_for_frame():
+    """cmf_wait_for_frame (addition to the reference's ABI, for a feeder thread that must not poll): 0 after the timeout while nothing
+    newer than `have_uid` exists, 1 at once when something does, 1 as soon as a writer publishes while it waits, 1 for a deleted block."""
+    d = _name("waitf")
+    lib = cmf._dllib
+    img = np.zeros((4, 4, 3), np.uint8)
+    w = BlockAccessor(d, max_entry_size_bytes=img.nbytes)
+    w.__enter__()
+    try:
+        with BlockAccessor(d) as r:
+            t0 = time.time()
+            assert lib.cmf_wait_for_frame(r._block_ptr, 0, 30000) == 0 and 0.02 < time.time() - t0 < 1.0
+            w.write_frame(1, img)
+            assert lib.cmf_wait_for_frame(r._block_ptr, 0, 1000000) == 1          # already there: no wait
+            assert lib.cmf_wait_for_frame(r._block_ptr, 1, 10000) == 0
+            th = threading.Thread(target=lambda: (time.sleep(0.05), w.write_frame(2, img)))
+            th.start()
+            t0 = time.time()
+            assert lib.cmf_wait_for_frame(r._block_ptr, 1, 2000000) == 1 and time.time() - t0 < 1.5
+            th.join()
+            assert lib.cmf_wait_for_frame(None, 0, 10) < 0
+    finally:
+        w.__exit__(None, None, None)

@@ -26,6 +26,17 @@ def cv2mod():
         sys.modules.pop("cv2", None)
 
 
+def _next_frame(r, timeout=2.0):
+    """read_frame_device until it reports something other than NO_NEW_FRAME: with the feeder thread a frame becomes visible a
+    fraction of a millisecond after it was written (the runtime's loop polls anyway)."""
+    t0 = time.time()
+    while True:
+        out = r.read_frame_device()
+        if out[0] != ReadStatus.NO_NEW_FRAME or time.time() - t0 > timeout:
+            return out
+        time.sleep(0.0005)
+
+
 def test_device_reads_deliver_the_frames_that_were_written(vp):
     """read_frame_device: every plane arrives as a device image that equals what the writer published (types, shapes, names, time),
     is private to the reader (later frames do not touch it) and is writable like the runtime's copies."""
@@ -38,13 +49,13 @@ def test_device_reads_deliver_the_frames_that_were_written(vp):
         st, data, t, private = r.read_frame_device()
         assert st == ReadStatus.NO_NEW_FRAME and data is None
         w.write_frame(11, [("forward", a), ("depth", depth)])
-        st, data, t, private = r.read_frame_device()
+        st, data, t, private = _next_frame(r)
         assert st == ReadStatus.SUCCESS and t == 11 and private and r.last_plane_names() == ("forward", "depth")
         fwd, dep = data
         assert isinstance(fwd, DeviceMat) and isinstance(dep, DeviceMat) and fwd._host is None and dep._host is None
         assert fwd.shape == (200, 320, 3) and fwd.dtype == np.uint8 and dep.shape == (200, 320, 1) and dep.dtype == np.float32
         w.write_frame(12, [("forward", b), ("depth", depth * 2)])
-        st2, data2, t2, _ = r.read_frame_device()
+        st2, data2, t2, _ = _next_frame(r)
         assert st2 == ReadStatus.SUCCESS and t2 == 12
         assert np.array_equal(fwd, a) and np.array_equal(dep[:, :, 0], depth)            # the first frame is untouched by the second
         assert np.array_equal(data2[0], b) and np.array_equal(data2[1][:, :, 0], depth * 2)
@@ -54,7 +65,7 @@ def test_device_reads_deliver_the_frames_that_were_written(vp):
         assert fwd[0, 0, 0] == 7 and np.asarray(data2[0])[0, 0, 0] == b[0, 0, 0]
         # a single-plane frame comes back as one image, and operators take it without an upload
         w.write_frame(13, a)
-        st4, img, t4, _ = r.read_frame_device()
+        st4, img, t4, _ = _next_frame(r)
         assert st4 == ReadStatus.SUCCESS and isinstance(img, DeviceMat) and img.shape == a.shape
         from vision.utils.color import bgr_to_gray
         assert np.array_equal(bgr_to_gray(img)[0], bgr_to_gray(a)[0]) and img._host is None
@@ -245,3 +256,18 @@ def test_buoy_module_gets_device_frames(vp, oracle):
     ref_img = frame.copy()
     draw_contours(ref_img, exp, thickness=10)                  # host rasteriser on a plain array
     assert np.array_equal(drawn, ref_img)
+
+
+def test_feeder_off_reads_in_the_loop(vp, monkeypatch):
+    """VP_FEEDER=0: the same device frames, fetched by the reading thread itself (peek -> DMA -> validate): synchronous, so a frame is
+    there at the first read after its write."""
+    import vision.core.bindings.camera_message_framework as cmfb
+    from vision.devmat import DeviceMat
+    monkeypatch.setattr(cmfb, "_FEEDER", False)
+    vp.default_context()
+    d = f"pytnofeed{PID}"
+    a = F.s1_buoy(4, 320, 200)
+    with BlockAccessor(d, max_entry_size_bytes=a.nbytes) as w, BlockAccessor(d) as r:
+        w.write_frame(5, a)
+        st, img, t, _ = r.read_frame_device()
+        assert st == ReadStatus.SUCCESS and t == 5 and isinstance(img, DeviceMat) and np.array_equal(img, a) and r._feeder is None
