@@ -384,9 +384,10 @@ def body_rates(which="buoy", w=1920, h=1080, calls=200):
     return out
 
 
-def runtime_rate(which="buoy", seconds=3.0, w=1920, h=1080, period=0.0002, flags=("--enable-performance",)):
+def runtime_rate(which="buoy", seconds=3.0, w=1920, h=1080, period=0.0, flags=("--enable-performance",)):
     """Frames per second of a harness module ON THE RUNTIME, end to end: a capture process publishes frames into a shared-memory block
-    faster than the module takes them (`period` s between writes), `ModuleBase.__call__` runs the loop thread: read_messages ->
+    faster than the module takes them (`period` s between writes; 0 = one write after the other, about 4-5 k frames a second),
+    `ModuleBase.__call__` runs the loop thread: read_messages ->
     frame into HBM -> @sources handler / process()."""
     saved = sys.argv[:]
     module_argv(*flags)
