@@ -14,7 +14,8 @@ python3 tools/exp_process.py 400 > $out/${tag}_process.txt 2>&1
 python3 tools/exp_hostfed.py 1080p > $out/${tag}_hostfed.txt 2>&1
 python3 tools/exp_hostfed.py 4k >> $out/${tag}_hostfed.txt 2>&1
 for m in buoy bins gate; do python3 tools/exp_runtime.py 4 $m 2>&1 | tail -1; done > $out/${tag}_runtime.txt
-VP_DEVICE_FRAMES=0 python3 tools/exp_runtime.py 4 buoy 2>&1 | tail -1 >> $out/${tag}_runtime.txt
+VP_FEEDER=0 python3 tools/exp_runtime.py 4 buoy 2>&1 | tail -1 >> $out/${tag}_runtime.txt
+VP_DEVICE_FRAMES=0 python3 tools/exp_runtime.py 4 buoy 0.0002 2>&1 | tail -1 >> $out/${tag}_runtime.txt
 python3 tools/exp_configs.py > $out/${tag}_configs.txt 2>&1
 python3 tools/exp_latency.py > $out/${tag}_latency.txt 2>&1
 python3 -m pytest tests/test_gpu_yolo_module.py -q -s -k rate > $out/${tag}_yolo.txt 2>&1
