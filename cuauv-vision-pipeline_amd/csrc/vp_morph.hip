@@ -18,6 +18,7 @@
 // shuffle: 237 us vs 60 us for 64 x 1080p — one wave per SIMD running serial LDS/shuffle chains) and fusing the
 // strip-local labelling into this kernel (140.6 us vs 81.3 + 58.1 us: both parts are bound by per-block latency).
 #include "vp_internal.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -105,6 +106,30 @@ __global__ __launch_bounds__(256) void k_unpack_bits(const u64* __restrict__ bit
     store_mask16(drow, grp * 16, w, (u32)(wv >> (16 * (grp & 3))) & 0xffffu, (((uintptr_t)drow) & 15) == 0);
 }
 
+// the batch as one run of 16-pixel groups (rows follow each other without a gap when w % 16 == 0): four groups per thread, a wave
+// stores 1 KB per instruction and no lane idles at the end of a row
+__global__ __launch_bounds__(256) void k_unpack_bits_flat(const u64* __restrict__ bits, u32 gpr, int ww, u32 ngroups, uint8_t* __restrict__ dst)
+{
+    for (u32 gb = blockIdx.x * 1024u; gb < ngroups; gb += gridDim.x * 1024u) {
+        const u32 g0 = gb + threadIdx.x;
+        u32 m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 g = g0 + 256u * k;
+            m[k] = 0;
+            if (g < ngroups) {
+                const u32 row = g / gpr, c = g - row * gpr;
+                m[k] = (u32)(bits[(size_t)row * ww + (c >> 2)] >> (16 * (c & 3))) & 0xffffu;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 g = g0 + 256u * k;
+            if (g < ngroups) vp_store16(dst + (size_t)g * 16, expand4m(m[k]), expand4m(m[k] >> 4), expand4m(m[k] >> 8), expand4m(m[k] >> 12));
+        }
+    }
+}
+
 int vpk_pack_bits(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int n, u64* d_bits, int* d_flags)
 {
     const int ww = vp_ww(w);
@@ -117,6 +142,12 @@ int vpk_pack_bits(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h
 int vpk_unpack_bits(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, uint8_t* d_dst)
 {
     const int ww = vp_ww(w);
+    const size_t ngroups = (size_t)n * h * (size_t)(w / 16);
+    if (w % 16 == 0 && (((uintptr_t)d_dst) & 15) == 0 && ngroups > 0 && ngroups < ((size_t)1 << 32) - 2048) {
+        hipLaunchKernelGGL(k_unpack_bits_flat, dim3((unsigned)((ngroups + 1023) / 1024)), dim3(256), 0, ctx->stream, d_bits, (u32)(w / 16), ww, (u32)ngroups, d_dst);
+        VP_HIP(ctx, hipGetLastError());
+        return VP_OK;
+    }
     dim3 grid((unsigned)((size_t)n * h), (unsigned)((ww * 4 + 255) / 256));
     hipLaunchKernelGGL(k_unpack_bits, grid, dim3(256), 0, ctx->stream, d_bits, w, ww, d_dst);
     VP_HIP(ctx, hipGetLastError());
@@ -226,12 +257,100 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits(const u64* __restrict
     }
 }
 
+// Vertical half of a stage, B -> A: a thread takes one word column and a run of K consecutive rows, loads the K + 2R rows its window
+// covers ONCE and slides over them in registers (windows of 2, 4, 8 rows by doubling, the odd row last): (K + 2R) / K LDS reads and
+// about log2(2R) operations per output instead of 2R + 1 reads with two comparisons each.  Rows outside the image never win: min and
+// max are idempotent, so reading the nearest image row again is the same as leaving them out - the row index is clamped to
+// [lo_r, hi_r] and no predicate is left (rows of the image that are not staged only feed halo rows nobody needs any more).
+template <int R, bool DIL, int K>
+__device__ __forceinline__ void mb_vpass(const u64* __restrict__ B, u64* __restrict__ A, int ww, int rows, int lo_r, int hi_r)
+{
+    static_assert(R == 1 || R == 2 || R == 4, "window sizes built by doubling");
+    const int r0 = (int)(threadIdx.x >> 5) * K;
+    if (r0 >= rows) return;
+    auto op = [](u64 a, u64 b) -> u64 { return DIL ? (a | b) : (a & b); };
+    for (int j = threadIdx.x & 31; j < ww; j += 32) {
+        u64 v[K + 2 * R];
+#pragma unroll
+        for (int k = 0; k < K + 2 * R; k++) v[k] = B[min(max(r0 - R + k, lo_r), hi_r) * ww + j];
+        u64 out[K];
+        if constexpr (R == 1) {
+#pragma unroll
+            for (int i = 0; i < K; i++) out[i] = op(op(v[i], v[i + 1]), v[i + 2]);
+        } else {
+            u64 p[K + 2 * R - 1];
+#pragma unroll
+            for (int i = 0; i < K + 2 * R - 1; i++) p[i] = op(v[i], v[i + 1]);                   // 2 rows
+            u64 q[K + 2 * R - 3];
+#pragma unroll
+            for (int i = 0; i < K + 2 * R - 3; i++) q[i] = op(p[i], p[i + 2]);                   // 4 rows
+            if constexpr (R == 2) {
+#pragma unroll
+                for (int i = 0; i < K; i++) out[i] = op(q[i], v[i + 4]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; i++) out[i] = op(op(q[i], q[i + 4]), v[i + 8]);           // 8 rows and the ninth
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (r0 + i < rows) A[(r0 + i) * ww + j] = out[i];
+    }
+}
+
+// one erode / dilate of radius R on the staged rows: horizontal half A -> B, vertical half B -> A
+template <int R, bool dil, int rows>
+__device__ __forceinline__ void mb_stage(u64* __restrict__ A, u64* __restrict__ B, int ww, int ybase, int h, u64 lastmask, int lo_r, int hi_r)
+{
+    // horizontal half: all reads of a thread first (its word column in every 16th row, neighbours at clamped indices and replaced
+    // by the neutral word afterwards - no branch), then straight-line shifts.  Rows outside the image are computed like any other:
+    // nothing reads them (mb_vpass clamps its rows to the image).
+    constexpr u64 neutral = dil ? 0ull : ~0ull;
+    constexpr int RQ = MB_THREADS / 32, NR = (rows + RQ - 1) / RQ;
+    const int rq = threadIdx.x >> 5;
+    for (int j = threadIdx.x & 31; j < ww; j += 32) {
+        const bool first = j == 0, last = j == ww - 1;
+        const int il = first ? 0 : -1, ir = last ? 0 : 1;
+        u64 cur[NR], prv[NR], nxt[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = rq + RQ * k;
+            if (RQ * k + RQ <= rows || r < rows) {
+                const int i = r * ww + j;
+                cur[k] = A[i]; prv[k] = A[i + il]; nxt[k] = A[i + ir];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = rq + RQ * k;
+            if (RQ * k + RQ <= rows || r < rows) {
+                u64 c = cur[k], pv = first ? neutral : prv[k], nx = last ? neutral : nxt[k];
+                if (!dil) {                                   // columns past the image inside the last word count as set
+                    if (last) c |= ~lastmask;
+                    if (j + 1 == ww - 1) nx |= ~lastmask;
+                }
+                u64 acc = c;
+#pragma unroll
+                for (int d = 1; d <= R; d++) {
+                    if (dil) acc |= fsr(nx, c, d) | fsl(c, pv, d);
+                    else acc &= fsr(nx, c, d) & fsl(c, pv, d);
+                }
+                if (last) acc &= lastmask;
+                B[r * ww + j] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    mb_vpass<R, dil, (rows + MB_THREADS / 32 - 1) / (MB_THREADS / 32)>(B, A, ww, rows, lo_r, hi_r);
+    __syncthreads();
+}
+
 // Compile-time specialisation for the plans the modules actually use (square kernels, centre anchor): radii and
 // kinds are template constants, so the shift loops unroll into immediate funnel shifts and the vertical windows
 // into straight-line LDS reads.  KIND bit k = stage k dilates.
 template <int NS, int R0, int R1, int R2, int KIND, int STRIP>
-__global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __restrict__ in, int w, int h, int ww, int strips,
-                                                               u64* __restrict__ out_bits, uint8_t* __restrict__ out_mask)
+__global__ __launch_bounds__(MB_THREADS, 8) void k_morph_bits_sym(const u64* __restrict__ in, int w, int h, int ww, int strips,
+                                                               u64* __restrict__ out_bits, uint8_t* __restrict__ out_mask, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int HALO = R0 + (NS > 1 ? R1 : 0) + (NS > 2 ? R2 : 0);
@@ -244,59 +363,24 @@ __global__ __launch_bounds__(MB_THREADS) void k_morph_bits_sym(const u64* __rest
     const int ybase = y0 - HALO;
     const u64* fin = in + (size_t)frame * h * ww;
     const u64 lastmask = (w & 63) ? ((1ull << (w & 63)) - 1ull) : ~0ull;
+    const int lo_r = max(0, -ybase), hi_r = min(rows - 1, h - 1 - ybase);      // the staged rows that are rows of the image
     MB_FOR_WORDS(r, j, i) {
         const int y = ybase + r;
-        A[i] = (y >= 0 && y < h) ? fin[(size_t)y * ww + j] : 0ull;
+        A[i] = (y >= 0 && y < h && !(dbg & 2)) ? fin[(size_t)y * ww + j] : 0ull;
     }
     __syncthreads();
-#pragma unroll
-    for (int si = 0; si < NS; si++) {
-        const int R = si == 0 ? R0 : (si == 1 ? R1 : R2);
-        const bool dil = (KIND >> si) & 1;
-        const u64 neutral = dil ? 0ull : ~0ull;
-        MB_FOR_WORDS(r, j, i) {
-            const int y = ybase + r;
-            if (y < 0 || y >= h) continue;
-            u64 cur = A[i];
-            u64 prev = j > 0 ? A[i - 1] : neutral;
-            u64 next = j + 1 < ww ? A[i + 1] : neutral;
-            if (!dil) {
-                if (j == ww - 1) cur |= ~lastmask;
-                if (j + 1 == ww - 1) next |= ~lastmask;
-            }
-            u64 acc = cur;
-#pragma unroll
-            for (int d = 1; d <= R; d++) {
-                if (dil) acc |= fsr(next, cur, d) | fsl(cur, prev, d);
-                else acc &= fsr(next, cur, d) & fsl(cur, prev, d);
-            }
-            if (j == ww - 1) acc &= lastmask;
-            B[i] = acc;
-        }
-        __syncthreads();
-        MB_FOR_WORDS(r, j, i) {
-            const int y = ybase + r;
-            if (y < 0 || y >= h) continue;
-            u64 acc = B[i];
-#pragma unroll
-            for (int d = 1; d <= R; d++) {
-                // rows outside the image never win; rows outside the staged range only feed dead halo rows
-                const bool up = (r - d >= 0) && (y - d >= 0), dn = (r + d < rows) && (y + d < h);
-                const u64 a = up ? B[i - d * ww] : neutral, b = dn ? B[i + d * ww] : neutral;
-                if (dil) acc |= a | b;
-                else acc &= a & b;
-            }
-            A[i] = acc;
-        }
-        __syncthreads();
+    if (!(dbg & 1)) {
+        mb_stage<R0, (KIND & 1) != 0, rows>(A, B, ww, ybase, h, lastmask, lo_r, hi_r);
+        if constexpr (NS > 1) mb_stage<R1, ((KIND >> 1) & 1) != 0, rows>(A, B, ww, ybase, h, lastmask, lo_r, hi_r);
+        if constexpr (NS > 2) mb_stage<R2, ((KIND >> 2) & 1) != 0, rows>(A, B, ww, ybase, h, lastmask, lo_r, hi_r);
     }
     const int nout_rows = min(STRIP, h - y0);
-    if (out_bits) {
+    if (out_bits && !(dbg & 4)) {
         u64* fo = out_bits + (size_t)frame * h * ww;
         for (int r = threadIdx.x >> 5; r < nout_rows; r += MB_THREADS / 32)
             for (int j = threadIdx.x & 31; j < ww; j += 32) fo[(size_t)(y0 + r) * ww + j] = A[(HALO + r) * ww + j];
     }
-    if (out_mask) {
+    if (out_mask && !(dbg & 8)) {
         uint8_t* fm = out_mask + (size_t)frame * h * w;
         const int gpr = ww * 4;
         for (int r = threadIdx.x >> 7; r < nout_rows; r += MB_THREADS / 128) {
@@ -318,7 +402,7 @@ static int launch_sym_strip(vp_ctx* ctx, const u64* d_in, int w, int h, int n, u
     if (lds > 64 * 1024) return VP_ERR_UNSUPPORTED;
     vp_prof_scope prof(ctx, VPK_MORPH);
     hipLaunchKernelGGL((k_morph_bits_sym<NS, R0, R1, R2, KIND, STRIP>), dim3((unsigned)((size_t)n * strips)), dim3(MB_THREADS), lds, ctx->stream, d_in, w, h,
-                       ww, strips, d_out_bits, d_out_mask);
+                       ww, strips, d_out_bits, d_out_mask, getenv("VP_MORPH_DBG") ? atoi(getenv("VP_MORPH_DBG")) : 0);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
