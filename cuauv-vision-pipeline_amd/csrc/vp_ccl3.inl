@@ -25,8 +25,7 @@
 // per 128 frames), agent-scope fences around every hand-over cost another 2.5 ms, and second arrivers were 1.7 x busier than the
 // average block.  Kernel boundaries are the cheaper seam here.
 #define C3_IDS 16384           // most segment ids per strip = entries of the LDS union-find (1080p: 16 rows = 15,360; VP_C3_IDS=8192: 8 rows)
-#define C3_LINK_THREADS 256    // k_ccl3_link, strips of up to 8192 ids; twice that for taller ones
-#define C3_SPLIT 1               // threads per word of a strip in the union and flatten passes of k_ccl3_link (2 with 512 threads: 12 % slower, more CAS contention)
+#define C3_LINK_THREADS 512    // k_ccl3_link, strips of up to 8192 ids; twice that for taller ones: a thread per 32-bit HALF of a word
 #define C3_LABEL_THREADS 512   // k_ccl3_label, likewise
 #define C3_ACC 1024            // local components whose statistics are accumulated per pass over the strip
 #define C3_TAB 128             // entries of a strip's table of partial components (beyond it: straight to global memory)
@@ -96,6 +95,32 @@ __device__ __forceinline__ void c3_unite(u32* p, u32* flags, u32* child, u32 a, 
         }
         a = old;
     }
+}
+
+// A contact between two segments of a strip (LDS, strip-relative ids).  Most contacts are the FIRST link of their upper end: one
+// atomicMin on parent[larger] settles them without a find (parents only ever decrease, so the pointers stay a forest).  When the
+// larger id already hung under something else, that something and the smaller id are one component: a real union
+// (compare-and-swap union-find with its finds) - a third of the contacts in raw noise instead of all of them.
+__device__ __forceinline__ void c3_contact(u32* lpar, u32 a, u32 b, int dbg = 0)
+{
+    const u32 hi = max(a, b), lo = min(a, b);
+    if (dbg & 2) { if (hi == 0xfffffff0u) lpar[0] = lo; return; }      // (timing experiments: the walk over the contacts alone)
+    const u32 old = atomicMin(lpar + hi, lo);
+    if (old != hi && old != lo && !(dbg & 4)) lds_unite(lpar, old, lo);  // (dbg 4: ... with the first links, without the real unions)
+}
+
+// first bit of the run of 1s of `w` that holds set bit x, on 32-bit halves (64-bit shifts and counts run at a quarter of the rate)
+__device__ __forceinline__ int c3_run_start(u64 w, int x)
+{
+    const u32 lo = (u32)w, hi = (u32)(w >> 32);
+    if (x >= 32) {
+        const u32 z = ~hi & ((1u << (x - 32)) - 1u);
+        if (z) return 64 - __clz(z);
+        const u32 zl = ~lo;
+        return zl ? 32 - __clz(zl) : 0;
+    }
+    const u32 z = ~lo & ((1u << x) - 1u);
+    return z ? 32 - __clz(z) : 0;
 }
 
 // adds a partial component to the strip's table (LDS), keyed by label; a full table sends it straight to the frame's accumulators
@@ -177,7 +202,7 @@ __device__ void c3_strip_bases(const c3_plan& P, const u32* __restrict__ scount,
 // ---- K1: strip-local union-find, boundaries, ranks --------------------------------------------------------------------------------
 // dynamic LDS: lbits[R * ww] u64 | lpar[ids] u32 | lroots[ids / 32] u32
 template <int LT>
-__global__ __launch_bounds__(LT) void k_ccl3_link(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
+__global__ __launch_bounds__(LT, 8) void k_ccl3_link(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
                                                                const u32* __restrict__ clist, u32* __restrict__ parent, u32* __restrict__ flags,
                                                                u32* __restrict__ child, u32* __restrict__ lrootbits, u32* __restrict__ root16,
                                                                ccl_acc* __restrict__ acc, int max_labels, int dbg)
@@ -210,11 +235,14 @@ __global__ __launch_bounds__(LT) void k_ccl3_link(const u64* __restrict__ bits, 
         for (u32 k = tid; k < P.ids / 32; k += NT) lroots[k] = 0u;
         __syncthreads();
         C3_PROBE(0);   // bits staged
-        // every segment its own parent
-        C3_FOR_WORDS(r, j, i, NT) {
-            u64 st = lbits[i] & ~(lbits[i] << 1);
+        // every segment its own parent.  A thread takes one 32-bit half of a word in this and the two passes below (a word of noise
+        // holds sixteen segments: per-segment work is serial in its thread)
+        for (int i2 = tid; i2 < nrows * ww * 2; i2 += NT) {
+            const int i = i2 >> 1, half = i2 & 1, r = i / ww, j = i - r * ww;
+            const u64 w = lbits[i];
+            u32 st = (u32)((w & ~(w << 1)) >> (32 * half));
             while (st) {
-                const int sb = __ffsll((long long)st) - 1;
+                const int sb = __ffs((int)st) - 1 + 32 * half;
                 st &= st - 1;
                 const u32 id = c3_rel(G, r, 64 * j + sb);
                 lpar[id] = id;
@@ -222,52 +250,52 @@ __global__ __launch_bounds__(LT) void k_ccl3_link(const u64* __restrict__ bits, 
         }
         __syncthreads();
         C3_PROBE(1);   // parents set
-        // unions: with the segment that ends the previous word of the row, and with the 8-connected segments of the row above.
-        // C3_SPLIT threads share a word and take its segments in turn (a word of noise holds sixteen: a chain of LDS round trips each)
-        for (int i2 = tid; i2 < nrows * ww * C3_SPLIT; i2 += NT) {
-            const int i = i2 / C3_SPLIT, part = i2 - i * C3_SPLIT;
-            const int r = i / ww, j = i - r * ww;
+        // contacts: with the segment that ends the previous word of the row, and with the 8-connected segments of the row above.
+        // Every (segment, segment above) pair shows as ONE bit of three masks: the first bit of their vertical overlap; a segment's
+        // last bit with a run above starting one column further (and nothing straight above); a segment's first bit with a run above
+        // ending one column before.  A thread walks the bits of its half of the masks.
+        for (int i2 = tid; i2 < nrows * ww * 2; i2 += NT) {
+            const int i = i2 >> 1, half = i2 & 1, r = i / ww, j = i - r * ww;
             const u64 w = lbits[i];
             if (!w) continue;
-            if (part == 0 && (w & 1ull) && j > 0 && (lbits[i - 1] >> 63))
-                lds_unite(lpar, c3_rel(G, r, 64 * j), c3_rel(G, r, 64 * (j - 1) + run_start(lbits[i - 1], 63)));
+            if (half == 0 && (w & 1ull) && j > 0 && (lbits[i - 1] >> 63))
+                c3_contact(lpar, c3_rel(G, r, 64 * j), c3_rel(G, r, 64 * (j - 1) + c3_run_start(lbits[i - 1], 63)), dbg);
             if (r == 0) continue;
             const u64 um = lbits[i - ww];
             const u64 ul = j > 0 ? lbits[i - ww - 1] : 0ull;
             const u64 ur = j + 1 < ww ? lbits[i - ww + 1] : 0ull;
-            if (!(um | (ul >> 63) | (ur & 1ull))) continue;
-            u64 rem = w;
-            int ord = 0;
-            while (rem) {
-                const int sb = __ffsll((long long)rem) - 1;
-                const int eb = run_end(rem, sb);
-                const u64 Sg = bit_range(sb, eb);
-                rem &= ~Sg;
-                if ((ord++ % C3_SPLIT) != part) continue;
-                const u32 me = c3_rel(G, r, 64 * j + sb);
-                u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
-                while (c) {
-                    const int b = __ffsll((long long)c) - 1;
-                    const int st = run_start(um, b), en = run_end(um, b);
-                    lds_unite(lpar, me, c3_rel(G, r - 1, 64 * j + st));
-                    c &= ~bit_range(st, en);
-                }
-                if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) lds_unite(lpar, me, c3_rel(G, r - 1, 64 * (j - 1) + run_start(ul, 63)));
-                if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) lds_unite(lpar, me, c3_rel(G, r - 1, 64 * (j + 1)));
+            const u64 up_r = (um >> 1) | (ur << 63), up_l = (um << 1) | (ul >> 63);      // the row above, one column to the right / left
+            const u64 V = w & um;
+            u32 vs = (u32)((V & ~(V << 1)) >> (32 * half));
+            u32 dr = (u32)((w & ~(w >> 1) & up_r & ~um) >> (32 * half));
+            u32 dl = (u32)((w & ~(w << 1) & up_l & ~um) >> (32 * half));
+            while (vs) {
+                const int x = __ffs((int)vs) - 1 + 32 * half;
+                vs &= vs - 1;
+                c3_contact(lpar, c3_rel(G, r, 64 * j + c3_run_start(w, x)), c3_rel(G, r - 1, 64 * j + c3_run_start(um, x)), dbg);
+            }
+            while (dr) {
+                const int x = __ffs((int)dr) - 1 + 32 * half;
+                dr &= dr - 1;
+                c3_contact(lpar, c3_rel(G, r, 64 * j + c3_run_start(w, x)), c3_rel(G, r - 1, 64 * j + x + 1), dbg);
+            }
+            while (dl) {
+                const int x = __ffs((int)dl) - 1 + 32 * half;
+                dl &= dl - 1;
+                const u32 b = x > 0 ? c3_rel(G, r - 1, 64 * j + c3_run_start(um, x - 1)) : c3_rel(G, r - 1, 64 * (j - 1) + c3_run_start(ul, 63));
+                c3_contact(lpar, c3_rel(G, r, 64 * j + x), b, dbg);
             }
         }
         __syncthreads();
-        C3_PROBE(2);   // unions
+        C3_PROBE(2);   // contacts
         // flatten (read-only walks; every thread stores the root over its OWN entries), note the local roots
-        for (int i2 = tid; i2 < nrows * ww * C3_SPLIT; i2 += NT) {
-            const int i = i2 / C3_SPLIT, part = i2 - i * C3_SPLIT;
-            const int r = i / ww, j = i - r * ww;
-            u64 st = lbits[i] & ~(lbits[i] << 1);
-            int ord = 0;
+        for (int i2 = tid; i2 < nrows * ww * 2; i2 += NT) {
+            const int i = i2 >> 1, half = i2 & 1, r = i / ww, j = i - r * ww;
+            const u64 w = lbits[i];
+            u32 st = (u32)((w & ~(w << 1)) >> (32 * half));
             while (st) {
-                const int sb = __ffsll((long long)st) - 1;
+                const int sb = __ffs((int)st) - 1 + 32 * half;
                 st &= st - 1;
-                if ((ord++ % C3_SPLIT) != part) continue;
                 const u32 id = c3_rel(G, r, 64 * j + sb);
                 const u32 root = lds_root(lpar, id);
                 lpar[id] = root;
@@ -349,7 +377,7 @@ __global__ __launch_bounds__(256) void k_ccl3_bound(const u64* __restrict__ bits
         C3_PROBE(6);   // boundary rows staged
         const unsigned short* lo16 = reinterpret_cast<const unsigned short*>(s_lo);
         const unsigned short* up16 = reinterpret_cast<const unsigned short*>(s_up16) + upoff;
-        // eight threads share a word of the boundary row and take its segments in turn
+        // eight threads share a word of the boundary row: one byte each of the three contact masks (see k_ccl3_link)
         for (int j = tid >> 3; j < ww && !(dbg & 1); j += NT / 8) {
             const size_t idx = (size_t)y * ww + j;
             const u64 w = fb[idx];
@@ -358,32 +386,35 @@ __global__ __launch_bounds__(256) void k_ccl3_bound(const u64* __restrict__ bits
             const u64 ul = j > 0 ? fb[idx - ww - 1] : 0ull;
             const u64 ur = j + 1 < ww ? fb[idx - ww + 1] : 0ull;
             if (!(um | (ul >> 63) | (ur & 1ull))) continue;
-            u64 rem = w;
-            int ord = 0;
-            while (rem) {
-                const int sb = __ffsll((long long)rem) - 1;
-                const int eb = run_end(rem, sb);
-                const u64 Sg = bit_range(sb, eb);
-                rem &= ~Sg;
-                if ((ord++ & 7) != (tid & 7)) continue;
+            const int sh = 8 * (tid & 7);
+            const u64 up_r = (um >> 1) | (ur << 63), up_l = (um << 1) | (ul >> 63);
+            const u64 V = w & um;
+            u32 vs = (u32)((V & ~(V << 1)) >> sh) & 0xffu;
+            u32 dr = (u32)((w & ~(w >> 1) & up_r & ~um) >> sh) & 0xffu;
+            u32 dl = (u32)((w & ~(w << 1) & up_l & ~um) >> sh) & 0xffu;
+            auto meet = [&](int sb, int xup) {
                 const u32 a = blo + (u32)lo16[c3_rel(G, 0, 64 * j + sb)];
-                auto meet = [&](int xup) {
-                    const u32 bb = bup + (u32)up16[c3_rel(G, P.R - 1, xup) - up0];
-                    // a pair some thread of the block has already united (the big component, over and over) is not united again
-                    const u32 slot = ((a * 2654435761u) ^ (bb * 40503u)) >> 24;
-                    if (pairs[2 * slot] == a && pairs[2 * slot + 1] == bb) return;
-                    pairs[2 * slot] = a; pairs[2 * slot + 1] = bb;                 // (a torn entry only costs a repeated union)
-                    c3_unite(fpar, ffl, fch, a, bb);
-                };
-                u64 c = um & (Sg | (Sg << 1) | (Sg >> 1));
-                while (c) {
-                    const int bt = __ffsll((long long)c) - 1;
-                    const int st = run_start(um, bt), en = run_end(um, bt);
-                    meet(64 * j + st);
-                    c &= ~bit_range(st, en);
-                }
-                if ((Sg & 1ull) && (ul >> 63) && !(um & 1ull)) meet(64 * (j - 1) + run_start(ul, 63));
-                if ((Sg >> 63) && (ur & 1ull) && !(um >> 63)) meet(64 * (j + 1));
+                const u32 bb = bup + (u32)up16[c3_rel(G, P.R - 1, xup) - up0];
+                // a pair some thread of the block has already united (the big component, over and over) is not united again
+                const u32 slot = ((a * 2654435761u) ^ (bb * 40503u)) >> 24;
+                if (pairs[2 * slot] == a && pairs[2 * slot + 1] == bb) return;
+                pairs[2 * slot] = a; pairs[2 * slot + 1] = bb;                 // (a torn entry only costs a repeated union)
+                c3_unite(fpar, ffl, fch, a, bb);
+            };
+            while (vs) {
+                const int x = __ffs((int)vs) - 1 + sh;
+                vs &= vs - 1;
+                meet(c3_run_start(w, x), 64 * j + c3_run_start(um, x));
+            }
+            while (dr) {
+                const int x = __ffs((int)dr) - 1 + sh;
+                dr &= dr - 1;
+                meet(c3_run_start(w, x), 64 * j + x + 1);
+            }
+            while (dl) {
+                const int x = __ffs((int)dl) - 1 + sh;
+                dl &= dl - 1;
+                meet(x, x > 0 ? 64 * j + c3_run_start(um, x - 1) : 64 * (j - 1) + c3_run_start(ul, 63));
             }
         }
         __syncthreads();

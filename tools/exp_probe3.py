@@ -27,7 +27,7 @@ ctx.chain_run(desc, b, B)
 pr = ctx.profile_end()
 L.vp_debug_probe3(out.ctypes.data)
 print({k: round(1e3 * v[0] / v[1], 1) for k, v in pr.items()})
-names = [["bits staged", "parents set", "unions", "flatten + roots", "dump issued", "acc cleared"],
+names = [["bits staged", "parents set", "contacts", "flatten + roots", "dump issued", "acc cleared"],
          ["", "", "", "", "", "", "boundary rows staged", "boundary unions"],
          ["bases + staged", "local roots ranked", "root labels", "accumulate", "emit rows / table", "table flushed", "label stores", "totals"]]
 for k, nm in enumerate(names):
