@@ -123,6 +123,22 @@ __device__ __forceinline__ int c3_run_start(u64 w, int x)
     return z ? 32 - __clz(z) : 0;
 }
 
+// last bit of the run of 1s of `w` that starts at bit sb, on 32-bit halves
+__device__ __forceinline__ int c3_run_end(u64 w, int sb)
+{
+    const u32 lo = (u32)w, hi = (u32)(w >> 32);
+    if (sb < 32) {
+        const u32 z = ~(lo >> sb);                      // bit 0 is clear; the zeros shifted in at the top end the count at 32 - sb
+        const int n = z ? __ffs((int)z) - 1 : 32;       // 32 - sb: the run reaches the upper half
+        if (n < 32 - sb) return sb + n - 1;
+        const u32 zh = ~hi;
+        return zh ? 32 + (__ffs((int)zh) - 1) - 1 : 63;
+    }
+    const u32 z = ~(hi >> (sb - 32));
+    const int n = z ? __ffs((int)z) - 1 : 32;
+    return (n < 64 - sb) ? sb + n - 1 : 63;
+}
+
 // adds a partial component to the strip's table (LDS), keyed by label; a full table sends it straight to the frame's accumulators
 __device__ __forceinline__ void c3_table_add(u32* t_label, contrib* t_rec, u32 label, const contrib& c, ccl_acc* facc)
 {
@@ -579,35 +595,49 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
                 u32 rk = off + inc - c;
                 lrp[tid] = rk;
                 u32 m = lrb[tid];
-                while (m) {                                   // labels of the local roots, while their ids are at hand
+                while (m) {                                   // ids of the local roots by rank
                     const int b = __ffs((int)m) - 1;
                     m &= m - 1;
-                    const u32 id = ((u32)tid << 5) + (u32)b;
-                    const u32 bit = 1u << b;
-                    rid[rk] = (unsigned short)id;
-                    u32 label;
-                    if (gfl[tid] & bit) {                     // still a root of the frame: its rank, from the strip's own slice
-                        label = sbase[s] + gpf[tid] + (u32)__popc(gfl[tid] & (bit - 1u)) + 1u;
-                    } else {                                  // absorbed: the ranking launch left the frame's root in its parent entry
-                        u32 g = base + id;
-                        for (u32 q = fpar[g]; q != g; q = fpar[g]) g = q;
-                        label = sbase[g / P.ids] + fpf[g >> 5] + (u32)__popc(ffl[g >> 5] & ((1u << (g & 31)) - 1u)) + 1u;
-                    }
-                    lab[rk] = label;
-                    rk++;
+                    rid[rk++] = (unsigned short)(((u32)tid << 5) + (u32)b);
                 }
             }
         }
         __syncthreads();
+        // labels of the local roots, one rank per thread and turn so that the look-ups of absorbed roots (two dependent reads of global
+        // memory each) are in flight together instead of queueing in the few threads whose bitmap words hold them
+        for (u32 r0 = tid; r0 < nroots; r0 += 4 * NT) {
+            u32 idv[4], gv[4];
+            bool own[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 rk = r0 + (u32)q * NT;
+                idv[q] = rk < nroots ? (u32)rid[rk] : 0u;
+                own[q] = (gfl[idv[q] >> 5] >> (idv[q] & 31)) & 1u;        // still a root of the frame: its rank comes from the strip's own slice
+                gv[q] = (rk < nroots && !own[q]) ? fpar[base + idv[q]] : 0u;   // absorbed: the ranking launch left the frame's root in its parent entry
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 rk = r0 + (u32)q * NT;
+                if (rk >= nroots) continue;
+                const u32 id = idv[q], g = gv[q];
+                u32 label;
+                if (own[q]) label = sbase[s] + gpf[id >> 5] + (u32)__popc(gfl[id >> 5] & ((1u << (id & 31)) - 1u)) + 1u;
+                else label = sbase[g / P.ids] + fpf[g >> 5] + (u32)__popc(ffl[g >> 5] & ((1u << (g & 31)) - 1u)) + 1u;
+                lab[rk] = label;
+            }
+        }
+        __syncthreads();
         C3_PROBE(1);   // local roots ranked and labelled
-        // every segment's entry: the id of its root -> the local rank of its root
-        C3_FOR_WORDS(r, j, i, NT) {
-            u64 st = lbits[i] & ~(lbits[i] << 1);
+        // every segment's entry: the id of its root -> the local rank of its root (a thread per half-word, as in k_ccl3_link)
+        for (int i2 = tid; i2 < nrows * ww * 2; i2 += NT) {
+            const int i = i2 >> 1, half = i2 & 1, r = i / ww, j = i - r * ww;
+            const u64 w = lbits[i];
+            u32 st = (u32)((w & ~(w << 1)) >> (32 * half));
             u32 ids_[4], rk_[4];                              // (reads first, writes after: a root's own entry is somebody's read)
             while (st) {
                 int cnt = 0;
                 while (st && cnt < 4) {
-                    const int sb = __ffsll((long long)st) - 1;
+                    const int sb = __ffs((int)st) - 1 + 32 * half;
                     st &= st - 1;
                     const u32 id = c3_rel(G, r, 64 * j + sb);
                     const u32 root = lr16[id];
@@ -629,18 +659,20 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
             // Every segment adds to its component's accumulators.  A wave's lanes mostly name the same component when one is large (half
             // the pixels of 50 % noise belong to one): 64 LDS atomics on one word take 64 turns, so the lanes that agree with the first
             // active lane are combined with shuffles first and added once.
-            for (int i0 = 0; i0 < nrows * ww; i0 += NT) {
-                const int i = i0 + tid;
-                const bool valid = i < nrows * ww;
+            for (int i0 = 0; i0 < nrows * ww * 2; i0 += NT) {
+                const int i2 = i0 + tid;
+                const bool valid = i2 < nrows * ww * 2;
+                const int i = i2 >> 1, half = i2 & 1;
                 const int r = valid ? i / ww : 0, j = valid ? i - r * ww : 0;
-                u64 rem = valid ? lbits[i] : 0ull;
-                while (__any(rem != 0ull)) {
-                    bool act = rem != 0ull;
+                const u64 w = valid ? lbits[i] : 0ull;
+                u32 rem = (u32)((w & ~(w << 1)) >> (32 * half));      // the segments that START in this thread's half of the word
+                while (__any(rem != 0u)) {
+                    bool act = rem != 0u;
                     u32 k = 0xffffffffu, len = 0, sxv = 0, syv = 0, xs = 0xffffffffu, xe = 0, rowbit = 0;
                     if (act) {
-                        const int sb = __ffsll((long long)rem) - 1;
-                        const int eb = run_end(rem, sb);
-                        rem &= ~bit_range(sb, eb);
+                        const int sb = __ffs((int)rem) - 1 + 32 * half;
+                        rem &= rem - 1;
+                        const int eb = c3_run_end(w, sb);
                         k = (u32)lr16[c3_rel(G, r, 64 * j + sb)] - c0;
                         act = k < (u32)C3_ACC;
                         len = (u32)(eb - sb + 1);
