@@ -386,8 +386,15 @@ __global__ __launch_bounds__(256) void k_ccl3_bound(const u64* __restrict__ bits
         u32* s_lo = stage;
         u32* s_up16 = stage + nlo;
         __syncthreads();
-        for (u32 k = tid; k < nlo; k += NT) s_lo[k] = f16[blo / 2 + k];
-        for (u32 k = tid; k < nup; k += NT) s_up16[k] = f16[(bup + up0 - upoff) / 2 + k];
+        {   // (all loads of a thread first: a load-then-store loop waits for each in turn)
+            u32 vl[4], vu[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const u32 k = tid + (u32)q * NT; vl[q] = k < nlo ? f16[blo / 2 + k] : 0u; vu[q] = k < nup ? f16[(bup + up0 - upoff) / 2 + k] : 0u; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const u32 k = tid + (u32)q * NT; if (k < nlo) s_lo[k] = vl[q]; if (k < nup) s_up16[k] = vu[q]; }
+            for (u32 k = tid + 4u * NT; k < nlo; k += NT) s_lo[k] = f16[blo / 2 + k];
+            for (u32 k = tid + 4u * NT; k < nup; k += NT) s_up16[k] = f16[(bup + up0 - upoff) / 2 + k];
+        }
         for (u32 k = tid; k < 512; k += NT) pairs[k] = 0xffffffffu;
         __syncthreads();
         C3_PROBE(6);   // boundary rows staged
