@@ -80,11 +80,18 @@ __device__ __forceinline__ u32 c3_rel(const ccl_geom& G, int r, int x)
 // the absorbing one is marked as having members outside its own strip-local component
 __device__ __forceinline__ void c3_unite(u32* p, u32* flags, u32* child, u32 a, u32 b)
 {
+    // both walks advance together: every step is a round trip to the memory side (agent-scope loads pass the L2 of this die), and the
+    // two chains do not depend on each other
+    u32 qa = ld_rlx(p + a), qb = ld_rlx(p + b);
     for (;;) {
-        a = uf_find_halve(p, a);
-        b = uf_find_halve(p, b);
+        while (qa != a || qb != b) {                          // a step: the grandparents of both, the entry left behind now skips one
+            const bool ma = qa != a, mb = qb != b;
+            const u32 ga = ma ? ld_rlx(p + qa) : qa, gb = mb ? ld_rlx(p + qb) : qb;
+            if (ma) { if (ga != qa) st_rlx(p + a, ga); a = qa; qa = ga; }
+            if (mb) { if (gb != qb) st_rlx(p + b, gb); b = qb; qb = gb; }
+        }
         if (a == b) return;
-        if (a < b) { const u32 t = a; a = b; b = t; }
+        if (a < b) { const u32 t = a; a = b; b = t; const u32 tq = qa; qa = qb; qb = tq; }
         const u32 old = atomicCAS(p + a, a, b);
         if (old == a) {
             atomicAnd(flags + (a >> 5), ~(1u << (a & 31)));
@@ -93,7 +100,8 @@ __device__ __forceinline__ void c3_unite(u32* p, u32* flags, u32* child, u32 a, 
             if (!(ld_rlx(child + (b >> 5)) & (1u << (b & 31)))) atomicOr(child + (b >> 5), 1u << (b & 31));
             return;
         }
-        a = old;
+        qa = old;                                             // somebody linked `a` first: go on from where it points now
+        qb = ld_rlx(p + b);
     }
 }
 
