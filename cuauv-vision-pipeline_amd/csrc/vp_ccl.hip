@@ -72,7 +72,7 @@ size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
            vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) +
            vp_align(ns * 4) + vp_align(ns * C2_RC * sizeof(contrib)) + vp_align(ns * sizeof(c2_box)) + vp_align(ns * C2_RC * 4) +
            vp_align((size_t)n * 4) + 2 * vp_align(nids / 8 * n) + vp_align((size_t)n * 4) + 256 + vp_align((size_t)n * C3_STATE_BYTES) +
-           vp_align((size_t)n * c3_strips_cap(h) * 12) + 4096;
+           vp_align((size_t)n * c3_strips_cap(h) * 12) + vp_align((size_t)n * c3_strips_cap(h) * 40) + 4096;
 }
 
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out)
@@ -96,13 +96,14 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->c3_clist = (u32*)vp_ws_take(ctx, (size_t)n * 4);
     out->c3_ncrowded = (u32*)vp_ws_take(ctx, 4);
     out->c3_state = vp_ws_take(ctx, (size_t)n * C3_STATE_BYTES);
+    out->c3_tot = vp_ws_take(ctx, (size_t)n * c3_strips_cap(h) * 40);              // sizeof(contrib)
     out->c3_barr = (u32*)vp_ws_take(ctx, (size_t)n * c3_strips_cap(h) * 12);   // per frame: boundary arrivals | boundaries done per strip | roots per strip
 }
 
 bool vp_ccl_ws_ok(const vp_ccl_ws& ws)
 {
     return ws.parent && ws.seglabel && ws.flags && ws.prefix && ws.acc && ws.wordlabel && ws.bgpart && ws.c2_ncomp && ws.c2_recs &&
-           ws.c2_bgbox && ws.c2_label && ws.c2_crowded && ws.c3_child && ws.c3_lroot && ws.c3_clist && ws.c3_ncrowded && ws.c3_state && ws.c3_barr;
+           ws.c2_bgbox && ws.c2_label && ws.c2_crowded && ws.c3_child && ws.c3_lroot && ws.c3_clist && ws.c3_ncrowded && ws.c3_state && ws.c3_barr && ws.c3_tot;
 }
 
 // ---- whole-image global-memory path (fallback for images too wide for the LDS strip kernel) ---------------
@@ -749,15 +750,15 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
             if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
               static const int agrid = getenv("VP_C3_AGRID") ? atoi(getenv("VP_C3_AGRID")) : 2;
               if (c3_tall) hipLaunchKernelGGL(k_ccl3_label<2 * C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(2 * C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
+                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
                                  d_centroids, c3_dbg);
               else hipLaunchKernelGGL(k_ccl3_label<C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
+                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
                                  d_centroids, c3_dbg); }
             if (d_stats || d_centroids) {
                 vp_prof_scope ps(ctx, VPK_CCL_FINAL);
                 hipLaunchKernelGGL(k_ccl3_rows, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.c3_child, ws.prefix,
-                                   ws.c3_barr, (const c3_state*)ws.c3_state, (const ccl_acc*)ws.acc, max_labels, d_stats, d_centroids);
+                                   ws.c3_barr, (const c3_state*)ws.c3_state, (const contrib*)ws.c3_tot, (int)c3_strips_cap(h), (const ccl_acc*)ws.acc, max_labels, d_stats, d_centroids);
             }
             VP_HIP(ctx, hipGetLastError());
         } else if (!P3.ok) {

@@ -501,7 +501,8 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
                                                                  const u32* __restrict__ flags, const u32* __restrict__ child,
                                                                  const u32* __restrict__ prefix, const u32* __restrict__ lrootbits,
                                                                  const u32* __restrict__ root16, const u32* __restrict__ barr,
-                                                                 c3_state* __restrict__ state, int32_t* __restrict__ nlabels,
+                                                                 c3_state* __restrict__ state, contrib* __restrict__ tot, int tot_stride,
+                                                                 int32_t* __restrict__ nlabels,
                                                                  ccl_acc* __restrict__ acc, int max_labels, int32_t* __restrict__ labels,
                                                                  int32_t* __restrict__ stats, double* __restrict__ cent, int dbg)
 {
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
     __shared__ u32 sbase[C3_MAX_STRIPS + 2];                   // roots in the strips before each strip
     __shared__ u32 t_label[C3_TAB];                            // labels of the components this strip only holds a part of ...
     __shared__ contrib t_rec[C3_TAB];                          // ... and what the strip adds to them
+    __shared__ contrib wtot[AT / 64];                          // the waves' shares of the strip's totals
     const int NT = AT;
     const int ww = G.ww, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwmax = P.R * ww;
@@ -552,20 +554,40 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
         const u32 base = (u32)s * P.ids;
         const u32 lim = min(P.ids, G.nids - base);
         __syncthreads();                                      // the previous item's LDS is done with
+        C3_PROBE(9);   // item set up, waited for the block
         // ---- everything the strip needs from global memory, requested together --------------------------------------------------------
         u32 sc[(C3_MAX_STRIPS + AT - 1) / AT];
 #pragma unroll
         for (int q = 0; q < (C3_MAX_STRIPS + AT - 1) / AT; q++) sc[q] = (q * NT + tid < P.strips) ? scount[q * NT + tid] : 0u;
-        C3_FOR_WORDS(r, j, i, NT) lbits[i] = fb[(size_t)(y0 + r) * ww + j];
-        for (u32 k = tid; k < lim / 2; k += NT) reinterpret_cast<u32*>(lr16)[k] = f16[base / 2 + k];
-        for (u32 k = tid; k < nsl; k += NT) {
-            const bool in = k < lim / 32;
-            gfl[k] = in ? ffl[base / 32 + k] : 0u;
-            gpf[k] = in ? fpf[base / 32 + k] : 0u;
-            gch[k] = in ? fch[base / 32 + k] : 0u;
-            lrb[k] = in ? flr[base / 32 + k] : 0u;
+        {   // every load of a thread is out before its first result is stored (loops of load-then-store pairs wait for each load in
+            // turn: 6 us per strip): its word of the strip, two 16-byte pieces of the u16 roots, its word of the four bitmaps
+            const int wr = tid / ww, wj = tid - wr * ww;
+            const bool hw = tid < nrows * ww;
+            const u64 v_bits = hw ? fb[(size_t)(y0 + wr) * ww + wj] : 0ull;
+            const uint4* src = reinterpret_cast<const uint4*>(f16 + base / 2);     // base / 2 and lim / 2 are multiples of 16 words
+            const u32 n4 = lim / 8;
+            uint4 v16[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) { const u32 k = tid + (u32)q * NT; if (k < n4) v16[q] = src[k]; }
+            const bool in = (u32)tid < lim / 32;
+            const u32 v_fl = in ? ffl[base / 32 + tid] : 0u, v_pf = in ? fpf[base / 32 + tid] : 0u, v_ch = in ? fch[base / 32 + tid] : 0u,
+                      v_lr = in ? flr[base / 32 + tid] : 0u;
+            if (hw) lbits[tid] = v_bits;
+            uint4* dst = reinterpret_cast<uint4*>(lr16);
+#pragma unroll
+            for (int q = 0; q < 2; q++) { const u32 k = tid + (u32)q * NT; if (k < n4) dst[k] = v16[q]; }
+            if ((u32)tid < nsl) { gfl[tid] = v_fl; gpf[tid] = v_pf; gch[tid] = v_ch; lrb[tid] = v_lr; }
+            // (not reached for any plan: a strip has at most NT / 2 words, 2 * NT pieces of roots and NT bitmap words)
+            for (int i = tid + NT; i < nrows * ww; i += NT) lbits[i] = fb[(size_t)(y0 + i / ww) * ww + i % ww];
+            for (u32 k = tid + 2u * NT; k < n4; k += NT) dst[k] = src[k];
+            for (u32 k = tid + NT; k < nsl; k += NT) {
+                const bool in2 = k < lim / 32;
+                gfl[k] = in2 ? ffl[base / 32 + k] : 0u; gpf[k] = in2 ? fpf[base / 32 + k] : 0u;
+                gch[k] = in2 ? fch[base / 32 + k] : 0u; lrb[k] = in2 ? flr[base / 32 + k] : 0u;
+            }
         }
         for (int k = tid; k < C3_TAB; k += NT) { t_label[k] = 0u; contrib_zero(t_rec[k]); }
+        C3_PROBE(8);   // this thread's loads have landed in LDS
         // roots in the strips before each strip: exclusive scan of the per-strip counts (the same in every block of the frame)
         {
             u32 run = 0;
@@ -815,7 +837,7 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
             }
         }
         C3_PROBE(6);   // label stores issued
-        // ---- totals of the strip for the frame's background row: foreground sums, bounding box of the zero pixels; one set of atomics per wave
+        // ---- totals of the strip for the frame's background row: foreground sums, bounding box of the zero pixels
         C3_FOR_WORDS(r, j, i, NT) {
             const u64 z = ~lbits[i] & (j == ww - 1 ? lastmask : ~0ull);
             if (!z) continue;
@@ -824,18 +846,18 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
             tot_c.miny = min(tot_c.miny, y0 + r);
             tot_c.maxy = max(tot_c.maxy, y0 + r);
         }
+        // (a record per strip, summed by k_ccl3_rows: atomics on the frame's one set of totals queue up at the memory side - every wave
+        // of every strip of the frame - and, retiring in order with everything else a wave sends there, they held back the next
+        // strip's loads)
         wave_combine(tot_c);
-        if (lane == 0) {
-            c3_state* st = state + f;
-            if (tot_c.area) {
-                atomicAdd(&st->fg_area, tot_c.area);
-                atomicAdd((unsigned long long*)&st->fg_sx, (unsigned long long)tot_c.sx);
-                atomicAdd((unsigned long long*)&st->fg_sy, (unsigned long long)tot_c.sy);
-            }
-            if (tot_c.minx != INT_MAX) {
-                atomicMin(&st->bg_minx, tot_c.minx); atomicMax(&st->bg_maxx, tot_c.maxx);
-                atomicMin(&st->bg_miny, tot_c.miny); atomicMax(&st->bg_maxy, tot_c.maxy);
-            }
+        if (lane == 0) wtot[wv] = tot_c;
+        __syncthreads();
+        if (wv == 0) {
+            contrib c;
+            contrib_zero(c);
+            if (lane < AT / 64) c = wtot[lane];
+            wave_combine(c);
+            if (lane == 0) tot[(size_t)f * tot_stride + s] = c;
         }
         C3_PROBE(7);   // totals
     }
@@ -847,8 +869,9 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
 // accumulators by now (the labelling launch is complete)
 __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded, const u32* __restrict__ clist,
                                                    const u32* __restrict__ flags, const u32* __restrict__ child, const u32* __restrict__ prefix,
-                                                   const u32* __restrict__ barr, const c3_state* __restrict__ state, const ccl_acc* __restrict__ acc,
-                                                   int max_labels, int32_t* __restrict__ stats, double* __restrict__ cent)
+                                                   const u32* __restrict__ barr, const c3_state* __restrict__ state, const contrib* __restrict__ tot,
+                                                   int tot_stride, const ccl_acc* __restrict__ acc, int max_labels, int32_t* __restrict__ stats,
+                                                   double* __restrict__ cent)
 {
     const u32 nc = *ncrowded;
     if (nc == 0 || (!stats && !cent)) return;
@@ -899,22 +922,33 @@ __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const 
                 if (cent) { cent[o * 2] = 0.0; cent[o * 2 + 1] = 0.0; }
             }
         }
-        if (s == 0 && tid == 0) {                             // the background row: the frame's totals minus the foreground's
-            const u64 W = (u64)G.w, H = (u64)G.h;
-            const u32 area = (u32)(W * H) - st.fg_area;
-            const u64 sx = H * (W * (W - 1ull) / 2ull) - st.fg_sx;
-            const u64 sy = W * (H * (H - 1ull) / 2ull) - st.fg_sy;
-            const size_t o = (size_t)f * max_labels;
-            if (stats) {
-                int32_t* sp = stats + o * 5;
-                sp[0] = st.bg_minx; sp[1] = st.bg_miny;
-                sp[2] = (int32_t)((u32)st.bg_maxx - (u32)st.bg_minx + 1u);
-                sp[3] = (int32_t)((u32)st.bg_maxy - (u32)st.bg_miny + 1u);
-                sp[4] = (int32_t)area;
-            }
-            if (cent) {
-                cent[o * 2] = (double)sx / (double)area;
-                cent[o * 2 + 1] = (double)sy / (double)area;
+        if (s == 0) {                                         // the background row: the frame's totals minus the foreground's (block-uniform)
+            __shared__ contrib wsum[256 / 64];
+            contrib c;
+            contrib_zero(c);
+            for (int k = tid; k < P.strips; k += NT) contrib_merge(c, tot[(size_t)f * tot_stride + k]);
+            wave_combine(c);
+            __syncthreads();
+            if ((tid & 63) == 0) wsum[tid >> 6] = c;
+            __syncthreads();
+            if (tid == 0) {
+                for (int k = 1; k < 256 / 64; k++) contrib_merge(c, wsum[k]);
+                const u64 W = (u64)G.w, H = (u64)G.h;
+                const u32 area = (u32)(W * H) - c.area;
+                const u64 sx = H * (W * (W - 1ull) / 2ull) - c.sx;
+                const u64 sy = W * (H * (H - 1ull) / 2ull) - c.sy;
+                const size_t o = (size_t)f * max_labels;
+                if (stats) {
+                    int32_t* sp = stats + o * 5;
+                    sp[0] = c.minx; sp[1] = c.miny;
+                    sp[2] = (int32_t)((u32)c.maxx - (u32)c.minx + 1u);
+                    sp[3] = (int32_t)((u32)c.maxy - (u32)c.miny + 1u);
+                    sp[4] = (int32_t)area;
+                }
+                if (cent) {
+                    cent[o * 2] = (double)sx / (double)area;
+                    cent[o * 2 + 1] = (double)sy / (double)area;
+                }
             }
         }
     }

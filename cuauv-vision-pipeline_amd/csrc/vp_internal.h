@@ -168,6 +168,7 @@ struct vp_ccl_ws {           // per-batch scratch, all device pointers
     u32* c3_ncrowded;        // [1]                    their number
     void* c3_state;          // [n]                    per-frame counters and totals
     u32* c3_barr;            // [n][strips + 1]        arrivals at every strip boundary
+    void* c3_tot;            // [n][strips]            per strip: foreground sums and the box of its zero pixels (for the background row)
 };
 bool vp_ccl_ws_ok(const vp_ccl_ws& ws);
 size_t vp_ccl_nids(int w, int h);   // multiple of 32

@@ -29,7 +29,7 @@ L.vp_debug_probe3(out.ctypes.data)
 print({k: round(1e3 * v[0] / v[1], 1) for k, v in pr.items()})
 names = [["bits staged", "parents set", "contacts", "flatten + roots", "dump issued", "acc cleared"],
          ["", "", "", "", "", "", "boundary rows staged", "boundary unions"],
-         ["bases + staged", "local roots ranked", "root labels", "accumulate", "emit rows / table", "table flushed", "label stores", "totals"]]
+         ["bases + staged", "local roots ranked", "root labels", "accumulate", "emit rows / table", "table flushed", "label stores", "totals", "staging: loads to LDS", "item set-up + wait for the block"]]
 for k, nm in enumerate(names):
     blocks = max(out[16 * k + 15], 1)
     tot = out[16 * k:16 * k + 15].sum()
