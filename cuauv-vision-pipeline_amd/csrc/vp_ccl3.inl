@@ -147,6 +147,52 @@ __device__ __forceinline__ int c3_run_end(u64 w, int sb)
     return (n < 64 - sb) ? sb + n - 1 : 63;
 }
 
+// Wave-wide reductions to a wave-uniform value without the LDS crossbar: four DPP steps make every row of 16 lanes uniform (quad
+// swaps, then the mirrored half-row and row - any lane of the other half serves once the halves are uniform), four lane reads
+// combine the rows.  (__shfl_xor is a ds_bpermute: 36 of them per turn of the statistics loop kept the LDS pipe busier than the
+// atomics they save.)  Every lane of the wave must be active.
+template <int CTRL>
+__device__ __forceinline__ u32 c3_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+#define C3_WAVE_REDUCE(name, OP)                                                                                   \
+    __device__ __forceinline__ u32 name(u32 v)                                                                     \
+    {                                                                                                              \
+        v = OP(v, c3_dpp<0xB1>(v)); v = OP(v, c3_dpp<0x4E>(v)); v = OP(v, c3_dpp<0x141>(v)); v = OP(v, c3_dpp<0x140>(v)); \
+        const u32 r0 = (u32)__builtin_amdgcn_readlane((int)v, 0), r1 = (u32)__builtin_amdgcn_readlane((int)v, 16),  \
+                  r2 = (u32)__builtin_amdgcn_readlane((int)v, 32), r3 = (u32)__builtin_amdgcn_readlane((int)v, 48); \
+        return OP(OP(r0, r1), OP(r2, r3));                                                                         \
+    }
+#define C3_OP_ADD(a, b) ((a) + (b))
+#define C3_OP_MIN(a, b) min((a), (b))
+#define C3_OP_MAX(a, b) max((a), (b))
+#define C3_OP_OR(a, b) ((a) | (b))
+C3_WAVE_REDUCE(c3_wave_add, C3_OP_ADD)
+C3_WAVE_REDUCE(c3_wave_min, C3_OP_MIN)
+C3_WAVE_REDUCE(c3_wave_max, C3_OP_MAX)
+C3_WAVE_REDUCE(c3_wave_or, C3_OP_OR)
+
+template <int CTRL>
+__device__ __forceinline__ u64 c3_dpp64(u64 v) { return ((u64)c3_dpp<CTRL>((u32)(v >> 32)) << 32) | (u64)c3_dpp<CTRL>((u32)v); }
+__device__ __forceinline__ u64 c3_wave_add64(u64 v)
+{
+    v += c3_dpp64<0xB1>(v); v += c3_dpp64<0x4E>(v); v += c3_dpp64<0x141>(v); v += c3_dpp64<0x140>(v);
+    u64 r = 0;
+#pragma unroll
+    for (int q = 0; q < 64; q += 16)
+        r += ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), q) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)v, q);
+    return r;
+}
+// every lane gets the wave's combined record (all lanes active)
+__device__ __forceinline__ void c3_wave_combine(contrib& c)
+{
+    c.area = c3_wave_add(c.area);
+    c.sx = c3_wave_add64(c.sx);
+    c.sy = c3_wave_add64(c.sy);
+    c.minx = (int)(c3_wave_min((u32)c.minx ^ 0x80000000u) ^ 0x80000000u);      // signed order through the unsigned reductions
+    c.maxx = (int)(c3_wave_max((u32)c.maxx ^ 0x80000000u) ^ 0x80000000u);
+    c.miny = (int)(c3_wave_min((u32)c.miny ^ 0x80000000u) ^ 0x80000000u);
+    c.maxy = (int)(c3_wave_max((u32)c.maxy ^ 0x80000000u) ^ 0x80000000u);
+}
+
 // adds a partial component to the strip's table (LDS), keyed by label; a full table sends it straight to the frame's accumulators
 __device__ __forceinline__ void c3_table_add(u32* t_label, contrib* t_rec, u32 label, const contrib& c, ccl_acc* facc)
 {
@@ -722,13 +768,8 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
                     const u32 kd = __shfl(k, lead);
                     const bool same = act && k == kd;
                     if (__popcll(__ballot(same)) >= 8) {
-                        u32 t_len = same ? len : 0u, t_sx = same ? sxv : 0u, t_sy = same ? syv : 0u, t_xs = same ? xs : 0xffffffffu,
-                            t_xe = same ? xe : 0u, t_rb = same ? rowbit : 0u;
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            t_len += __shfl_xor(t_len, d); t_sx += __shfl_xor(t_sx, d); t_sy += __shfl_xor(t_sy, d);
-                            t_xs = min(t_xs, (u32)__shfl_xor(t_xs, d)); t_xe = max(t_xe, (u32)__shfl_xor(t_xe, d)); t_rb |= __shfl_xor(t_rb, d);
-                        }
+                        const u32 t_len = c3_wave_add(same ? len : 0u), t_sx = c3_wave_add(same ? sxv : 0u), t_sy = c3_wave_add(same ? syv : 0u),
+                                  t_xs = c3_wave_min(same ? xs : 0xffffffffu), t_xe = c3_wave_max(same ? xe : 0u), t_rb = c3_wave_or(same ? rowbit : 0u);
                         if (lane == lead) {
                             atomicAdd(a_area + kd, t_len); atomicAdd(a_sx + kd, t_sx); atomicAdd(a_sy + kd, t_sy);
                             atomicMin(a_minx + kd, t_xs); atomicMax(a_maxx + kd, t_xe); atomicOr(a_rows + kd, t_rb);
@@ -790,7 +831,7 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
                     if (__popcll(sm) >= 4) {
                         contrib g = c;
                         if (!same) contrib_zero(g);
-                        wave_combine(g);
+                        c3_wave_combine(g);
                         if (lane == lead) c3_table_add(t_label, t_rec, ld, g, facc);
                     } else if (same) {
                         c3_table_add(t_label, t_rec, label, c, facc);
@@ -849,14 +890,14 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
         // (a record per strip, summed by k_ccl3_rows: atomics on the frame's one set of totals queue up at the memory side - every wave
         // of every strip of the frame - and, retiring in order with everything else a wave sends there, they held back the next
         // strip's loads)
-        wave_combine(tot_c);
+        c3_wave_combine(tot_c);
         if (lane == 0) wtot[wv] = tot_c;
         __syncthreads();
         if (wv == 0) {
             contrib c;
             contrib_zero(c);
             if (lane < AT / 64) c = wtot[lane];
-            wave_combine(c);
+            c3_wave_combine(c);
             if (lane == 0) tot[(size_t)f * tot_stride + s] = c;
         }
         C3_PROBE(7);   // totals
