@@ -137,13 +137,10 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
                 bb.miny = bb.maxy = y0 + lane;
             }
         }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            bb.minx = min(bb.minx, __shfl_xor(bb.minx, d));
-            bb.maxx = max(bb.maxx, __shfl_xor(bb.maxx, d));
-            bb.miny = min(bb.miny, __shfl_xor(bb.miny, d));
-            bb.maxy = max(bb.maxy, __shfl_xor(bb.maxy, d));
-        }
+        bb.minx = (int)(c3_wave_min((u32)bb.minx ^ 0x80000000u) ^ 0x80000000u);   // (DPP steps + lane reads, vp_ccl3.inl: no LDS crossbar)
+        bb.maxx = (int)(c3_wave_max((u32)bb.maxx ^ 0x80000000u) ^ 0x80000000u);
+        bb.miny = (int)(c3_wave_min((u32)bb.miny ^ 0x80000000u) ^ 0x80000000u);
+        bb.maxy = (int)(c3_wave_max((u32)bb.maxy ^ 0x80000000u) ^ 0x80000000u);
         if (lane == 0) bgbox[sidx] = bb;
     }
     __syncthreads();
@@ -380,9 +377,8 @@ __global__ __launch_bounds__(256) void k_ccl2_local(const u64* __restrict__ bits
                 const int lead = __ffsll((long long)act) - 1;
                 const u32 ref = __shfl(k0, lead);
                 if (__popcll(act) >= 8 && __all(k0 == NONE || k0 == ref)) {
-                    wave_combine(c0);
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) c0.pad = min(c0.pad, (u32)__shfl_xor(c0.pad, d));
+                    c3_wave_combine(c0);
+                    c0.pad = c3_wave_min(c0.pad);
                     if (lane == lead) acc_add(ref, c0);
                 } else if (k0 != NONE) {
                     acc_add(k0, c0);
