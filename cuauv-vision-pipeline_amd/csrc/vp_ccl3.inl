@@ -27,7 +27,7 @@
 #define C3_IDS 16384           // most segment ids per strip = entries of the LDS union-find (1080p: 16 rows = 15,360; VP_C3_IDS=8192: 8 rows)
 #define C3_LINK_THREADS 512    // k_ccl3_link, strips of up to 8192 ids; twice that for taller ones: a thread per 32-bit HALF of a word
 #define C3_LABEL_THREADS 512   // k_ccl3_label, likewise
-#define C3_ACC 1024            // local components whose statistics are accumulated per pass over the strip
+#define C3_ACC 2304            // local components whose statistics are accumulated per pass over the strip (the labelling launch has a CU's LDS to itself either way: one pass for raw noise at 10 % and 50 %)
 #define C3_TAB 128             // entries of a strip's table of partial components (beyond it: straight to global memory)
 #define C3_MAX_STRIPS 512      // per-strip root counts of a frame are scanned in LDS by every block of the later launches
 
