@@ -573,10 +573,10 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
     u32* gfl = lrp + nsl;
     u32* gpf = gfl + nsl;
     u32* gch = gpf + nsl;
-    u32* a_area = gch + nsl;
-    u32* a_sx = a_area + C3_ACC;
-    u32* a_sy = a_sx + C3_ACC;
-    u32* a_minx = a_sy + C3_ACC;
+    // area | sum of y | sum of x of a local component in ONE 64-bit word (16 | 20 | 28 bits: a strip holds at most 32,768 pixels in at
+    // most 32 rows of at most 4,096 columns - c3_make_plan), so that a segment costs one LDS add for the three
+    unsigned long long* a_pack = reinterpret_cast<unsigned long long*>(gch + nsl + (nsl & 1u));   // (five bitmaps of nsl words before it: an odd nsl leaves a gap of one word)
+    u32* a_minx = reinterpret_cast<u32*>(a_pack + C3_ACC);
     u32* a_maxx = a_minx + C3_ACC;
     u32* a_rows = a_maxx + C3_ACC;
     const u64 lastmask = (G.w & 63) ? ((1ull << (G.w & 63)) - 1ull) : ~0ull;
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
         contrib tot_c;
         contrib_zero(tot_c);
         for (u32 c0 = 0; c0 < nroots && !(dbg & 8); c0 += C3_ACC) {
-            for (u32 k = tid; k < C3_ACC; k += NT) { a_area[k] = 0; a_sx[k] = 0; a_sy[k] = 0; a_minx[k] = 0xffffffffu; a_maxx[k] = 0; a_rows[k] = 0; }
+            for (u32 k = tid; k < C3_ACC; k += NT) { a_pack[k] = 0ull; a_minx[k] = 0xffffffffu; a_maxx[k] = 0; a_rows[k] = 0; }
             __syncthreads();
             // Every segment adds to its component's accumulators.  A wave's lanes mostly name the same component when one is large (half
             // the pixels of 50 % noise belong to one): 64 LDS atomics on one word take 64 turns, so the lanes that agree with the first
@@ -771,13 +771,13 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
                         const u32 t_len = c3_wave_add(same ? len : 0u), t_sx = c3_wave_add(same ? sxv : 0u), t_sy = c3_wave_add(same ? syv : 0u),
                                   t_xs = c3_wave_min(same ? xs : 0xffffffffu), t_xe = c3_wave_max(same ? xe : 0u), t_rb = c3_wave_or(same ? rowbit : 0u);
                         if (lane == lead) {
-                            atomicAdd(a_area + kd, t_len); atomicAdd(a_sx + kd, t_sx); atomicAdd(a_sy + kd, t_sy);
+                            atomicAdd(a_pack + kd, ((unsigned long long)t_len << 48) | ((unsigned long long)t_sy << 28) | (unsigned long long)t_sx);
                             atomicMin(a_minx + kd, t_xs); atomicMax(a_maxx + kd, t_xe); atomicOr(a_rows + kd, t_rb);
                         }
                         act = act && !same;
                     }
                     if (act) {
-                        atomicAdd(a_area + k, len); atomicAdd(a_sx + k, sxv); atomicAdd(a_sy + k, syv);
+                        atomicAdd(a_pack + k, ((unsigned long long)len << 48) | ((unsigned long long)syv << 28) | (unsigned long long)sxv);
                         atomicMin(a_minx + k, xs); atomicMax(a_maxx + k, xe); atomicOr(a_rows + k, rowbit);
                     }
                 }
@@ -798,9 +798,10 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
                 if (k < (u32)C3_ACC && c0 + k < nroots) {
                     const u32 id = rid[c0 + k];
                     const u32 bit = 1u << (id & 31);
-                    c.area = a_area[k];
-                    c.sx = (u64)a_sx[k];
-                    c.sy = (u64)a_sy[k] + (u64)c.area * (u64)y0;
+                    const unsigned long long pk = a_pack[k];
+                    c.area = (u32)(pk >> 48);
+                    c.sx = pk & 0xfffffffull;
+                    c.sy = ((pk >> 28) & 0xfffffull) + (u64)c.area * (u64)y0;
                     c.minx = (int)a_minx[k]; c.maxx = (int)a_maxx[k];
                     c.miny = y0 + (__ffs((int)a_rows[k]) - 1); c.maxy = y0 + (31 - __clz((int)a_rows[k]));
                     tot_c.area += c.area; tot_c.sx += c.sx; tot_c.sy += c.sy;
@@ -998,5 +999,5 @@ __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const 
 static size_t c3_link_lds(const ccl_geom& G, const c3_plan& P) { return (size_t)P.R * G.ww * 8 + (size_t)P.ids * 4 + (size_t)P.ids / 32 * 4; }
 static size_t c3_label_lds(const ccl_geom& G, const c3_plan& P)
 {
-    return (size_t)P.R * G.ww * 8 + (size_t)P.ids / 2 * 4 + (size_t)P.ids * 2 + (size_t)P.ids / 2 * 2 + (size_t)P.ids / 32 * 4 * 5 + (size_t)C3_ACC * 4 * 6;
+    return (size_t)P.R * G.ww * 8 + (size_t)P.ids / 2 * 4 + (size_t)P.ids * 2 + (size_t)P.ids / 2 * 2 + (size_t)P.ids / 32 * 4 * 5 + 8 + (size_t)C3_ACC * 4 * 5;
 }
