@@ -244,18 +244,20 @@ def main():
     # ---- the rates a module sees (not `value`; PCIe and Python inclusive): module bodies through the per-operator mirror, a module on
     # the runtime end to end, host-fed batches through the dispatcher - each with the bound it runs against, measured in this run
     if not args.no_extras and rank == 0 and n_gpus == 1:
+        import contextlib
         import module_harness as MH
         try:
-            extras["process_body_red_buoy"] = MH.body_rates("buoy")
-            extras["process_body_bins"] = MH.body_rates("bins")
-            extras["runtime_e2e_red_buoy"] = MH.runtime_rate("buoy", seconds=3.0)
-            extras["runtime_e2e_bins"] = MH.runtime_rate("bins", seconds=2.0)
-            up = MH.pcie_upload_rate(ctx)
-            for tag, (fw, fh, nb) in (("host_fed_1080p", (1920, 1080, 10)), ("host_fed_4k", (3840, 2160, 4))):
-                r = MH.host_fed_rate(fw, fh, batch=32, batches=nb, ring=4)
-                r["pcie_upload_GBps_measured_now"] = round(up, 2)
-                r["frac_of_pcie"] = round(r["pcie_GBps"] / up, 3)
-                extras[tag] = r
+            with contextlib.redirect_stdout(sys.stderr):   # the modules announce themselves on stdout; stdout is for the one JSON line
+                extras["process_body_red_buoy"] = MH.body_rates("buoy")
+                extras["process_body_bins"] = MH.body_rates("bins")
+                extras["runtime_e2e_red_buoy"] = MH.runtime_rate("buoy", seconds=3.0)
+                extras["runtime_e2e_bins"] = MH.runtime_rate("bins", seconds=2.0)
+                up = MH.pcie_upload_rate(ctx)
+                for tag, (fw, fh, nb) in (("host_fed_1080p", (1920, 1080, 10)), ("host_fed_4k", (3840, 2160, 4))):
+                    r = MH.host_fed_rate(fw, fh, batch=32, batches=nb, ring=4)
+                    r["pcie_upload_GBps_measured_now"] = round(up, 2)
+                    r["frac_of_pcie"] = round(r["pcie_GBps"] / up, 3)
+                    extras[tag] = r
         except Exception as e:   # a side measurement must not take the headline down with it; the failure is reported as such
             extras["runtime_rates_error"] = repr(e)
 
