@@ -105,14 +105,24 @@ __device__ __forceinline__ void c3_unite(u32* p, u32* flags, u32* child, u32 a, 
     }
 }
 
-// A contact between two segments of a strip (LDS, strip-relative ids).  Most contacts are the FIRST link of their upper end: one
+// A contact between two segments of a strip (LDS, strip-relative ids).  Most contacts are the FIRST link of their larger end: one
 // atomicMin on parent[larger] settles them without a find (parents only ever decrease, so the pointers stay a forest).  When the
 // larger id already hung under something else, that something and the smaller id are one component: a real union
 // (compare-and-swap union-find with its finds) - a third of the contacts in raw noise instead of all of them.
 __device__ __forceinline__ void c3_contact(u32* lpar, u32 a, u32 b, int dbg = 0)
 {
-    const u32 hi = max(a, b), lo = min(a, b);
-    if (dbg & 2) { if (hi == 0xfffffff0u) lpar[0] = lo; return; }      // (timing experiments: the walk over the contacts alone)
+    const u32 hi = max(a, b), lo0 = min(a, b);
+    if (dbg & 2) { if (hi == 0xfffffff0u) lpar[0] = lo0; return; }     // (timing experiments: the walk over the contacts alone)
+    // ... under where the smaller end points NOW, up to four levels up (any ancestor of it will do): the rows of a strip are linked
+    // all at once, so the forest of first links would otherwise be as deep as the strip has rows, and the finds of the real unions walk
+    // it (strip union-find of 50 % noise: 1,055 -> 820 us per 128 frames)
+    u32 lo = lo0;
+#pragma unroll
+    for (int hop = 0; hop < 4; hop++) {
+        const u32 q = lpar[lo];
+        if (q == lo) break;
+        lo = q;
+    }
     const u32 old = atomicMin(lpar + hi, lo);
     if (old != hi && old != lo && !(dbg & 4)) lds_unite(lpar, old, lo);  // (dbg 4: ... with the first links, without the real unions)
 }
