@@ -181,3 +181,21 @@ def test_1080p_noise_frames(ccl_ctx, oracle, lo, numbering):
         assert np.array_equal(out["centroids"][f][:on].view(np.uint64), oce.view(np.uint64)), f
         assert not out["stats"][f][on:].any()
     assert int(out["nlabels"][2]) == 1 and not out["labels"][2].any()
+
+
+@pytest.mark.parametrize("lo,numbering", [(190, 2), (128, 1)], ids=["10pc", "50pc"])
+def test_4k_noise_frame(ccl_ctx, oracle, lo, numbering):
+    """The crowded-frame kernels at the other plan 1080p does not take: 3840 columns = 60 words per row, 8-row strips of 15,360 ids (270
+    strips per frame), one noise frame beside an empty one."""
+    from vision import _vp
+    from vision.utils import chain
+    fr = F.s3_noise(3, 3840, 2160)
+    on, olab, ost, oce = oracle.ccl(oracle.inrange(oracle.bgr2gray(fr), lo, 255), block=numbering)
+    batch = np.stack([np.zeros_like(fr), fr])
+    out = chain.run_chain(batch, _vp.BGR2GRAY, (lo, 0, 0), (255, 255, 255), [], ccl=1, numbering=numbering, max_labels=1 << 20)
+    assert int(out["nlabels"][1]) == on, (int(out["nlabels"][1]), on)
+    assert np.array_equal(out["labels"][1], olab)
+    assert np.array_equal(out["stats"][1][:on], ost)
+    assert np.array_equal(out["centroids"][1][:on].view(np.uint64), oce.view(np.uint64))
+    assert not out["stats"][1][on:].any()
+    assert int(out["nlabels"][0]) == 1 and not out["labels"][0].any()
