@@ -63,17 +63,25 @@ __device__ __forceinline__ u32 uf_find_halve(u32* p, u32 x)
         x = g;
     }
 }
-// links the larger root under the smaller; the absorbed root loses its bit in the root bitmap
+// links the larger root under the smaller; the absorbed root loses its bit in the root bitmap.  The two walks advance side by side,
+// halving as they go: every hop is a round trip to the memory side (agent-scope loads pass this die's L2) and the chains do not depend
+// on each other.
 __device__ __forceinline__ void uf_unite(u32* p, u32* flags, u32 a, u32 b)
 {
+    u32 qa = ld_rlx(p + a), qb = ld_rlx(p + b);
     for (;;) {
-        a = uf_find_halve(p, a);
-        b = uf_find_halve(p, b);
+        while (qa != a || qb != b) {
+            const bool ma = qa != a, mb = qb != b;
+            const u32 ga = ma ? ld_rlx(p + qa) : qa, gb = mb ? ld_rlx(p + qb) : qb;
+            if (ma) { if (ga != qa) st_rlx(p + a, ga); a = qa; qa = ga; }
+            if (mb) { if (gb != qb) st_rlx(p + b, gb); b = qb; qb = gb; }
+        }
         if (a == b) return;
-        if (a < b) { const u32 t = a; a = b; b = t; }
+        if (a < b) { const u32 t = a; a = b; b = t; const u32 tq = qa; qa = qb; qb = tq; }
         const u32 old = atomicCAS(p + a, a, b);
         if (old == a) { atomicAnd(flags + (a >> 5), ~(1u << (a & 31))); return; }
-        a = old;
+        qa = old;
+        qb = ld_rlx(p + b);
     }
 }
 
