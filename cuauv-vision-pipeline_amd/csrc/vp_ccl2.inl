@@ -13,8 +13,9 @@
 //   k_ccl2_write  label image: label = table[strip][component index of the word], one cached look-up in front of the store
 //
 // Frames that do not fit (a strip with more segments than its LDS union-find holds or more components than C2_RC, a frame with
-// more than C2_MCAP strip components) are flagged `crowded` by k_ccl2_merge and finished by the one-level kernels, which are
-// launched unconditionally on a side stream and leave at once for every other frame (vpk_ccl).
+// more than C2_MCAP strip components) are flagged `crowded` by k_ccl2_merge, which appends them to a list; the crowded-frame kernels
+// of vp_ccl3.inl (five launches behind the merge, on the same stream) finish the frames of that list and leave at once when it is
+// empty.  Geometries those kernels do not take fall back to the one-level kernels of vp_ccl.hip (vpk_ccl).
 
 // C2_RC (vp_ccl.hip): stride of the per-strip component tables; a kernel argument (rc <= C2_RC) bounds the count in use
 #ifdef VP_PROBE   // measurement builds only (tools/build_probe.sh): ticks between probe points, one slot per block (plain stores)

@@ -5,12 +5,14 @@
 // than a 962-entry LDS union-find fell back to compare-and-swap unions in global memory (5.9 ms per 128 frames of 50 % noise), and
 // every segment paid four dependent uncoalesced reads plus seven global atomics for its statistics (1.9 - 3.5 ms).  Here:
 //
-//   * strips are R rows with R * ceil(w/2) <= 8192 segment ids (1080p: 8 rows), so a strip's union-find ALWAYS fits in LDS - it is
+//   * strips are R rows with R * ceil(w/2) <= 16384 segment ids (1080p: 16 rows), so a strip's union-find ALWAYS fits in LDS - it is
 //     indexed by the strip-relative segment id itself, no compaction, no capacity fallback; links point at the smaller id, so a
 //     strip-local root is its component's smallest id (cv2's numbering key, section 4.3 of DESIGN.md);
-//   * what leaves the strip is one contiguous block of u16 "root of every segment id" (15 KB) and the bits of its local roots;
-//   * strips meet at their boundaries through a global union-find over LOCAL ROOTS only (a few per boundary once repeated pairs are
-//     dropped); a root that absorbs another is marked "has members elsewhere";
+//   * contacts between segments are bits of three masks per word, walked by a thread per half-word; most are settled by one
+//     atomicMin (first links), the rest by compare-and-swap unions;
+//   * what leaves the strip is one contiguous block of u16 "root of every segment id" (30 KB) and the bits of its local roots;
+//   * strips meet at their boundaries through a global union-find over LOCAL ROOTS only; a root that absorbs another is marked
+//     "has members elsewhere";
 //   * ranks (= labels) come from the root bitmap + popcount prefix as before;
 //   * a second pass per strip reloads the strip's u16 block into LDS and does everything else there: labels of the local roots
 //     (from the strip's own slice of bitmap + prefix; only absorbed roots walk global memory), statistics accumulated in LDS per
