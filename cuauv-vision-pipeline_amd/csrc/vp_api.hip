@@ -93,6 +93,7 @@ vp_ctx* vp_create(int device)
     hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming);
     ctx->ccl_levels = 2;
     ctx->ccl_mcap = -1;
+    for (size_t& v : ctx->c3_lds_set) v = 0;
     if (const char* env = getenv("VP_CCL_LEVELS")) { const int v = atoi(env); if (v == 1 || v == 2) ctx->ccl_levels = v; }
     // tables: gamma u16[256] | cbrt u16[2048] | sdiv i32[256] | hdiv i32[256]
     std::vector<uint16_t> gamma(256), cbrt(3072);

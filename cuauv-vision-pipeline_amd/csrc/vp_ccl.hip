@@ -703,11 +703,10 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
         if (P3.ok && !c3_off && (size_t)P3.strips + 1 <= c3_strips_cap(h) && sizeof(c3_state) == C3_STATE_BYTES) {
             lds3a = c3_link_lds(G, P3);
             lds3b = c3_label_lds(G, P3);
-            static size_t attr_a = 0, attr_b = 0;      // (grow-only; kernels accept more dynamic LDS than the 64 KB default once told so)
+            // (grow-only; kernels accept more dynamic LDS than the 64 KB default once told so - per device, hence kept in the context)
             const void* fa_ = c3_tall ? (const void*)k_ccl3_link<2 * C3_LINK_THREADS> : (const void*)k_ccl3_link<C3_LINK_THREADS>;
             const void* fb_ = c3_tall ? (const void*)k_ccl3_label<2 * C3_LABEL_THREADS> : (const void*)k_ccl3_label<C3_LABEL_THREADS>;
-            static size_t attr_a2 = 0, attr_b2 = 0;
-            size_t& ra = c3_tall ? attr_a2 : attr_a; size_t& rb = c3_tall ? attr_b2 : attr_b;
+            size_t& ra = ctx->c3_lds_set[c3_tall ? 2 : 0]; size_t& rb = ctx->c3_lds_set[c3_tall ? 3 : 1];
             if (lds3a > ra) { if (hipFuncSetAttribute(fa_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3a) == hipSuccess) ra = lds3a; else { (void)hipGetLastError(); P3.ok = 0; } }
             if (P3.ok && lds3b > rb) { if (hipFuncSetAttribute(fb_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3b) == hipSuccess) rb = lds3b; else { (void)hipGetLastError(); P3.ok = 0; } }
         } else {

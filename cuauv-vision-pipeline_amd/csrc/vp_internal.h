@@ -47,6 +47,7 @@ struct vp_ctx {
     const u32* cb_folds_dev;      // colour balance: device counter of tiles whose running mean had to be folded (last call); null or cb_folds_own
     u32* cb_folds_own;            // context-owned device word the counter is copied to (the workspace it is made in is carved anew per call)
     int ccl_levels;               // 2: two-level labelling with the one-level kernels as fallback (default); 1: one-level only
+    size_t c3_lds_set[4];         // dynamic LDS the crowded-frame kernels have been allowed on THIS device (link, label; short and tall strips): the attribute is per device
     int ccl_mcap;                 // components per frame the merge block accepts (-1: its LDS capacity); tests lower it to force the fallback
     vp_prof prof;
     char err[256];
