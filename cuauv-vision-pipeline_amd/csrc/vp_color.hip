@@ -49,6 +49,41 @@ __device__ __forceinline__ void hsv_px(const HsvLds& t, int b, int g, int r, int
     V = v;
 }
 
+// ---- BGR -> Lab inside the threshold kernels ------------------------------------------------------------------------------------------
+// The threshold kernels do not need L, a, b themselves, only "lo <= channel <= hi".  Every channel is a clamped, monotonic function
+// of one integer - L of fY, a of fX - fY, b of fY - fZ (lab_px above) - so the host turns each range into the interval of that integer
+// (lab_interval) and the kernel compares there: no multiply-shift-clamp per pixel.  And the three gamma look-ups + nine multiply-adds
+// of the X / Y / Z sums become three look-ups of pre-multiplied (X, Y) pairs + adds: coefficient * gamma[value] per input channel,
+// the rounding constant folded into the blue entries.  Same integers as OpenCV's statement sequence, ≈ half the VALU instructions
+// (the kernel was bound by them, not by HBM: it took the same time without its mask stores).
+struct LabTLds { uint2 xy[3][256]; u32 z[3][256]; uint16_t cbrt[2048]; };   // [0] blue, [1] green, [2] red
+
+__device__ __forceinline__ bool in_span(int v, int lo, int hi)             // lo <= v <= hi as one unsigned comparison; lo > hi: never
+{
+    const bool empty = lo > hi;                                            // wave-uniform (kernel arguments)
+    const u32 l = empty ? 0x7fffffffu : (u32)lo, span = empty ? 0u : (u32)hi - (u32)lo;
+    return (u32)v - l <= span;
+}
+
+// q holds the intervals of fY, fX - fY, fY - fZ (vpk_color_thresh)
+template <int NEED>
+__device__ __forceinline__ bool lab_test(const LabTLds& t, const vp_range3& q, int b, int g, int r)
+{
+    const uint2 pb = t.xy[0][b], pg = t.xy[1][g], pr = t.xy[2][r];
+    const int fY = t.cbrt[(pb.y + pg.y + pr.y) >> 12];
+    bool ok = true;
+    if (NEED & 1) ok = ok & in_span(fY, q.lo[0], q.hi[0]);
+    if (NEED & 2) {
+        const int fX = t.cbrt[(pb.x + pg.x + pr.x) >> 12];
+        ok = ok & in_span(fX - fY, q.lo[1], q.hi[1]);
+    }
+    if (NEED & 4) {
+        const int fZ = t.cbrt[(t.z[0][b] + t.z[1][g] + t.z[2][r]) >> 12];
+        ok = ok & in_span(fY - fZ, q.lo[2], q.hi[2]);
+    }
+    return ok;
+}
+
 __device__ __forceinline__ int gray_px(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14; }
 
 // lo <= c <= hi per channel as one unsigned comparison each: (unsigned)(c - lo) <= (unsigned)(hi - lo).  For an empty range (lo > hi) the
@@ -91,18 +126,35 @@ __device__ __forceinline__ void load_lds(typename ModeLds<MODE>::type& s, const 
     __syncthreads();
 }
 
-// predicate for one pixel
-template <int MODE, int NEED>
-__device__ __forceinline__ bool px_pred(const typename ModeLds<MODE>::type& s, const vp_range3& q, int b, int g, int r)
+// LDS of the threshold kernels: the pre-multiplied Lab tables, otherwise what the conversions use
+template <int MODE>
+struct ThreshLds { typedef typename ModeLds<MODE>::type type; };
+template <>
+struct ThreshLds<VP_BGR2LAB> { typedef LabTLds type; };
+
+template <int MODE>
+__device__ __forceinline__ void load_tlds(typename ThreshLds<MODE>::type& s, const vp_tables& tab)
 {
     if constexpr (MODE == VP_BGR2LAB) {
-        int L = 0, A = 0, Bc = 0;
-        lab_px<NEED>(s, b, g, r, L, A, Bc);
-        bool ok = true;
-        if (NEED & 1) ok = ok & (L >= q.lo[0]) & (L <= q.hi[0]);
-        if (NEED & 2) ok = ok & (A >= q.lo[1]) & (A <= q.hi[1]);
-        if (NEED & 4) ok = ok & (Bc >= q.lo[2]) & (Bc <= q.hi[2]);
-        return ok;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+            const u32 G = tab.gamma[i];
+            s.xy[0][i] = make_uint2(778u * G + 2048u, 296u * G + 2048u);  s.z[0][i] = 3575u * G + 2048u;   // blue (+ the rounding constant)
+            s.xy[1][i] = make_uint2(1541u * G, 2929u * G);                s.z[1][i] = 448u * G;            // green
+            s.xy[2][i] = make_uint2(1777u * G, 871u * G);                 s.z[2][i] = 73u * G;             // red
+        }
+        for (int i = threadIdx.x; i < 2048; i += blockDim.x) s.cbrt[i] = tab.cbrt[i];
+        __syncthreads();
+    } else {
+        load_lds<MODE>(s, tab);
+    }
+}
+
+// predicate for one pixel
+template <int MODE, int NEED>
+__device__ __forceinline__ bool px_pred(const typename ThreshLds<MODE>::type& s, const vp_range3& q, int b, int g, int r)
+{
+    if constexpr (MODE == VP_BGR2LAB) {
+        return lab_test<NEED>(s, q, b, g, r);
     } else if constexpr (MODE == VP_BGR2HSV) {
         int H, S, V;
         hsv_px(s, b, g, r, H, S, V);
@@ -126,8 +178,8 @@ __global__ __launch_bounds__(256, 8) void k_color_thresh_flat(const uint8_t* __r
                                                            vp_tables tab, vp_range3 q, uint8_t* __restrict__ mask,
                                                            u64* __restrict__ bits)
 {
-    __shared__ typename ModeLds<MODE>::type s;
-    load_lds<MODE>(s, tab);
+    __shared__ typename ThreshLds<MODE>::type s;
+    load_tlds<MODE>(s, tab);
     const size_t stride = (size_t)gridDim.x * 256;
     size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= ngroups) return;   // ngroups % 4 == 0 and g is quad-aligned: the 4 lanes of a word leave together
@@ -188,8 +240,8 @@ __global__ __launch_bounds__(256) void k_color_thresh_rows(const uint8_t* __rest
                                                            vp_tables tab, vp_range3 q, uint8_t* __restrict__ mask,
                                                            u64* __restrict__ bits)
 {
-    __shared__ typename ModeLds<MODE>::type s;
-    load_lds<MODE>(s, tab);
+    __shared__ typename ThreshLds<MODE>::type s;
+    load_tlds<MODE>(s, tab);
     const size_t row = blockIdx.x;
     const int grp = blockIdx.y * 256 + threadIdx.x;  // 16-px group, 4 per word
     const bool live = grp < ww * 4;
@@ -244,6 +296,21 @@ static int launch_thresh(vp_ctx* ctx, const uint8_t* d_bgr, size_t stride, int w
     return VP_OK;
 }
 
+// lo <= clamp255((mult * v + add) >> 15) <= hi  <=>  *vlo <= v <= *vhi (mult > 0; >> is the arithmetic shift = floor).  A bound the
+// clamp satisfies for every v becomes +-2^24 (v itself stays within +-2^16); an impossible range comes back as vlo > vhi.
+static void lab_interval(int lo, int hi, long long mult, long long add, int* vlo, int* vhi)
+{
+    const long long BIG = 1ll << 24;
+    auto floor_div = [](long long a, long long b) { long long q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) q--; return q; };
+    if (lo > hi || lo > 255 || hi < 0) { *vlo = 1; *vhi = 0; return; }
+    long long a = -BIG, b = BIG;
+    if (lo > 0) a = -floor_div(-((long long)lo * 32768 - add), mult);                 // ceil((lo * 2^15 - add) / mult)
+    if (hi < 255) b = floor_div(((long long)hi + 1) * 32768 - 1 - add, mult);
+    if (a < -BIG) a = -BIG;
+    if (b > BIG) b = BIG;
+    *vlo = (int)a; *vhi = (int)b;
+}
+
 int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride, int w, int h, int n, const vp_range3& q,
                      uint8_t* d_mask, u64* d_bits)
 {
@@ -253,12 +320,17 @@ int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride,
         int need = 0;
         for (int c = 0; c < 3; c++)
             if (!(q.lo[c] <= 0 && q.hi[c] >= 255)) need |= 1 << c;
+        // the ranges of L, a, b as intervals of fY, fX - fY, fY - fZ (lab_px: channel = clamp255((mult * v + add) >> 15))
+        vp_range3 qi;
+        lab_interval(q.lo[0], q.hi[0], 296, (long long)LAB_LSHIFT + 16384, &qi.lo[0], &qi.hi[0]);
+        lab_interval(q.lo[1], q.hi[1], 500, (128ll << 15) + 16384, &qi.lo[1], &qi.hi[1]);
+        lab_interval(q.lo[2], q.hi[2], 200, (128ll << 15) + 16384, &qi.lo[2], &qi.hi[2]);
         switch (need) {
             case 0: need = 1;  // everything passes; evaluate L so that the kernel stays generic
-            case 1: return launch_thresh<VP_BGR2LAB, 1>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
-            case 2: return launch_thresh<VP_BGR2LAB, 2>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
-            case 4: return launch_thresh<VP_BGR2LAB, 4>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
-            default: return launch_thresh<VP_BGR2LAB, 7>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+            case 1: return launch_thresh<VP_BGR2LAB, 1>(ctx, d_bgr, stride, w, h, n, qi, d_mask, d_bits);
+            case 2: return launch_thresh<VP_BGR2LAB, 2>(ctx, d_bgr, stride, w, h, n, qi, d_mask, d_bits);
+            case 4: return launch_thresh<VP_BGR2LAB, 4>(ctx, d_bgr, stride, w, h, n, qi, d_mask, d_bits);
+            default: return launch_thresh<VP_BGR2LAB, 7>(ctx, d_bgr, stride, w, h, n, qi, d_mask, d_bits);
         }
     }
     if (mode == VP_BGR2HSV) return launch_thresh<VP_BGR2HSV, 7>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
