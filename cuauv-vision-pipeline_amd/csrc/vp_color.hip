@@ -9,6 +9,7 @@
 // kernels consume.  The arithmetic is OpenCV's 8-bit fixed point; the
 // LUTs live in LDS.  HBM-bound: 4.125 B/px.
 #include "vp_internal.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -18,6 +19,14 @@ struct LabLds { uint16_t gamma[256]; uint16_t cbrt[2048]; };
 struct HsvLds { int32_t sdiv[256]; int32_t hdiv[256]; };
 
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// signed 24-bit multiply, low 32 bits of the product (full rate; v_mul_lo_u32 runs at a quarter of it).  Spelled as the instruction:
+// __mul24 becomes it only where the compiler can bound both operands itself.
+__device__ __forceinline__ int mul_i24(int a, int b)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // NEED bit0 = L, bit1 = a, bit2 = b
 template <int NEED>
@@ -41,9 +50,9 @@ __device__ __forceinline__ void hsv_px(const HsvLds& t, int b, int g, int r, int
     int v = max(max(b, g), r);
     int vmin = min(min(b, g), r);
     int diff = v - vmin;
-    S = (diff * t.sdiv[v] + 2048) >> 12;
+    S = (mul_i24(diff, t.sdiv[v]) + 2048) >> 12;   // (operands of 8 x 20 and 12 x 17 bits: the 24-bit multiply is exact)
     int hh = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
-    hh = (hh * t.hdiv[diff] + 2048) >> 12;
+    hh = (mul_i24(hh, t.hdiv[diff]) + 2048) >> 12;
     hh += hh < 0 ? 180 : 0;
     H = hh;            // in [0, 180): the three branches give [-30, 30], [30, 90], [90, 150] before the wrap, so no clamp is needed
     V = v;
@@ -82,6 +91,19 @@ __device__ __forceinline__ bool lab_test(const LabTLds& t, const vp_range3& q, i
         ok = ok & in_span(fY - fZ, q.lo[2], q.hi[2]);
     }
     return ok;
+}
+
+// BGR -> HSV inside the threshold kernels, the same idea: S and H are floor((product + 2048) / 4096) of a product the kernel has
+// anyway, so their ranges are compared as intervals of the products (hsv_intervals); the hue's "+ 180 when negative" makes its range two
+// intervals, one for each sign.  q: [0] and lo2 / hi2 = the two intervals of hh * hdiv[diff], [1] = interval of diff * sdiv[v], [2] = V.
+__device__ __forceinline__ bool hsv_test(const HsvLds& t, const vp_range3& q, int b, int g, int r)
+{
+    const int v = max(max(b, g), r);
+    const int diff = v - min(min(b, g), r);
+    const int ps = mul_i24(diff, t.sdiv[v]);          // 8 x 20 bits, and 12 x 17 bits below: the full-rate 24-bit multiply is exact (v_mul_lo_u32 runs at a quarter of the rate)
+    const int hh = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    const int ph = mul_i24(hh, t.hdiv[diff]);
+    return (in_span(ph, q.lo[0], q.hi[0]) | in_span(ph, q.lo2, q.hi2)) & in_span(ps, q.lo[1], q.hi[1]) & in_span(v, q.lo[2], q.hi[2]);
 }
 
 __device__ __forceinline__ int gray_px(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14; }
@@ -156,9 +178,7 @@ __device__ __forceinline__ bool px_pred(const typename ThreshLds<MODE>::type& s,
     if constexpr (MODE == VP_BGR2LAB) {
         return lab_test<NEED>(s, q, b, g, r);
     } else if constexpr (MODE == VP_BGR2HSV) {
-        int H, S, V;
-        hsv_px(s, b, g, r, H, S, V);
-        return in3(q, H, S, V);
+        return hsv_test(s, q, b, g, r);
     } else {
         int y = gray_px(b, g, r);
         return (y >= q.lo[0]) & (y <= q.hi[0]);
@@ -311,6 +331,25 @@ static void lab_interval(int lo, int hi, long long mult, long long add, int* vlo
     *vlo = (int)a; *vhi = (int)b;
 }
 
+// lo <= floor((p + 2048) / 4096) <= hi  <=>  *plo <= p <= *phi (bounds clamped so that the products stay inside int)
+static void shift12_interval(long long lo, long long hi, int* plo, int* phi)
+{
+    if (lo > hi) { *plo = 1; *phi = 0; return; }
+    lo = std::max(lo, -100000ll); hi = std::min(hi, 100000ll);
+    *plo = (int)(lo * 4096 - 2048);
+    *phi = (int)((hi + 1) * 4096 - 2049);
+}
+// the H / S / V ranges of an HSV threshold as what hsv_test compares: H = t (t >= 0) or t + 180 (t < 0) with t = floor((ph + 2048) / 4096)
+static void hsv_intervals(const vp_range3& q, vp_range3* o)
+{
+    const long long hlo = q.lo[0], hhi = q.hi[0];
+    shift12_interval(std::max(hlo, 0ll), hhi, &o->lo[0], &o->hi[0]);                      // t >= 0
+    shift12_interval(hlo - 180, std::min(hhi - 180, -1ll), &o->lo2, &o->hi2);             // t < 0
+    shift12_interval(std::max((long long)q.lo[1], 0ll), q.hi[1], &o->lo[1], &o->hi[1]);  // S >= 0 always
+    o->lo[2] = q.lo[2]; o->hi[2] = q.hi[2];
+    if (q.lo[0] > q.hi[0]) { o->lo[0] = o->lo2 = 1; o->hi[0] = o->hi2 = 0; }
+}
+
 int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride, int w, int h, int n, const vp_range3& q,
                      uint8_t* d_mask, u64* d_bits)
 {
@@ -333,7 +372,11 @@ int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride,
             default: return launch_thresh<VP_BGR2LAB, 7>(ctx, d_bgr, stride, w, h, n, qi, d_mask, d_bits);
         }
     }
-    if (mode == VP_BGR2HSV) return launch_thresh<VP_BGR2HSV, 7>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
+    if (mode == VP_BGR2HSV) {
+        vp_range3 qi;
+        hsv_intervals(q, &qi);
+        return launch_thresh<VP_BGR2HSV, 7>(ctx, d_bgr, stride, w, h, n, qi, d_mask, d_bits);
+    }
     if (mode == VP_BGR2GRAY) return launch_thresh<VP_BGR2GRAY, 1>(ctx, d_bgr, stride, w, h, n, q, d_mask, d_bits);
     return vp_fail(ctx, VP_ERR_INVALID, "color mode");
 }

@@ -87,7 +87,7 @@ int vp_fail(vp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 void vp_host_tables(uint16_t* gamma, uint16_t* cbrt_tab, int32_t* sdiv, int32_t* hdiv180, int32_t* labC);
 
 // ---- colour kernels (vp_color.hip) ---------------------------------------------------------
-struct vp_range3 { int lo[3], hi[3]; };
+struct vp_range3 { int lo[3], hi[3]; int lo2, hi2; };   // lo2 / hi2: second interval of the hue test inside the HSV threshold kernels (vpk_color_thresh)
 // fused convert + inRange (+ optional u8 mask, + optional bit-packed mask) over n frames
 int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride, int w, int h, int n,
                      const vp_range3& r, uint8_t* d_mask /*nullable*/, u64* d_bits /*nullable*/);
