@@ -1366,9 +1366,16 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
         for (int f0 = 0; f0 < n; f0 += group) {
             const int g = std::min(group, n - f0);
             ctx->ws_off = mark;   // every group reuses the same scratch (stream order keeps them apart)
+            // the chain has just labelled this very mask: its label image and statistics give the contour pass every component's first pixel
+            vp_known_labels kn = {nullptr, nullptr, nullptr, 0};
+            const bool same_mask = d->ccl && ccl_bits == src && b->labels && b->stats;
+            if (same_mask) {
+                kn.labels = b->labels + (size_t)f0 * w * h; kn.stats = b->stats + (size_t)f0 * d->max_labels * 5;
+                kn.nlabels = (b->nlabels ? b->nlabels : d_nl) + f0; kn.max_labels = d->max_labels;
+            }
             VP_TRY(vpk_find_contours(ctx, src + (size_t)f0 * fw, w, h, g, cd->mode, cd->method, cb->counts + f0 * mc, cb->is_hole + f0 * mc,
                                      cb->offsets + f0 * mc, cb->points + 2 * (size_t)f0 * (size_t)cd->max_points, cd->max_contours,
-                                     cd->max_points, cb->info + 2 * (size_t)f0));
+                                     cd->max_points, cb->info + 2 * (size_t)f0, same_mask ? &kn : nullptr));
         }
         if (cb->features) VP_TRY(vpk_contour_features(ctx, cb->info, cb->counts, cb->offsets, cb->points, n, cd->max_contours, cd->max_points, cb->features));
     }

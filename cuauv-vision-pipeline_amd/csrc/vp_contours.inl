@@ -652,13 +652,43 @@ size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
     const size_t words = (size_t)n * h * vp_ww(w);
     const size_t hcap = ct_hcap(w, h) * n;
     return 2 * vp_align(nids * 4 * n) + 3 * vp_align(nids / 8 * n) + 3 * vp_align(words * 8) + vp_align(words * 32) + 2 * vp_align(words * 4) +
-           2 * vp_align(hcap * 4) + vp_align(hcap * 8) + 2 * vp_align((size_t)n * max_contours * 4) + vp_align(sizeof(ct_aux) * n) + 2 * vp_align(words / 64 + 4 * n) + 8192;
+           2 * vp_align(hcap * 4) + vp_align(hcap * 8) + 2 * vp_align((size_t)n * max_contours * 4) + vp_align(sizeof(ct_aux) * n) + 2 * vp_align(words / 64 + 4 * n) + vp_align((size_t)n * 4) + 8192;
+}
+
+// Root bitmap of the foreground from a labelling that already exists: a component's first pixel in raster order lies in the top row of
+// its box and is the first pixel of that row that carries its label; the segment starting there is the component's smallest segment id
+// (pixel numbering) - the bit the foreground union-find would have left.  One wave per label; frames whose statistics table was too
+// small for their labels are marked in `only` and go through the union-find as before.  grid (ceil((max_labels - 1) / 4), n) x 256.
+__global__ __launch_bounds__(256) void k_ct_roots_from_labels(ccl_geom G, const int32_t* __restrict__ labels, const int32_t* __restrict__ stats,
+                                                              const int32_t* __restrict__ nlabels, int max_labels, u32* __restrict__ flags,
+                                                              u32* __restrict__ only)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int nl = nlabels[f];
+    if (blockIdx.x == 0 && threadIdx.x == 0) only[f] = nl > max_labels ? 1u : 0u;
+    if (nl > max_labels) return;
+    const int L = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
+    if (L >= nl) return;
+    const int32_t* st = stats + ((size_t)f * max_labels + L) * 5;
+    const int x0 = st[0], y = st[1], x1 = st[0] + st[2];
+    const int32_t* row = labels + ((size_t)f * G.h + y) * G.w;
+    for (int xb = x0; xb < x1; xb += 64) {
+        const int x = xb + lane;
+        const unsigned long long m = __ballot(x < x1 && row[x] == L);
+        if (m) {
+            if (lane == 0) {
+                const u32 id = seg_id(G, y, xb + __ffsll((long long)m) - 1);
+                atomicOr(flags + (size_t)f * G.nw32 + (id >> 5), 1u << (id & 31));
+            }
+            return;
+        }
+    }
 }
 
 // d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
 // stored in discovery order (raster order of the start pixel); cv2 returns them reversed - the caller reverses.
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
-                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info)
+                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
 {
     if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
     if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
@@ -723,7 +753,24 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     }
     // join whatever was queued on the side stream, also after an error
     const hipError_t j1 = hipEventRecord(ctx->ev_fb_join, side);
-    if (rc == VP_OK) rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
+    {
+        // the foreground's root bitmap: from the caller's labelling of the same mask when there is one (frames it could not hold keep
+        // the union-find through its per-frame switch), otherwise the union-find for every frame
+        size_t cap_unused;
+        static const bool known_off = getenv("VP_CT_KNOWN") && atoi(getenv("VP_CT_KNOWN")) == 0;
+        const bool use_known = known && !known_off && known->labels && known->stats && known->nlabels && known->max_labels >= 2 && known->max_labels <= 4096 &&
+                               ccl_local_lds(Gf, cap_unused) <= 64 * 1024;
+        if (rc == VP_OK && use_known) {
+            u32* only = (u32*)vp_ws_take(ctx, (size_t)n * 4);
+            if (!only) return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
+            VP_HIP(ctx, hipMemsetAsync(fg_flags, 0, (size_t)Gf.nw32 * 4 * n, s));
+            hipLaunchKernelGGL(k_ct_roots_from_labels, dim3((unsigned)((known->max_labels - 1 + 3) / 4), (unsigned)n), dim3(256), 0, s, Gf, known->labels,
+                               known->stats, known->nlabels, known->max_labels, fg_flags, only);
+            rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags, only);
+        } else if (rc == VP_OK) {
+            rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
+        }
+    }
     if (rc == VP_OK) {
         hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2);
         hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);

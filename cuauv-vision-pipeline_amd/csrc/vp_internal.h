@@ -178,8 +178,13 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
 size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours);
 int vpk_contour_features(vp_ctx* ctx, const int32_t* d_info, const int32_t* d_counts, const int32_t* d_offsets, const int32_t* d_points, int n,
                          int max_contours, long long max_points, double* d_features);
+// A labelling of the very mask the contours are asked for, when the caller has one (the chain's): label image, statistics rows and
+// label counts of the same frames, all on the device.  The contour pass then takes every component's first pixel from them instead of
+// running its own foreground union-find.
+struct vp_known_labels { const int32_t* labels; const int32_t* stats; const int32_t* nlabels; int max_labels; };
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
-                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info);
+                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info,
+                      const struct vp_known_labels* known = nullptr);
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
             int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels);
 

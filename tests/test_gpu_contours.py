@@ -334,3 +334,28 @@ def test_every_4x4_pattern_through_morphology(vp, oracle):
                              ("morph_borders", oracle.GRADIENT)):
                 got = getattr(transform, name)(m, se)
                 assert np.array_equal(got, oracle.morph(op, m, se)), (pitch, shape, k, name)
+
+
+@pytest.mark.parametrize("max_labels,numbering", [(256, 2), (3, 1), (2, 2)])
+def test_chain_contours_from_the_chains_own_labelling(vp, oracle, max_labels, numbering):
+    """With the label image and the statistics among the outputs, the contour pass of the same mask takes every component's first pixel
+    from them instead of running its foreground union-find; frames with more labels than the statistics table holds keep the union-find.
+    A batch that mixes both kinds (blobs, empty, full, speckle): contours, hole flags and labels as the oracle's, for every table size."""
+    from vision import _vp
+    from vision.utils import chain
+    h, w = 200, 320
+    rng = np.random.default_rng(7)
+    frames = np.stack([F.s1_buoy(1, w, h), F.s4_flat(0, w, h), F.s1_buoy(2, w, h), F.s4_flat(255, w, h), F.s2_bins(3, w, h), F.s1_buoy(5, w, h)])
+    morph = ((_vp.MORPH_OPEN, 3, 3),)
+    for mode in (0, 1):
+        out = chain.run_chain(frames, _vp.BGR2LAB, (0, 140, 0), (255, 255, 255), morph, ccl=1, numbering=numbering, max_labels=max_labels,
+                              want=("cleaned", "labels", "stats"), contours=dict(source="cleaned", mode=mode, method=2, max_contours=512, max_points=1 << 15))
+        k = np.ones((3, 3), np.uint8)
+        for f in range(len(frames)):
+            th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(frames[f])[:, :, 1]), 140, 255)
+            cl = oracle.morph(oracle.OPEN, th, k, fast=True)
+            on, olab, ost, _ = oracle.ccl(cl, block=numbering)
+            assert int(out["nlabels"][f]) == on and np.array_equal(out["labels"][f], olab)
+            exp, eh = oracle.find_contours(cl, mode, 2, with_holes=True)
+            got, gh = out["contours"][f]
+            assert _same(got, exp) and np.array_equal(gh, eh), (max_labels, mode, f, len(got), len(exp))
