@@ -745,3 +745,31 @@ def test_adaptive_threshold_mean_u8(vp, oracle):
     labels = rng.integers(0, 3, (6, 7))
     masks = color.mask_from_labels(labels, np.zeros((3, 3)))
     assert len(masks) == 3 and all(np.array_equal(m, np.where(labels == i, 255, 0)) for i, m in enumerate(masks))
+
+
+def test_fused_threshold_kernels_over_many_ranges_all_colours(vp, oracle):
+    """The fused convert + threshold kernels compare Lab and HSV ranges as intervals of the integers the channels are made from (the host
+    turns each range into such an interval): every one of the 2^24 colours against the oracle's convert-then-inRange for ranges at the
+    edges of that translation - single values, the ends of the type, bounds outside it, empty ranges, every channel alone and together."""
+    from vision import _vp
+    from vision.utils import chain
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.stack([(v & 255), (v >> 8) & 255, v >> 16], axis=1).astype(np.uint8).reshape(4096, 4096, 3)
+    olab, ohsv = oracle.bgr2lab(img), oracle.bgr2hsv(img)
+    lab_ranges = [((0, 0, 0), (255, 255, 255)), ((0, 0, 0), (0, 255, 255)), ((255, 0, 0), (255, 255, 255)), ((1, 0, 0), (254, 255, 255)),
+                  ((128, 0, 0), (128, 255, 255)), ((0, 128, 0), (255, 128, 255)), ((0, 0, 128), (255, 255, 128)), ((0, 127, 0), (255, 129, 255)),
+                  ((0, 0, 0), (255, 0, 255)), ((0, 255, 0), (255, 255, 255)), ((0, 0, 255), (255, 255, 255)), ((0, 0, 0), (255, 255, 0)),
+                  ((0, 42, 0), (255, 41, 255)), ((-5, -1, -300), (300, 400, 256)), ((0, 256, 0), (255, 300, 255)), ((0, -9, 0), (255, -1, 255)),
+                  ((97, 131, 77), (98, 200, 201)), ((0, 100, 100), (255, 150, 150)), ((50, 0, 120), (60, 255, 136)), ((254, 127, 127), (255, 129, 129))]
+    hsv_ranges = [((0, 0, 0), (179, 255, 255)), ((0, 0, 0), (0, 255, 255)), ((179, 0, 0), (179, 255, 255)), ((1, 0, 0), (178, 255, 255)),
+                  ((150, 0, 0), (179, 255, 255)), ((0, 0, 0), (29, 255, 255)), ((30, 0, 0), (90, 255, 255)), ((90, 0, 0), (150, 255, 255)),
+                  ((0, 0, 0), (179, 0, 255)), ((0, 255, 0), (179, 255, 255)), ((0, 1, 0), (179, 254, 255)), ((0, 0, 0), (179, 255, 0)),
+                  ((0, 0, 255), (179, 255, 255)), ((0, 0, 1), (179, 255, 254)), ((60, 0, 0), (59, 255, 255)), ((0, 90, 0), (179, 89, 255)),
+                  ((-3, -1, -2), (200, 300, 256)), ((180, 0, 0), (255, 255, 255)), ((0, 0, 0), (-1, 255, 255)), ((10, 20, 60), (30, 100, 255)),
+                  ((120, 128, 128), (121, 129, 129)), ((0, 0, 200), (179, 30, 255))]
+    for mode, conv, ranges in ((_vp.BGR2LAB, olab, lab_ranges), (_vp.BGR2HSV, ohsv, hsv_ranges)):
+        for lo, hi in ranges:
+            out = chain.run_chain(img[None], mode, lo, hi, [], ccl=0, want=("threshed",))
+            c = conv.astype(np.int32)                                                           # inRange on the oracle's conversion, bounds as given
+            exp = (np.all((c >= np.array(lo)) & (c <= np.array(hi)), axis=2) * 255).astype(np.uint8)
+            assert np.array_equal(out["threshed"][0], exp), (mode, lo, hi, int((out["threshed"][0] != exp).sum()))
