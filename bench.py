@@ -251,6 +251,8 @@ def main():
                 extras["process_body_red_buoy"] = MH.body_rates("buoy")
                 extras["process_body_bins"] = MH.body_rates("bins")
                 extras["runtime_e2e_red_buoy"] = MH.runtime_rate("buoy", seconds=3.0)
+                # the reference's default mode: every post() published for the GUI (core/base.py:846-876; --enable-performance is opt-in)
+                extras["runtime_e2e_red_buoy_posts_on"] = MH.runtime_rate("buoy", seconds=3.0, flags=())
                 extras["runtime_e2e_bins"] = MH.runtime_rate("bins", seconds=2.0)
                 up = MH.pcie_upload_rate(ctx)
                 for tag, (fw, fh, nb) in (("host_fed_1080p", (1920, 1080, 10)), ("host_fed_4k", (3840, 2160, 4))):

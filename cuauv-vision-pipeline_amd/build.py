@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
-VP_SOURCES = ["vp_api.hip", "vp_color.hip", "vp_morph.hip", "vp_ccl.hip", "vp_balance.hip", "vp_yolo.hip", "vp_filter.hip", "vp_feed.hip", "vp_tables.cpp"]
+VP_SOURCES = ["vp_api.hip", "vp_color.hip", "vp_morph.hip", "vp_ccl.hip", "vp_balance.hip", "vp_yolo.hip", "vp_filter.hip", "vp_feed.hip", "vp_post.hip", "vp_tables.cpp"]
 
 
 def _stale(target, deps):

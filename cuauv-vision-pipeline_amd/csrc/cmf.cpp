@@ -60,6 +60,8 @@ static_assert(offsetof(ShmHeader, cond) == 1104, "cond offset");
 static_assert(offsetof(ShmHeader, mutex) == 1152, "mutex offset");
 static_assert(offsetof(ShmHeader, payload) == 1216, "payload offset");
 static_assert(sizeof(FramePlane) == 72 && sizeof(Frame) == 360 && sizeof(FramePlaneWrite) == 48, "ABI structs");
+// libvp's feeder (csrc/vp_feed.hip) reads these two fields out of a Frame it only knows as 360 bytes
+static_assert(offsetof(Frame, uid) == 40 && offsetof(Frame, total_size) == 56, "Frame field offsets the feeder relies on");
 
 thread_local char t_err[256] = "";
 void set_err(const char* what, const std::string& detail = "")
@@ -128,6 +130,8 @@ struct Block {
     ShmHeader* shm = nullptr;
     size_t mapped = 0;
     int refs = 0;   // handles given out by create_block / open_block in this process
+    uint64_t open_seq = 0;   // sequence number of a deferred write in progress (cmf_write_begin), 0: none; single writer per block
+    size_t open_idx = 0;     // its slot
 
     size_t shm_size() const { return offsetof(ShmHeader, payload) + shm->max_entry_size_bytes * CMF_BUFFER_CNT; }
     ~Block()
@@ -305,40 +309,51 @@ void delete_block(Block* block)
     }
 }
 
-int write_frame_planes(Block* block, uint64_t acquisition_time, const FramePlaneWrite* planes, size_t plane_count)
+// Validates the planes of a write and returns the bytes they take in the slot (negative: a CMF_ERR_* status, text in cmf_last_error).
+// need_data: write_frame_planes copies from planes[i].data itself; the deferred form (cmf_write_commit) only describes what was moved.
+static long long planes_bytes(const ShmHeader* h, const FramePlaneWrite* planes, size_t plane_count, bool need_data)
 {
-    if (!block || !block->shm) { set_err("null block"); return CMF_ERR_INVALID; }
-    ShmHeader* h = block->shm;
-    if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
     if (!planes) { set_err("planes pointer cannot be null"); return CMF_ERR_INVALID; }
     if (plane_count == 0 || plane_count > CMF_MAX_PLANE_CNT) { set_err("invalid plane count"); return CMF_ERR_INVALID; }
     size_t entry = 0;
     for (size_t i = 0; i < plane_count; i++) {
         const FramePlaneWrite& p = planes[i];
-        if (!p.data) { set_err("plane has null data pointer"); return CMF_ERR_INVALID; }
+        if (need_data && !p.data) { set_err("plane has null data pointer"); return CMF_ERR_INVALID; }
         if (p.type_size != 1 && p.type_size != 4 && p.type_size != 8) { set_err("unsupported type size (expected 1, 4 or 8)"); return CMF_ERR_INVALID; }
         entry += p.width * p.height * p.depth * p.type_size;
     }
     if (entry > h->max_entry_size_bytes) { set_err("frame larger than the block's max_entry_size_bytes"); return CMF_ERR_TOO_LARGE; }
+    return (long long)entry;
+}
 
+// First half of a write: the slot after the newest one is opened (readers that still copy its old frame now see begin != end and
+// retry).  The slot is NOT the one readers are sent to (that is uid % 3) until publish_slot.
+static uint64_t open_slot(ShmHeader* h, size_t* idx_out)
+{
     const uint64_t uid = load_acq(&h->uid);
     const size_t idx = (size_t)((uid + 1) % CMF_BUFFER_CNT);
     ShmSlot& s = h->slots[idx];
     const uint64_t seq = load_acq(&s.seq_begin) + 1;
     store_rel(&s.seq_begin, seq);                       // readers of this slot now see begin != end
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    unsigned char* dst = h->payload + idx * h->max_entry_size_bytes;
-    size_t cursor = 0;
+    *idx_out = idx;
+    return seq;
+}
+
+// Second half: metadata, closing sequence number, uid, wake-up.  The payload is in the slot by now.
+static void publish_slot(ShmHeader* h, size_t idx, uint64_t seq, uint64_t acquisition_time, const FramePlaneWrite* planes, size_t plane_count,
+                         size_t entry)
+{
+    ShmSlot& s = h->slots[idx];
     ShmSlot meta;                                       // the slot's metadata, built here and copied over in one go
     memset(&meta, 0, sizeof meta);
+    size_t cursor = 0;
     for (size_t i = 0; i < plane_count; i++) {
         const FramePlaneWrite& p = planes[i];
-        const size_t bytes = p.width * p.height * p.depth * p.type_size;
-        racy_write(dst + cursor, p.data, bytes);
         ShmPlane& m = meta.planes[i];
         m.width = p.width; m.height = p.height; m.depth = p.depth; m.type_size = p.type_size; m.offset = cursor;
         if (p.name) strncpy(m.name, p.name, CMF_PLANE_NAME_MAX_LEN - 1);
-        cursor += bytes;
+        cursor += p.width * p.height * p.depth * p.type_size;
     }
     meta.acquisition_time = acquisition_time;
     meta.total_size = entry;
@@ -350,6 +365,70 @@ int write_frame_planes(Block* block, uint64_t acquisition_time, const FramePlane
     store_rel(&s.seq_end, seq);                         // frame complete
     __atomic_fetch_add(&h->uid, 1, __ATOMIC_ACQ_REL);   // publish: slot uid % 3 is the newest
     pthread_cond_broadcast(&h->cond);
+}
+
+int write_frame_planes(Block* block, uint64_t acquisition_time, const FramePlaneWrite* planes, size_t plane_count)
+{
+    if (!block || !block->shm) { set_err("null block"); return CMF_ERR_INVALID; }
+    ShmHeader* h = block->shm;
+    if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    const long long entry = planes_bytes(h, planes, plane_count, true);
+    if (entry < 0) return (int)entry;
+    if (block->open_seq) { set_err("a deferred write (cmf_write_begin) is open on this block: commit or abort it first"); return CMF_ERR_INVALID; }
+    size_t idx;
+    const uint64_t seq = open_slot(h, &idx);
+    unsigned char* dst = h->payload + idx * h->max_entry_size_bytes;
+    size_t cursor = 0;
+    for (size_t i = 0; i < plane_count; i++) {
+        const FramePlaneWrite& p = planes[i];
+        const size_t bytes = p.width * p.height * p.depth * p.type_size;
+        racy_write(dst + cursor, p.data, bytes);
+        cursor += bytes;
+    }
+    publish_slot(h, idx, seq, acquisition_time, planes, plane_count, (size_t)entry);
+    return SUCCESS;
+}
+
+int cmf_write_begin(Block* block, uint64_t entry_bytes, void** payload, uint64_t* ticket)
+{
+    if (!block || !block->shm || !payload || !ticket) { set_err("null block, payload or ticket"); return CMF_ERR_INVALID; }
+    ShmHeader* h = block->shm;
+    if (__atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE)) return FRAMEWORK_DELETED;
+    if (entry_bytes == 0) { set_err("empty frame"); return CMF_ERR_INVALID; }
+    if (entry_bytes > h->max_entry_size_bytes) { set_err("frame larger than the block's max_entry_size_bytes"); return CMF_ERR_TOO_LARGE; }
+    if (block->open_seq) { set_err("a deferred write is already open on this block"); return CMF_ERR_INVALID; }
+    size_t idx;
+    const uint64_t seq = open_slot(h, &idx);
+    block->open_seq = seq;
+    block->open_idx = idx;
+    *payload = h->payload + idx * h->max_entry_size_bytes;
+    *ticket = seq;
+    return SUCCESS;
+}
+
+int cmf_write_commit(Block* block, uint64_t ticket, uint64_t acquisition_time, const FramePlaneWrite* planes, size_t plane_count)
+{
+    if (!block || !block->shm) { set_err("null block"); return CMF_ERR_INVALID; }
+    ShmHeader* h = block->shm;
+    if (!block->open_seq || block->open_seq != ticket) { set_err("no deferred write with this ticket is open on the block"); return CMF_ERR_INVALID; }
+    const long long entry = planes_bytes(h, planes, plane_count, false);
+    if (entry < 0) return (int)entry;
+    // the payload was moved by somebody else (a copy engine): order its completion, which the caller has observed, before the metadata
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    publish_slot(h, block->open_idx, ticket, acquisition_time, planes, plane_count, (size_t)entry);
+    block->open_seq = 0;
+    return __atomic_load_n(&h->deleted, __ATOMIC_ACQUIRE) ? FRAMEWORK_DELETED : SUCCESS;
+}
+
+int cmf_write_abort(Block* block, uint64_t ticket)
+{
+    if (!block || !block->shm) { set_err("null block"); return CMF_ERR_INVALID; }
+    if (!block->open_seq || block->open_seq != ticket) { set_err("no deferred write with this ticket is open on the block"); return CMF_ERR_INVALID; }
+    // The slot never became the newest one, so no reader is sent to it; a reader that was still copying its OLD frame has seen
+    // begin != end since cmf_write_begin and retries on a newer slot.  Closing the sequence pair leaves the slot reusable: the next
+    // write opens the same slot again (uid did not move) and bumps the pair once more.
+    store_rel(&block->shm->slots[block->open_idx].seq_end, ticket);
+    block->open_seq = 0;
     return SUCCESS;
 }
 

@@ -124,6 +124,7 @@ int vp_destroy(vp_ctx* ctx)
     if (!ctx) return VP_ERR_INVALID;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    vp_post_teardown(ctx);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->hstage) hipHostFree(ctx->hstage);
     if (ctx->d_tables) hipFree(ctx->d_tables);
@@ -266,6 +267,12 @@ int vp_host_unregister(vp_ctx* ctx, void* p)
 {
     const hipError_t e = hipHostUnregister(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return ctx ? vp_fail(ctx, VP_ERR_HIP, "hipHostUnregister", e) : VP_ERR_HIP; }
+    return VP_OK;
+}
+int vp_memcpy_d2d_async(vp_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx || !dst || !src) return VP_ERR_INVALID;
+    if (bytes) VP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return VP_OK;
 }
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst, const void* src, size_t bytes)

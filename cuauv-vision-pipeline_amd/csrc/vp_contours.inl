@@ -761,12 +761,18 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
         const bool use_known = known && !known_off && known->labels && known->stats && known->nlabels && known->max_labels >= 2 && known->max_labels <= 4096 &&
                                ccl_local_lds(Gf, cap_unused) <= 64 * 1024;
         if (rc == VP_OK && use_known) {
+            // (no early return in here: the side stream is joined below whatever happens, and the caller reuses the scratch after an error)
             u32* only = (u32*)vp_ws_take(ctx, (size_t)n * 4);
-            if (!only) return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
-            VP_HIP(ctx, hipMemsetAsync(fg_flags, 0, (size_t)Gf.nw32 * 4 * n, s));
-            hipLaunchKernelGGL(k_ct_roots_from_labels, dim3((unsigned)((known->max_labels - 1 + 3) / 4), (unsigned)n), dim3(256), 0, s, Gf, known->labels,
-                               known->stats, known->nlabels, known->max_labels, fg_flags, only);
-            rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags, only);
+            if (!only) rc = vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
+            if (rc == VP_OK) {
+                const hipError_t em = hipMemsetAsync(fg_flags, 0, (size_t)Gf.nw32 * 4 * n, s);
+                if (em != hipSuccess) rc = vp_fail(ctx, VP_ERR_HIP, "hipMemsetAsync (root bitmap)", em);
+            }
+            if (rc == VP_OK) {
+                hipLaunchKernelGGL(k_ct_roots_from_labels, dim3((unsigned)((known->max_labels - 1 + 3) / 4), (unsigned)n), dim3(256), 0, s, Gf, known->labels,
+                                   known->stats, known->nlabels, known->max_labels, fg_flags, only);
+                rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags, only);
+            }
         } else if (rc == VP_OK) {
             rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
         }

@@ -19,7 +19,9 @@
 
 namespace {
 constexpr int kSlots = 4;
-constexpr size_t kFrameBytes = 360;          // sizeof(Frame) of include/camera_message_framework_c.h (asserted by the binding)
+constexpr size_t kFrameBytes = 360;          // sizeof(Frame) of include/camera_message_framework_c.h; the two offsets below likewise: asserted
+constexpr size_t kFrameUidOff = 40;          // at compile time in csrc/cmf.cpp and by the binding before it starts a feeder
+constexpr size_t kFrameTotalOff = 56;        // (Frame: width, height, depth, type_size (4 x 8), acquisition_time @32, uid @40, data @48, total_size @56)
 typedef int (*fn_wait_t)(void*, uint64_t, uint32_t);
 typedef int (*fn_peek_t)(void*, void*, const void**, uint64_t*);
 typedef int (*fn_validate_t)(void*, uint64_t, uint64_t);
@@ -63,7 +65,12 @@ static void feeder_loop(vp_feeder* f)
     (void)hipSetDevice(f->device);
     uint64_t have = 0;
     while (!f->stop.load(std::memory_order_acquire)) {
-        if (f->wait(f->block, have, 2000) != 1) continue;
+        const auto t_wait = std::chrono::steady_clock::now();
+        if (f->wait(f->block, have, 2000) != 1) {
+            // a wait that comes back empty-handed well before its bound could not wait (the block's mutex is unusable): do not spin
+            if (std::chrono::steady_clock::now() - t_wait < std::chrono::microseconds(500)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            continue;
+        }
         const void* payload = nullptr;
         uint64_t ticket = 0;
         const int rc = f->peek(f->block, f->frame, &payload, &ticket);
@@ -72,8 +79,8 @@ static void feeder_loop(vp_feeder* f)
         unsigned char meta[kFrameBytes];
         memcpy(meta, f->frame, kFrameBytes);
         uint64_t uid, total;
-        memcpy(&uid, meta + 40, 8);           // Frame: width, height, depth, type_size (4 x 8), acquisition_time @32, uid @40, data @48, total_size @56
-        memcpy(&total, meta + 56, 8);
+        memcpy(&uid, meta + kFrameUidOff, 8);
+        memcpy(&total, meta + kFrameTotalOff, 8);
         have = uid;
         if (total == 0 || total > f->entry_bytes) continue;
         int pick = -1;
@@ -86,7 +93,15 @@ static void feeder_loop(vp_feeder* f)
                     if (f->slots[i].state == 1 && i != f->newest) { pick = i; break; }
             if (pick >= 0) f->slots[pick].state = 3;   // being filled
         }
-        if (pick < 0) { std::this_thread::sleep_for(std::chrono::microseconds(100)); have = uid - 1; continue; }   // the consumer holds them all
+        if (pick < 0) {
+            // The consumer holds every buffer (the binding keeps that from happening: beyond two held buffers it hands out private
+            // copies).  Wait a little and look at the SAME frame again: the peek answers "nothing new" while the Frame still carries
+            // this uid, so the Frame is put back to the uid before it as well.
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+            have = uid - 1;
+            memcpy((unsigned char*)f->frame + kFrameUidOff, &have, 8);
+            continue;
+        }
         Slot& s = f->slots[pick];
         bool ok = true;
         if (s.wait_release) { ok = hipStreamWaitEvent(f->stream, s.released, 0) == hipSuccess; s.wait_release = false; }
@@ -162,6 +177,13 @@ int vp_feeder_release(vp_feeder* f, vp_ctx* consumer, void* dev)
         Slot& s = f->slots[i];
         if (s.dev != dev || s.state != 2) continue;
         if (consumer && hipEventRecord(s.released, consumer->stream) == hipSuccess) s.wait_release = true;
+        else {
+            // no stream to order the next copy behind (context gone, or the record failed): whatever still reads the buffer has to
+            // have finished before the buffer is written again - wait for the device here, once, instead of racing
+            (void)hipSetDevice(f->device);
+            if (hipDeviceSynchronize() != hipSuccess) snprintf(f->err, sizeof f->err, "feeder: could not order a released buffer behind its readers");
+            (void)hipGetLastError();
+        }
         s.state = 0;
         return VP_OK;
     }

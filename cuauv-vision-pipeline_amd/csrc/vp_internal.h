@@ -44,6 +44,11 @@ struct vp_ctx {
     hipStream_t fb_stream;        // side stream of the labelling: the one-level kernels for crowded frames run here, beside the label write
     hipEvent_t ev_fb_fork, ev_fb_join;
     hipEvent_t ev_upload;         // recorded after an enqueued host-to-device copy (vp_memcpy_h2d_async / vp_wait_uploads)
+    hipStream_t post_stream;      // posts by DMA (vp_post.hip): device image -> ring slot copies run here, beside the context's stream; made on first use
+    hipEvent_t post_fork;         // "the image as it is now" on the context's stream
+    hipEvent_t post_free[32];     // end-of-copy events handed back by vp_post_free
+    int post_nfree;
+    int post_lock;                // spin lock of the three fields above (a context is zero-filled at creation: no constructors in here)
     const u32* cb_folds_dev;      // colour balance: device counter of tiles whose running mean had to be folded (last call); null or cb_folds_own
     u32* cb_folds_own;            // context-owned device word the counter is copied to (the workspace it is made in is carved anew per call)
     int ccl_levels;               // 2: two-level labelling with the one-level kernels as fallback (default); 1: one-level only
@@ -70,6 +75,8 @@ struct vp_prof_scope {
         if (rec >= 0) (void)hipEventRecord(c->prof.ev[2 * rec + 1], c->stream);
     }
 };
+
+void vp_post_teardown(vp_ctx* ctx);                        // vp_post.hip: joins and frees the post stream (vp_destroy)
 
 // ---- workspace ---------------------------------------------------------------------------
 int vp_ws_reserve(vp_ctx* ctx, size_t bytes);               // may reallocate (synchronises)

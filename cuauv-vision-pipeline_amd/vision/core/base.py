@@ -9,7 +9,9 @@ was deleted) - SURVEY.md section 3.1 / 8b lists the behaviours with their lines.
   * a frame does not pass through host memory on its way to a module: `BlockAccessor.read_frame_device` moves it from its ring
     slot into HBM with one DMA and hands out device images (`vision.devmat.DeviceMat`, array-likes that materialise on the host
     only if Python touches them).  On a box without a device the frames are private host arrays, as in the reference;
-  * the loop body is split into `_deliver`, `_fire_handlers` and `_flush_posts`.
+  * the loop body is split into `_deliver`, `_fire_handlers` and `_flush_posts`;
+  * posts of device images go into their block's ring slot by DMA and are committed when the copy has arrived
+    (`vision.core.posts`): no host pass over the pixels of a post.
 
 Differences a module can observe: logging falls back to stdout when `auvlog` is absent; every VideoSourceMetadata owns its latency
 window (the reference shares one deque between all instances through a dataclass default); `UMat` inputs to post() are unwrapped by
@@ -30,8 +32,7 @@ import numpy as np
 from vision.core.bindings.camera_message_framework import BLOCK_STUB, BlockAccessor, ReadStatus
 from vision.core.tuners import BoolTuner, DoubleTuner, IntTuner, TunerBase
 from vision.core.frames import copy_frame
-from vision.devmat import DeviceMat
-from vision.utils.helpers import as_mat
+from vision.core.posts import VALID_COLOR_SPACES, PostQueue
 
 try:  # the CUAUV logging daemon client, when the monorepo is around
     from auvlog.client import log as auvlog  # type: ignore
@@ -57,7 +58,6 @@ except Exception:  # pragma: no cover - exercised wherever auvlog is absent
 _PLANE_TYPES = {1: ((("u8", np.uint8), ("i8", np.int8)), np.uint8),
                 4: ((("u32", np.uint32), ("i32", np.int32), ("f32", np.float32)), np.float32),
                 8: ((("u64", np.uint64), ("i64", np.int64), ("f64", np.float64)), np.float64)}
-VALID_COLOR_SPACES = ("BGR", "RGB", "HSV", "LAB", "HLS", "YCRCB", "LUV", "GRAY")
 _SOURCE_SPEC = re.compile(r"^\s*(?P<name>[^\[\]:]*?)\s*(?:\[(?P<aliases>[^\]]*)\])?\s*(?::(?P<types>.*))?$")
 
 
@@ -158,12 +158,16 @@ class ModuleManager:
             raise RuntimeError("attempted to access ModuleManager while not in a context manager")
         return self._open
 
-    def post(self, name: str, idx: int, acquisition_time: int, data: np.ndarray):
-        stack = self._stack()
+    def post_block(self, name: str, idx: int, nbytes: int) -> BlockAccessor:
+        """The block of post `name` (`<post name>#<colour space>`), created on first use with the size of that first image."""
         block = self._posts.get(name)
         if block is None:
-            block = self._posts[name] = stack.enter_context(BlockAccessor(f"{self._module_name}_post%{idx}%{name}", data.nbytes))
-        block.write_frame(acquisition_time, data)
+            block = self._posts[name] = self._stack().enter_context(BlockAccessor(f"{self._module_name}_post%{idx}%{name}", nbytes))
+        return block
+
+    def post(self, name: str, idx: int, acquisition_time: int, data: np.ndarray):
+        self._stack()
+        self.post_block(name, idx, data.nbytes).write_frame(acquisition_time, data)
 
     def read_messages(self) -> List[VideoMessage]:
         self._stack()
@@ -396,7 +400,8 @@ class ModuleBase:
         self._chatty = bool(args.verbose)
         self._performance_enabled: bool = args.enable_performance
         self._module_manager = ModuleManager(self._name, chosen, tuners)
-        self._post_queue: "OrderedDict[str, Tuple[np.ndarray, str]]" = OrderedDict()
+        self._posts = PostQueue(self._module_manager.post_block, self._module_manager.post, enabled=not self._performance_enabled)
+        self._post_queue = self._posts.queue               # name -> (what is queued, colour space); emptied by every flush
         self._retry = True                                # __call__ keeps (re-)entering the manager while this is set
         self._directions: Dict[str, VideoSourceMetadata] = {}     # per direction and per named plane
         for s in chosen:
@@ -502,10 +507,10 @@ class ModuleBase:
             elif fresh.intersection(aliases):
                 handler(*(cache[a] for a in aliases))
 
-    def _flush_posts(self):
-        for idx, (name, (data, color_space)) in enumerate(self._post_queue.items()):
-            self._module_manager.post(f"{name}#{color_space}", idx, _now_ms(), data)
-        self._post_queue.clear()
+    def _flush_posts(self, wait: bool = False):
+        """Publishes the iteration's posts.  Device images are already on their way into their blocks' slots (post() queued the
+        copies); those that have arrived are committed, the others by the next call - `wait` blocks until every one is out."""
+        self._posts.flush(wait)
 
     def _loop(self, quit_flag: threading.Event, say):
         cache: Dict[str, Any] = {}
@@ -513,39 +518,42 @@ class ModuleBase:
         covered = {alias for _, aliases in handlers for alias in aliases}
         told: set = set()
         period = 1.0 / self._fps
-        while not quit_flag.is_set():
-            began = time.monotonic()
-            try:
-                messages = self._module_manager.read_messages()
-            except RuntimeError as problem:               # a source went away: __call__ re-enters the manager
-                say(f"Error: {problem}", True)
-                self._retry = True
-                quit_flag.set()
-                break
-            fresh: set = set()
-            for message in messages:
-                if message.status == ReadStatus.SUCCESS:
-                    self._deliver(message, cache, fresh, covered)
-                elif message.status == ReadStatus.NO_NEW_FRAME and self._directions[message.source.name].mark_as_dead():
-                    say(f"{message.source.name} appears to be slow or dead!", self._chatty)
-            self._fire_handlers(handlers, cache, fresh, told, say)
-            self._flush_posts()
-            time.sleep(max(period - (time.monotonic() - began), 0))
+        try:
+            while not quit_flag.is_set():
+                began = time.monotonic()
+                try:
+                    messages = self._module_manager.read_messages()
+                except RuntimeError as problem:               # a source went away: __call__ re-enters the manager
+                    say(f"Error: {problem}", True)
+                    self._retry = True
+                    quit_flag.set()
+                    break
+                fresh: set = set()
+                for message in messages:
+                    if message.status == ReadStatus.SUCCESS:
+                        self._deliver(message, cache, fresh, covered)
+                    elif message.status == ReadStatus.NO_NEW_FRAME and self._directions[message.source.name].mark_as_dead():
+                        say(f"{message.source.name} appears to be slow or dead!", self._chatty)
+                self._fire_handlers(handlers, cache, fresh, told, say)
+                self._flush_posts()
+                slack = period - (time.monotonic() - began)
+                if slack > 0:
+                    # the loop is about to idle: posts whose copies are still crossing are published now rather than one period later
+                    # (a saturated loop leaves them to the next iteration, where they overlap with its work)
+                    if self._posts.pending():
+                        self._flush_posts(wait=True)
+                        slack = period - (time.monotonic() - began)
+                    time.sleep(max(slack, 0))
+        finally:
+            self._posts.drain()                               # no copy may target a block once the manager closes it
 
     # -- services used by module code -------------------------------------------------------------------------------------------
     def post(self, name: str, image, color_space: str = "BGR"):
-        """Queues a uint8 copy of `image` for the GUI (published after the handlers of this iteration); no-op under --enable-performance."""
+        """Queues `image` as it is now for the GUI (published after the handlers of this iteration); no-op under --enable-performance.
+        A host array is copied (uint8); a device image is copied by the GPU straight into its block (vision.core.posts)."""
         if self._performance_enabled:
             return
-        if "%" in name:
-            raise RuntimeError("Cannot have % in name")
-        image = as_mat(image)
-        if isinstance(image, DeviceMat) and image.dtype == np.uint8:
-            image = image.host_copy()                    # one download into an array of its own; the image stays usable on the device
-        else:
-            image = np.array(image, np.uint8, copy=True, order="C", ndmin=1)
-        color_space = color_space.upper()
-        self._post_queue[name] = (image, color_space if color_space in VALID_COLOR_SPACES else "BGR")
+        self._posts.post(name, image, color_space)
 
     def get_latency(self) -> int:
         return self._directions[self._current_direction].get_latency()

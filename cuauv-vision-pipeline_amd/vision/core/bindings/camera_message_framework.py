@@ -72,13 +72,23 @@ def _load():
     lib.cmf_block_mapping.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.cmf_wait_for_frame.restype = C.c_int
     lib.cmf_wait_for_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+    lib.cmf_write_begin.restype = C.c_int
+    lib.cmf_write_begin.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.cmf_write_commit.restype = C.c_int
+    lib.cmf_write_commit.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(_FramePlaneWrite), C.c_size_t]
+    lib.cmf_write_abort.restype = C.c_int
+    lib.cmf_write_abort.argtypes = [C.c_void_p, C.c_uint64]
     return lib
 
 
 _dllib = _load()
+# libvp's feeder copies a Frame as 360 bytes and reads uid / total_size at fixed offsets (csrc/vp_feed.hip; csrc/cmf.cpp asserts the same
+# at compile time): a layout change must fail here, not overflow a buffer there
+assert C.sizeof(_Frame) == 360 and _Frame.uid.offset == 40 and _Frame.total_size.offset == 56, "Frame layout differs from what libvp's feeder expects"
 _PRIVATE_READS = os.environ.get("VP_PRIVATE_READS", "1") != "0"
 _DEVICE_FRAMES = os.environ.get("VP_DEVICE_FRAMES", "1") != "0"
 _FEEDER = os.environ.get("VP_FEEDER", "1") != "0"          # device frames fetched ahead by a thread of libvp's own (vp_feeder_*)
+_FEEDER_HELD_MAX = 2        # frames a module may hold in the feeder's own buffers; frames beyond that are handed out as private copies
 _registered = {}            # mapping base address -> [reference count, bytes]: block mappings page-locked for the copy engine
 _registered_lock = threading.Lock()
 _device_frames_broken = False   # no device / hipHostRegister refused shared-memory mappings: decided once per process
@@ -109,6 +119,7 @@ class _Feeder:
                                                 fn("cmf_peek_validate"), fn("create_frame"), fn("delete_frame"))
         if not self.handle:
             raise RuntimeError("vp_feeder_start failed")
+        self.out = 0                    # device buffers of this feeder that images handed to the module still refer to
 
     def take(self):
         """-> (status 0 / 1 / 2, _Frame or None, device pointer or None)"""
@@ -144,10 +155,12 @@ class _SlotBuf:
 
     def __init__(self, feeder, ctx, ptr):
         self.ptr, self._feeder, self._ctx = ptr, feeder, ctx
+        feeder.out += 1
 
     def __del__(self):
         try:
             from vision import _vp
+            self._feeder.out -= 1
             if self._feeder.handle:
                 _vp.lib().vp_feeder_release(self._feeder.handle, self._ctx.handle if self._ctx is not None and self._ctx.handle else None, self.ptr)
         except Exception:
@@ -291,6 +304,56 @@ class BlockAccessor:
             raise RuntimeError(f"write_frame on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
         return WriteStatus(rc)
 
+    # -- writing, payload moved by the copy engine ---------------------------------------------------
+    def begin_device_write(self, ctx, nbytes: int):
+        """First half of a write whose bytes a DMA puts into the slot (cmf_write_begin): -> (address of the slot's bytes, ticket), or
+        None when this block cannot take device copies (its mapping could not be page-locked): the caller posts a host array then.
+        Raises what write_frame raises for a frame larger than the block."""
+        if not self._inside_ctx_manager:
+            raise RuntimeError(f"Attempted to access block while not in a context manager: {_caller_line()}")
+        if not self._ensure_registered(ctx):
+            return None
+        slot, ticket = C.c_void_p(), C.c_uint64()
+        rc = _dllib.cmf_write_begin(self._block_ptr, int(nbytes), C.byref(slot), C.byref(ticket))
+        if rc < 0:
+            raise RuntimeError(f"write_frame on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
+        if rc != 0:
+            return None                                         # deleted: the host path reports it the way write_frame does
+        return slot.value, ticket.value
+
+    def commit_device_write(self, ticket: int, acquisition_time_ms: int, shape, itemsize: int = 1):
+        """Second half (cmf_write_commit): one plane of `shape` (1-3 dimensions, as write_frame takes an ndarray) is in the slot."""
+        shape = tuple(int(v) for v in shape)
+        if not 1 <= len(shape) <= 3:
+            raise RuntimeError(f"np.ndarray at index 0 has {len(shape)} dimensions, expected between 1-3")
+        desc = (_FramePlaneWrite * 1)()
+        desc[0].height, desc[0].width, desc[0].depth = shape[0], shape[1] if len(shape) > 1 else 1, shape[2] if len(shape) > 2 else 1
+        desc[0].type_size, desc[0].data, desc[0].name = int(itemsize), None, b""
+        rc = _dllib.cmf_write_commit(self._block_ptr, int(ticket), int(acquisition_time_ms), desc, 1)
+        if rc < 0:
+            raise RuntimeError(f"write_frame on '{self._direction}' failed: {_dllib.cmf_last_error().decode()}")
+        return WriteStatus(rc)
+
+    def abort_device_write(self, ticket: int):
+        if self._block_ptr:
+            _dllib.cmf_write_abort(self._block_ptr, int(ticket))
+
+    def _ensure_registered(self, ctx) -> bool:
+        """The block's mapping page-locked for the copy engine (once; undone by __exit__)."""
+        global _device_frames_broken
+        if self._dev_state is None:
+            if _device_frames_broken:
+                return False
+            base, nbytes = C.c_void_p(), C.c_uint64()
+            ok = _dllib.cmf_block_mapping(self._block_ptr, C.byref(base), C.byref(nbytes)) == 0 and \
+                _register_mapping(ctx, base.value, int(nbytes.value))
+            if not ok:
+                self._dev_state = False
+                _device_frames_broken = True                   # the runtime refuses shared-memory mappings: do not ask again
+                return False
+            self._dev_state, self._dev_base = True, base.value
+        return bool(self._dev_state)
+
     # -- reading ---------------------------------------------------------------------------------
     def read_frame(self):
         """-> (ReadStatus, ndarray | tuple of ndarrays | None, acquisition time).  Arrays are (h, w, d) views of the
@@ -391,16 +454,7 @@ class BlockAccessor:
         except Exception:
             _device_frames_broken = True                       # no device in this process: the copying paths serve
             return None
-        if self._dev_state is None:
-            base, nbytes = C.c_void_p(), C.c_uint64()
-            ok = _dllib.cmf_block_mapping(self._block_ptr, C.byref(base), C.byref(nbytes)) == 0 and \
-                _register_mapping(ctx, base.value, int(nbytes.value))
-            if not ok:
-                self._dev_state = False
-                _device_frames_broken = True                   # the runtime refuses shared-memory mappings: do not ask again
-                return None
-            self._dev_state, self._dev_base = True, base.value
-        return ctx
+        return ctx if self._ensure_registered(ctx) else None
 
     def read_frame_device(self):
         """read_frame_private whose arrays are device images (vision.devmat.DeviceMat: array-likes that reach host memory only when
@@ -428,7 +482,17 @@ class BlockAccessor:
             if rc != 0:
                 return ReadStatus.NO_NEW_FRAME, self._frame_data, self._acquisition_time, True
             self.torn_reads = self._feeder.counts()[1]
-            return self._planes_on_device(ctx, fr, _SlotBuf(self._feeder, ctx, dev))
+            held = _SlotBuf(self._feeder, ctx, dev)
+            if self._feeder.out > _FEEDER_HELD_MAX:
+                # The module keeps earlier frames (a history deque, prev_frame: in the reference every frame is a private copy it may
+                # keep for good, core/base.py:765-768).  The feeder has four buffers and needs two to keep fetching, so from the third
+                # one out on the frame moves into an allocation of the module's own (device to device, on the context's stream) and the
+                # feeder's buffer goes straight back: the stream of frames never stalls on what the module holds.
+                own = _DevBuf(ctx, int(fr.total_size))
+                _vp.check(_vp.lib().vp_memcpy_d2d_async(ctx.handle, own.ptr, dev, int(fr.total_size)), ctx.handle)
+                del held                                        # released behind the copy (an event on the context's stream)
+                return self._planes_on_device(ctx, fr, own)
+            return self._planes_on_device(ctx, fr, held)
         lib = _vp.lib()
         payload, ticket = C.c_void_p(), C.c_uint64()
         while True:

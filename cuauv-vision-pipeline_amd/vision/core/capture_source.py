@@ -74,21 +74,25 @@ class CaptureSource:
         self._quit_flag = threading.Event()
 
     # -- threads ------------------------------------------------------------------------------------------------------------
-    def _spawn(self, label: str, run: Callable[[], None]):
-        """A worker that stops the whole source when it ends, however it ends."""
+    def _spawn(self, label: str, run: Callable[[], None], stop_on_return: bool):
+        """A worker that stops the whole source when it raises - and, for a capture UDL (`stop_on_return`), also when it simply
+        ends: an exhausted capture stops the source, a logical UDL that returns (one-shot hardware set-up) does not
+        (core/capture_source.py:113-127 sets the flag in its `except` only)."""
         def guarded():
             try:
                 run()
             except Exception:
                 self._say(f"Caught exception in {label} printing stack trace and unwinding ...")
                 traceback.print_exc()
-            finally:
                 self._quit_flag.set()
+            else:
+                if stop_on_return:
+                    self._quit_flag.set()
         self._workers.append(threading.Thread(target=guarded, name=f"capture-{label}"))
 
     def register_logical_udl(self, udl: Callable[[FpsLimiter, Tuple[Any, ...]], None], args: Tuple[Any, ...] = ()):
         """A UDL that publishes nothing itself (it steers hardware, watches a flag ...)."""
-        self._spawn("logical udl", lambda: udl(FpsLimiter("", self._quit_flag), args))
+        self._spawn("logical udl", lambda: udl(FpsLimiter("", self._quit_flag), args), stop_on_return=False)
 
     def register_capture_udl(self, name: str, udl, args: Tuple[Any, ...] = ()):
         def pump():
@@ -101,7 +105,7 @@ class CaptureSource:
                 self._send(*item)
             told_to = self._quit_flag.is_set()
             self._say(f"capture udl '{name}' stopped as a result of another stop signal" if told_to else f"capture udl '{name}' exhausted", True)
-        self._spawn(name, pump)
+        self._spawn(name, pump, stop_on_return=True)
 
     def run_event_loop(self):
         if threading.current_thread() is threading.main_thread():

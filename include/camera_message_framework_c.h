@@ -107,6 +107,23 @@ int cmf_block_mapping(Block* block, void** base, uint64_t* bytes);
  * (lib/camera_message_framework.cpp:395-410), with a caller-chosen bound.  For a feeder thread that must not poll. */
 int cmf_wait_for_frame(Block* block, uint64_t have_uid, uint32_t timeout_us);
 
+/* not in the reference: a write whose payload is moved by the caller - a copy engine that puts a device image straight into the ring
+ * slot, instead of a download into a host array followed by write_frame's memcpy (lib/camera_message_framework.cpp:306-374 does both
+ * halves in one call; core/base.py:846-876 / :832-839 queue and flush a module's posts through it).  The slot protocol is the
+ * reference's, cut in two at the payload copy:
+ *   cmf_write_begin(block, entry_bytes, &payload, &ticket): picks the slot after the newest one ((uid + 1) % 3), bumps its first
+ *     sequence number (a reader still copying the slot's old frame will retry) and returns the address of the slot's bytes inside the
+ *     block's mapping.  Readers are NOT sent to this slot yet: uid has not moved, read_frame keeps serving the last complete frame.
+ *     SUCCESS / FRAMEWORK_DELETED / negative (too large, a deferred write already open: one writer per block, one write at a time).
+ *   cmf_write_commit(block, ticket, acquisition_time, planes, plane_count): call once the bytes are in the slot.  Writes the metadata
+ *     (planes[i].data is ignored, sizes and names are used exactly as write_frame_planes uses them), the second sequence number, bumps
+ *     uid and wakes waiting readers - the second half of write_frame_planes.
+ *   cmf_write_abort(block, ticket): the copy failed or was given up: closes the slot without publishing it.
+ * write_frame / write_frame_planes on a block with a deferred write open fail (negative status). */
+int cmf_write_begin(Block* block, uint64_t entry_bytes, void** payload, uint64_t* ticket);
+int cmf_write_commit(Block* block, uint64_t ticket, uint64_t acquisition_time, const FramePlaneWrite* planes, size_t plane_count);
+int cmf_write_abort(Block* block, uint64_t ticket);
+
 #ifdef __cplusplus
 }
 #endif

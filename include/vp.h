@@ -365,6 +365,26 @@ int vp_feeder_counts(vp_feeder* f, unsigned long long* fetched, unsigned long lo
 int vp_feeder_stop(vp_feeder* f);
 int vp_feeder_destroy(vp_feeder* f);
 
+/* ---- posts by DMA: a device image into the ring slot of a camera_message_framework block, no host pass over the pixels ---------
+ * Replaces, for ModuleBase.post() of an image that lives in HBM, the download into a fresh array (core/base.py:846-876 `np.array(copy)`)
+ * plus write_frame's memcpy into the slot (lib/camera_message_framework.cpp:306-374) at the flush (core/base.py:832-839).  The caller
+ * opens the slot (cmf_write_begin, include/camera_message_framework_c.h), then:
+ *   vp_post_d2h(ctx, slot_bytes, image_dev, bytes, &done): the image AS IT IS NOW (everything queued so far on the context's stream) is
+ *     copied into `slot_bytes` (inside a mapping page-locked with vp_host_register) on the context's post stream; *done is an opaque
+ *     handle on the end of that copy.  Returns at once.
+ *   vp_post_done(ctx, done) -> 1 the bytes are in the slot (commit the write), 0 not yet, negative on a device error.
+ *   vp_post_wait(ctx, done): blocks the calling thread until they are.
+ *   vp_post_fence(ctx, done): work queued on the context's stream from now on starts after the copy - call before anything OVERWRITES
+ *     the image (readers may run beside the copy).
+ *   vp_post_free(ctx, done): hands the handle back (ctx may be NULL: the context is gone). */
+int vp_post_d2h(vp_ctx* ctx, void* slot_bytes_host, const void* image_dev, size_t bytes, void** done);
+int vp_post_done(vp_ctx* ctx, void* done);
+int vp_post_wait(vp_ctx* ctx, void* done);
+int vp_post_fence(vp_ctx* ctx, void* done);
+int vp_post_free(vp_ctx* ctx, void* done);
+
+/* device -> device on the context's stream (ordered with everything else the context runs); returns at once */
+int vp_memcpy_d2d_async(vp_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 int vp_memcpy_h2d(vp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
 /* The same copy enqueued on the context's stream: src_host must stay unchanged until vp_wait_uploads (or vp_synchronize) returns.
  * vp_wait_uploads waits for the copies only, not for kernels enqueued behind them: an operator enqueues the copy of its input,

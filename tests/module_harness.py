@@ -82,19 +82,42 @@ def buoy_tuners(lo=150, hi=255):
 
 
 class PlainSelf:
-    """What a module body touches of ModuleBase when it is called outside the runtime (body rates: bench.py extras)."""
+    """What a module body touches of ModuleBase when it is called outside the runtime (body rates: bench.py extras).  With posts on,
+    post() and flush() are the runtime's own (`vision.core.posts.PostQueue` over real post blocks under /dev/shm, named as
+    ModuleManager names them): the body rate with posts includes everything a module pays for them."""
 
-    def __init__(self, shape_hw, posts, tuners=None):
+    def __init__(self, shape_hw, posts, tuners=None, tag="Body"):
+        import contextlib
+        from vision.core.posts import PostQueue
         self.tuners = dict(tuners or {"thresh_min": 150, "thresh_max": 255})
-        self.posts, self.posted, self.shape = posts, {}, shape_hw
+        self.posts, self.shape = posts, shape_hw
+        self._stem = f"module_{tag}{os.getpid()}-on-x"
+        self._stack, self._blocks = contextlib.ExitStack(), {}
+        self.queue = PostQueue(self._open_block, self._write_host, enabled=bool(posts))
+
+    def _open_block(self, key, idx, nbytes):
+        from vision.core.bindings.camera_message_framework import BlockAccessor
+        block = self._blocks.get(key)
+        if block is None:
+            block = self._blocks[key] = self._stack.enter_context(BlockAccessor(f"{self._stem}_post%{idx}%{key}", nbytes))
+        return block
+
+    def _write_host(self, key, idx, stamp, data):
+        self._open_block(key, idx, data.nbytes).write_frame(stamp, data)
 
     def post(self, name, image, color_space="BGR"):
-        if not self.posts:                           # --enable-performance (core/base.py:857)
-            return
-        from vision.devmat import DeviceMat
-        from vision.utils.helpers import as_mat
-        image = as_mat(image)
-        self.posted[name] = image.host_copy() if isinstance(image, DeviceMat) else np.array(image, np.uint8, copy=True, order="C", ndmin=1)
+        self.queue.post(name, image, color_space)           # a no-op with posts off (--enable-performance, core/base.py:857)
+
+    def flush(self, wait=False):
+        self.queue.flush(wait)
+
+    def block_names(self):
+        return {key: b.direction for key, b in self._blocks.items()}
+
+    def close(self):
+        self.queue.drain()
+        self._stack.close()
+        self._blocks.clear()
 
     def normalize(self, c):
         return (c[0] - self.shape[0] / 2) / self.shape[1], (c[1] - self.shape[1] / 2) / self.shape[1]
@@ -365,22 +388,34 @@ def body_rates(which="buoy", w=1920, h=1080, calls=200):
     out = {}
     for kind in ("host", "device"):
         for posts in (False, True):
-            me = PlainSelf((h, w), posts)
+            me = PlainSelf((h, w), posts, tag="Rate" + which.capitalize())
 
             def call(img):
-                return buoy_body(me, img, normal) if which == "buoy" else bins_body(me, "forward", img)
+                # the body, then what the loop does after the handlers of an iteration (core/base.py:832-839): publish the posts
+                out = buoy_body(me, img, normal) if which == "buoy" else bins_body(me, "forward", img)
+                me.flush()
+                return out
 
             def fresh(i):
                 return copy_frame(base[i % 4]) if kind == "host" else DeviceMat.from_host(ctx, base[i % 4])
-            for i in range(3):
-                call(fresh(i))
-            t_body = 0.0
-            for i in range(calls):
-                img = fresh(i)
+            try:
+                for i in range(3):
+                    call(fresh(i))
+                t_body = 0.0
+                for i in range(calls):
+                    img = fresh(i)
+                    t1 = time.perf_counter()
+                    call(img)
+                    t_body += time.perf_counter() - t1
                 t1 = time.perf_counter()
-                call(img)
+                me.flush(wait=True)                         # the last call's posts: the tail belongs to the measurement
                 t_body += time.perf_counter() - t1
+                counts = (me.queue.dma_posts, me.queue.host_posts)
+            finally:
+                me.close()
             out[f"{kind}_frame_posts_{'on' if posts else 'off'}"] = {"calls_per_s": round(calls / t_body, 1), "ms_per_call": round(1e3 * t_body / calls, 4)}
+            if posts:
+                out[f"{kind}_frame_posts_on"]["posts_by_dma"], out[f"{kind}_frame_posts_on"]["posts_by_host_copy"] = counts
     return out
 
 

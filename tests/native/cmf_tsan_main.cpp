@@ -1,5 +1,5 @@
 // ThreadSanitizer harness for the shared-memory seqlock (csrc/cmf.cpp), built with -fsanitize=thread by tests/test_cmf.py:
-// a writer thread and three reader threads (one polling, one blocking on the condition variable, one that peeks and copies the payload itself) work on ONE mapping of a block, so
+// a writer thread (every fourth frame written in the deferred form: slot opened, payload moved by another thread, committed or given up) and three reader threads (one polling, one blocking on the condition variable, one that peeks and copies the payload itself) work on ONE mapping of a block, so
 // the sanitizer sees every access of both sides.  Readers check what they accept: payload all one value that matches the frame's
 // acquisition time, plane metadata intact, time never going backwards.  Exit code 0 = no torn frame accepted; the sanitizer adds
 // its own verdict (TSAN_OPTIONS exitcode).  SURVEY section 5 asks for this build of the replacement; the reference has no such test.
@@ -14,6 +14,7 @@
 
 static std::atomic<int> g_bad{0};
 static std::atomic<bool> g_done{false};
+static long g_deferred = 0;
 
 static void reader(Block* b, bool blocking, long* accepted)
 {
@@ -81,7 +82,26 @@ int main(int argc, char** argv)
         memset(p0.data(), t % 251, p0.size());
         memset(p1.data(), t % 251, p1.size());
         FramePlaneWrite planes[2] = {{64, 64, 1, 1, p0.data(), "first"}, {64, 64, 1, 1, p1.data(), "second"}};
-        if (write_frame_planes(w, (uint64_t)t, planes, 2) != SUCCESS) { fprintf(stderr, "write failed\n"); g_bad.fetch_add(1); break; }
+        if (t % 4 == 0) {
+            // The deferred form (posts by DMA): the slot is opened, ANOTHER thread - the stand-in for the copy engine - fills it while
+            // the readers keep running, the writer commits once that thread is done.  Every 64th such write is given up instead
+            // (cmf_write_abort): the next write must reuse the slot without a reader ever accepting the abandoned bytes.
+            void* slot = nullptr;
+            uint64_t ticket = 0;
+            if (cmf_write_begin(w, 2 * 4096, &slot, &ticket) != SUCCESS) { fprintf(stderr, "begin failed\n"); g_bad.fetch_add(1); break; }
+            if (write_frame_planes(w, (uint64_t)t, planes, 2) >= 0) { fprintf(stderr, "a plain write went through beside an open deferred write\n"); g_bad.fetch_add(1); }
+            const bool give_up = t % 256 == 0;
+            std::thread engine([slot, t, give_up] {
+                unsigned char* dst = static_cast<unsigned char*>(slot);
+                const unsigned char v = give_up ? (unsigned char)((t + 7) % 251) : (unsigned char)(t % 251);   // abandoned bytes are WRONG bytes
+                for (size_t i = 0; i < 2 * 4096; i++) __atomic_store_n(dst + i, v, __ATOMIC_RELAXED);
+            });
+            engine.join();
+            FramePlaneWrite meta[2] = {{64, 64, 1, 1, nullptr, "first"}, {64, 64, 1, 1, nullptr, "second"}};
+            const int rc = give_up ? cmf_write_abort(w, ticket) : cmf_write_commit(w, ticket, (uint64_t)t, meta, 2);
+            if (rc != SUCCESS) { fprintf(stderr, "commit / abort failed: %s\n", cmf_last_error()); g_bad.fetch_add(1); break; }
+            g_deferred++;
+        } else if (write_frame_planes(w, (uint64_t)t, planes, 2) != SUCCESS) { fprintf(stderr, "write failed\n"); g_bad.fetch_add(1); break; }
         if ((t & 1023) == 0) usleep(200);     // let the blocking reader through now and then
     }
     g_done.store(true, std::memory_order_release);
@@ -91,6 +111,7 @@ int main(int argc, char** argv)
     t3.join();
     delete_block(r);
     delete_block(w);
+    printf("deferred writes (begin / engine thread / commit or abort) %ld; ", g_deferred);
     printf("frames written %d, accepted by the polling reader %ld, by the blocking reader %ld, by the peek reader %ld (%ld copies discarded as lapped), bad %d\n",
            n, a1, a2, a3, torn3, g_bad.load());
     return (g_bad.load() == 0 && a1 + a2 > 0 && a3 > 0) ? 0 : 1;

@@ -306,3 +306,103 @@ def test_wait_for_frame():
             assert lib.cmf_wait_for_frame(None, 0, 10) < 0
     finally:
         w.__exit__(None, None, None)
+
+
+def _raw_header(direction):
+    """(uid, [(seq_begin, seq_end) per slot]) straight from the file: what a reference-built reader sees."""
+    with open(BLOCK_STUB + direction, "rb") as fh:
+        head = fh.read(1216)
+    uid = struct.unpack_from("<Q", head, 0)[0]
+    return uid, [struct.unpack_from("<QQ", head, 24 + 360 * i) for i in range(3)]
+
+
+def test_deferred_write_is_the_reference_protocol_cut_in_two():
+    """cmf_write_begin / cmf_write_commit (posts by DMA): between the halves the slot after the newest one has begin != end, uid has
+    not moved and readers are served the last complete frame; the commit leaves the file exactly as a plain write_frame would have
+    (lib/camera_message_framework.cpp:306-374: slot (uid + 1) % 3, both sequence words = old + 1, metadata, uid + 1); an abort
+    publishes nothing and the next write reuses the slot; plain writes are refused while a deferred one is open."""
+    d = _name("deferred")
+    a = np.arange(6 * 8 * 3, dtype=np.uint8).reshape(6, 8, 3)
+    b = (a[::-1] ^ 0x5A).copy()
+    with BlockAccessor(d, max_entry_size_bytes=a.nbytes) as w, BlockAccessor(d) as r:
+        lib = cmf._dllib
+        w.write_frame(11, a)
+        st, data, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 11 and np.array_equal(data, a)
+        uid0, seq0 = _raw_header(d)
+        assert uid0 == 1
+        slot, ticket = C.c_void_p(), C.c_uint64()
+        assert lib.cmf_write_begin(w._block_ptr, a.nbytes, C.byref(slot), C.byref(ticket)) == 0
+        uid1, seq1 = _raw_header(d)
+        idx = (uid0 + 1) % 3
+        assert uid1 == uid0 and seq1[idx] == (seq0[idx][0] + 1, seq0[idx][1]) and ticket.value == seq0[idx][0] + 1
+        assert [seq1[i] for i in range(3) if i != idx] == [seq0[i] for i in range(3) if i != idx]
+        base, nbytes = C.c_void_p(), C.c_uint64()
+        assert lib.cmf_block_mapping(w._block_ptr, C.byref(base), C.byref(nbytes)) == 0
+        assert slot.value == base.value + 1216 + idx * a.nbytes                       # the slot's bytes, inside the mapping
+        assert r.read_frame()[0] == ReadStatus.NO_NEW_FRAME                             # nothing new for readers yet
+        with BlockAccessor(d) as late:                                                  # a reader that arrives meanwhile gets the last complete frame
+            st, data, t = late.read_frame()
+            assert st == ReadStatus.SUCCESS and t == 11 and np.array_equal(data, a)
+        with pytest.raises(RuntimeError, match="deferred write"):
+            w.write_frame(12, a)                                                        # one write at a time
+        assert lib.cmf_write_begin(w._block_ptr, a.nbytes, C.byref(C.c_void_p()), C.byref(C.c_uint64())) < 0
+        C.memmove(slot.value, b.ctypes.data, b.nbytes)                                  # "the copy engine"
+        assert w.commit_device_write(ticket.value, 13, b.shape) == WriteStatus.SUCCESS
+        uid2, seq2 = _raw_header(d)
+        assert uid2 == uid0 + 1 and seq2[idx] == (ticket.value, ticket.value)
+        st, data, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 13 and data.shape == b.shape and np.array_equal(data, b)
+        fr = r._frame_ptr.contents
+        assert (fr.width, fr.height, fr.depth, fr.type_size, fr.plane_count, fr.total_size) == (8, 6, 3, 1, 1, b.nbytes)
+        # the same frame written the plain way into a second block: byte-identical slot metadata (everything but the time stamp's slot index)
+        d2 = _name("deferredref")
+        with BlockAccessor(d2, max_entry_size_bytes=a.nbytes) as w2:
+            w2.write_frame(11, a)
+            w2.write_frame(13, b)
+            with open(BLOCK_STUB + d, "rb") as f1, open(BLOCK_STUB + d2, "rb") as f2:
+                h1, h2 = f1.read(1104), f2.read(1104)
+            assert h1 == h2
+        # a commit with a stale ticket, a commit with nothing open
+        assert lib.cmf_write_commit(w._block_ptr, ticket.value, 0, None, 0) < 0
+        # abort: nothing is published, the next write reuses the slot and bumps its pair once more
+        assert lib.cmf_write_begin(w._block_ptr, a.nbytes, C.byref(slot), C.byref(ticket)) == 0
+        C.memmove(slot.value, a.ctypes.data, a.nbytes)
+        w.abort_device_write(ticket.value)
+        uid3, seq3 = _raw_header(d)
+        idx3 = (uid2 + 1) % 3
+        assert uid3 == uid2 and seq3[idx3] == (ticket.value, ticket.value)
+        assert r.read_frame()[0] == ReadStatus.NO_NEW_FRAME
+        w.write_frame(14, a)
+        uid4, seq4 = _raw_header(d)
+        assert uid4 == uid2 + 1 and seq4[idx3] == (ticket.value + 1, ticket.value + 1)
+        st, data, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 14 and np.array_equal(data, a)
+        # too large / zero-sized
+        assert lib.cmf_write_begin(w._block_ptr, a.nbytes + 1, C.byref(slot), C.byref(ticket)) < 0
+        assert lib.cmf_write_begin(w._block_ptr, 0, C.byref(slot), C.byref(ticket)) < 0
+
+
+def test_a_reader_overlapping_a_deferred_write_retries():
+    """Old-reader safety: a consumer that is still copying a slot's OLD frame when a deferred write opens that slot must not accept
+    its copy (the writer lapped the ring) - the first sequence word is bumped at cmf_write_begin, before the copy engine touches the
+    bytes, exactly as write_frame bumps it before its memcpy."""
+    d = _name("deferredlap")
+    img = np.full((4, 4, 3), 7, np.uint8)
+    with BlockAccessor(d, max_entry_size_bytes=img.nbytes) as w, BlockAccessor(d) as r:
+        lib = cmf._dllib
+        w.write_frame(1, img)
+        payload, ticket = C.c_void_p(), C.c_uint64()
+        assert lib.cmf_peek_frame(r._block_ptr, r._frame_ptr, C.byref(payload), C.byref(ticket)) == 0
+        uid = r._frame_ptr.contents.uid
+        w.write_frame(2, img)
+        w.write_frame(3, img)                                   # the ring is full: the next write reuses the slot the reader is copying
+        assert lib.cmf_peek_validate(r._block_ptr, uid, ticket.value) == 1
+        slot, t2 = C.c_void_p(), C.c_uint64()
+        assert lib.cmf_write_begin(w._block_ptr, img.nbytes, C.byref(slot), C.byref(t2)) == 0
+        assert slot.value == payload.value                       # the very bytes the reader is looking at
+        assert lib.cmf_peek_validate(r._block_ptr, uid, ticket.value) == 0      # ... so its copy is void from now on, before any byte changed
+        w.commit_device_write(t2.value, 4, img.shape)
+        assert lib.cmf_peek_validate(r._block_ptr, uid, ticket.value) == 0
+        st, data, t = r.read_frame()
+        assert st == ReadStatus.SUCCESS and t == 4

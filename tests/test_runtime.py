@@ -248,6 +248,51 @@ def test_capture_source_harness_and_image_directory(tmp_path):
     assert not os.path.exists(BLOCK_STUB + d)
 
 
+def test_logical_udl_that_returns_leaves_the_source_running():
+    """A logical UDL that returns normally (one-shot hardware set-up) does NOT stop the source; one that raises does, and so does a
+    capture UDL that is exhausted (core/capture_source.py:113-127 sets the quit flag in `except` only; :147-170 after the loop)."""
+    from vision.core.capture_source import CaptureSource
+    d = f"pyt_logical_{PID}"
+    src = CaptureSource()
+    ran = []
+    src.register_logical_udl(lambda limiter, args: ran.append(args), ("set-up",))
+    frame = np.zeros((4, 4, 3), np.uint8)
+
+    def capture(limiter, args):
+        for n, t in enumerate(limiter.rate(200)):
+            frame[0, 0, 0] = n % 251
+            yield d, t, frame
+    src.register_capture_udl("cam", capture)
+    t = threading.Thread(target=src.run_event_loop)
+    t.start()
+    try:
+        assert _wait(lambda: bool(ran), timeout=5)
+        seen = set()
+        with BlockAccessor(d) as r:
+            def pump():
+                st, data, _ = r.read_frame()
+                if data is not None:
+                    seen.add(int(data[0, 0, 0]))
+                return len(seen) >= 5                       # frames keep coming long after the logical UDL has returned
+            assert _wait(pump, timeout=5)
+        assert not src._quit_flag.is_set() and t.is_alive()
+    finally:
+        src._quit_flag.set()
+        t.join(5)
+        src.close()
+    # a logical UDL that raises stops everything
+    src2 = CaptureSource()
+
+    def broken(limiter, args):
+        raise ValueError("boom")
+    src2.register_logical_udl(broken)
+    t2 = threading.Thread(target=src2.run_event_loop)
+    t2.start()
+    t2.join(5)
+    assert not t2.is_alive() and src2._quit_flag.is_set()
+    src2.close()
+
+
 def test_video_capture_source(tmp_path):
     """capture_sources/video.py:9-39: one decoded frame per tick fanned out to every listed direction."""
     from vision.capture_sources.video import Video
