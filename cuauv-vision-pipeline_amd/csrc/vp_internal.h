@@ -44,7 +44,7 @@ struct vp_ctx {
     hipStream_t fb_stream;        // side stream of the labelling: the one-level kernels for crowded frames run here, beside the label write
     hipEvent_t ev_fb_fork, ev_fb_join;
     hipEvent_t ev_upload;         // recorded after an enqueued host-to-device copy (vp_memcpy_h2d_async / vp_wait_uploads)
-    hipStream_t post_stream;      // posts by DMA (vp_post.hip): device image -> ring slot copies run here, beside the context's stream; made on first use
+    hipStream_t post_stream[4];   // posts by DMA (vp_post.hip): device image -> ring slot copies run on these lanes, beside the context's stream; made on first use
     hipEvent_t post_fork;         // "the image as it is now" on the context's stream
     hipEvent_t post_free[32];     // end-of-copy events handed back by vp_post_free
     int post_nfree;

@@ -6,7 +6,7 @@
 // library's memcpy - two host passes over 10 MB per red_buoy frame.  Here the copy engine writes the slot itself:
 //
 //   post():   cmf_write_begin (slot opened: first sequence word bumped)  ->  vp_post_d2h: an event on the context's stream marks
-//             "the image as it is now", the post stream waits for it and copies device -> slot (the block's mapping is page-locked
+//             "the image as it is now", a post stream (one of four lanes; a block keeps its lane) waits for it and copies device -> slot (the block's mapping is page-locked
 //             once, vp_host_register), a second event marks the end of the copy
 //   flush:    once that event has passed: cmf_write_commit (metadata, second sequence word, uid, wake-up)
 //
@@ -24,11 +24,13 @@ struct PostLock {
     ~PostLock() { __atomic_store_n(w, 0, __ATOMIC_RELEASE); }
 };
 
+constexpr int kLanes = (int)(sizeof(((vp_ctx*)nullptr)->post_stream) / sizeof(hipStream_t));
+
 int post_setup(vp_ctx* ctx)
 {
-    if (ctx->post_stream) return VP_OK;
+    if (ctx->post_stream[0]) return VP_OK;
     (void)hipSetDevice(ctx->device);
-    VP_HIP(ctx, hipStreamCreateWithFlags(&ctx->post_stream, hipStreamNonBlocking));
+    for (int i = kLanes - 1; i >= 0; i--) VP_HIP(ctx, hipStreamCreateWithFlags(&ctx->post_stream[i], hipStreamNonBlocking));
     VP_HIP(ctx, hipEventCreateWithFlags(&ctx->post_fork, hipEventDisableTiming));
     return VP_OK;
 }
@@ -36,9 +38,9 @@ int post_setup(vp_ctx* ctx)
 
 extern "C" {
 
-int vp_post_d2h(vp_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, void** done)
+int vp_post_d2h(vp_ctx* ctx, int lane, void* host_dst, const void* dev_src, size_t bytes, void** done)
 {
-    if (!ctx || !host_dst || !dev_src || !bytes || !done) return VP_ERR_INVALID;
+    if (!ctx || !host_dst || !dev_src || !bytes || !done || lane < 0) return VP_ERR_INVALID;
     hipEvent_t ev = nullptr;
     {
         PostLock g(ctx);
@@ -47,14 +49,17 @@ int vp_post_d2h(vp_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, 
         if (ctx->post_nfree > 0) ev = ctx->post_free[--ctx->post_nfree];
     }
     if (!ev) VP_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    // "the image as it is now": everything queued so far on the context's stream, nothing queued later
+    // "the image as it is now": everything queued so far on the context's stream, nothing queued later.  Copies of one lane run in
+    // the order they were queued (a block keeps its lane, so a slot is never written by two copies at once); different lanes run
+    // side by side on the copy engines - a copy has ~30 us of fixed latency, and a module's posts of one frame go to different blocks.
+    hipStream_t ps = ctx->post_stream[lane % kLanes];
     hipError_t e = hipEventRecord(ctx->post_fork, ctx->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->post_stream, ctx->post_fork, 0);
-    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->post_stream);
-    if (e == hipSuccess) e = hipEventRecord(ev, ctx->post_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ps, ctx->post_fork, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ps);
+    if (e == hipSuccess) e = hipEventRecord(ev, ps);
     if (e != hipSuccess) {
         // whatever part was queued must not be writing into the slot when the caller aborts the write
-        (void)hipStreamSynchronize(ctx->post_stream);
+        (void)hipStreamSynchronize(ps);
         (void)hipEventDestroy(ev);
         return vp_fail(ctx, VP_ERR_HIP, "post copy (device image -> ring slot)", e);
     }
@@ -100,11 +105,10 @@ int vp_post_free(vp_ctx* ctx, void* done)
 
 void vp_post_teardown(vp_ctx* ctx)
 {
-    if (!ctx->post_stream) return;
-    (void)hipStreamSynchronize(ctx->post_stream);
+    if (!ctx->post_stream[0]) return;
+    for (int i = 0; i < kLanes; i++) (void)hipStreamSynchronize(ctx->post_stream[i]);
     for (int i = 0; i < ctx->post_nfree; i++) (void)hipEventDestroy(ctx->post_free[i]);
     ctx->post_nfree = 0;
     (void)hipEventDestroy(ctx->post_fork);
-    (void)hipStreamDestroy(ctx->post_stream);
-    ctx->post_stream = nullptr;
+    for (int i = 0; i < kLanes; i++) { (void)hipStreamDestroy(ctx->post_stream[i]); ctx->post_stream[i] = nullptr; }
 }

@@ -130,7 +130,7 @@ _SIGS = {
     "vp_feeder_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "vp_feeder_stop": (C.c_int, [C.c_void_p]),
     "vp_feeder_destroy": (C.c_int, [C.c_void_p]),
-    "vp_post_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vp_post_d2h": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vp_post_done": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_post_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_post_fence": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -41,10 +41,10 @@ def _now_ms() -> int:
 class _DmaPost:
     """One image on its way into its block's open slot.  Doubles as a 'pending reader' of the image (`_pending` / `_force` is the
     protocol of DeviceMat._consumers): forcing it fences the module's stream behind the copy."""
-    __slots__ = ("block", "ticket", "slot", "event", "ctx", "shape", "keep", "flushed", "_pending", "__weakref__")
+    __slots__ = ("block", "ticket", "slot", "lane", "event", "ctx", "shape", "keep", "flushed", "_pending", "__weakref__")
 
-    def __init__(self, block, slot, ticket):
-        self.block, self.slot, self.ticket = block, slot, ticket
+    def __init__(self, block, slot, ticket, lane):
+        self.block, self.slot, self.ticket, self.lane = block, slot, ticket, lane
         self.event = self.ctx = self.keep = self.shape = self._pending = None
         self.flushed = False
 
@@ -56,7 +56,7 @@ class _DmaPost:
         ctx = image._ctx
         src = image.dev_ptr                                     # launches the operator if the image was still deferred
         done = C.c_void_p()
-        _vp.check(_vp.lib().vp_post_d2h(ctx.handle, self.slot, src, image.nbytes, C.byref(done)), ctx.handle)
+        _vp.check(_vp.lib().vp_post_d2h(ctx.handle, self.lane, self.slot, src, image.nbytes, C.byref(done)), ctx.handle)
         self._release_event()
         self.event, self.ctx, self.shape, self.keep = done.value, ctx, image.shape, image._buf
         self._pending = True
@@ -117,6 +117,7 @@ class PostQueue:
         self._open_block, self._write_host, self.enabled = open_block, write_host, enabled
         self.queue: "OrderedDict[str, tuple]" = OrderedDict()   # name -> (ndarray | _DmaPost, colour space)
         self._open: Dict[str, _DmaPost] = {}                    # block name -> post whose slot is open (queued or flushed, not committed)
+        self._lanes: Dict[str, int] = {}                        # block name -> post stream of its copies (a block keeps its lane)
         self.dma_posts = self.host_posts = 0                    # counters for tools and tests
 
     def __len__(self):
@@ -173,7 +174,7 @@ class PostQueue:
         opened = block.begin_device_write(image._ctx, image.nbytes)
         if opened is None:
             return None
-        p = _DmaPost(block, opened[0], opened[1])
+        p = _DmaPost(block, opened[0], opened[1], self._lanes.setdefault(key, len(self._lanes)))
         try:
             p.copy_from(image)
         except Exception:

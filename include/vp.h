@@ -369,15 +369,16 @@ int vp_feeder_destroy(vp_feeder* f);
  * Replaces, for ModuleBase.post() of an image that lives in HBM, the download into a fresh array (core/base.py:846-876 `np.array(copy)`)
  * plus write_frame's memcpy into the slot (lib/camera_message_framework.cpp:306-374) at the flush (core/base.py:832-839).  The caller
  * opens the slot (cmf_write_begin, include/camera_message_framework_c.h), then:
- *   vp_post_d2h(ctx, slot_bytes, image_dev, bytes, &done): the image AS IT IS NOW (everything queued so far on the context's stream) is
- *     copied into `slot_bytes` (inside a mapping page-locked with vp_host_register) on the context's post stream; *done is an opaque
- *     handle on the end of that copy.  Returns at once.
+ *   vp_post_d2h(ctx, lane, slot_bytes, image_dev, bytes, &done): the image AS IT IS NOW (everything queued so far on the context's
+ *     stream) is copied into `slot_bytes` (inside a mapping page-locked with vp_host_register) on post stream `lane` (taken modulo the
+ *     four the context has: copies of one lane run in order - a block keeps its lane - different lanes side by side); *done is an
+ *     opaque handle on the end of that copy.  Returns at once.
  *   vp_post_done(ctx, done) -> 1 the bytes are in the slot (commit the write), 0 not yet, negative on a device error.
  *   vp_post_wait(ctx, done): blocks the calling thread until they are.
  *   vp_post_fence(ctx, done): work queued on the context's stream from now on starts after the copy - call before anything OVERWRITES
  *     the image (readers may run beside the copy).
  *   vp_post_free(ctx, done): hands the handle back (ctx may be NULL: the context is gone). */
-int vp_post_d2h(vp_ctx* ctx, void* slot_bytes_host, const void* image_dev, size_t bytes, void** done);
+int vp_post_d2h(vp_ctx* ctx, int lane, void* slot_bytes_host, const void* image_dev, size_t bytes, void** done);
 int vp_post_done(vp_ctx* ctx, void* done);
 int vp_post_wait(vp_ctx* ctx, void* done);
 int vp_post_fence(vp_ctx* ctx, void* done);
