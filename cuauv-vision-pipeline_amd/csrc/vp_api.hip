@@ -93,6 +93,7 @@ vp_ctx* vp_create(int device)
     hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming);
     ctx->ccl_levels = 2;
     ctx->ccl_mcap = -1;
+    ctx->flat_ops = 1;
     for (size_t& v : ctx->c3_lds_set) v = 0;
     if (const char* env = getenv("VP_CCL_LEVELS")) { const int v = atoi(env); if (v == 1 || v == 2) ctx->ccl_levels = v; }
     // tables: gamma u16[256] | cbrt u16[2048] | sdiv i32[256] | hdiv i32[256]
@@ -155,6 +156,7 @@ int vp_set_option(vp_ctx* ctx, int option, int value)
     if (option == VP_OPT_CHAIN_STREAMS && value >= 1 && value <= 4) { ctx->chain_streams = value; return VP_OK; }
     if (option == VP_OPT_CCL_LEVELS && (value == 1 || value == 2)) { ctx->ccl_levels = value; return VP_OK; }
     if (option == VP_OPT_CCL_MERGE_CAP && value >= -1) { ctx->ccl_mcap = value; return VP_OK; }
+    if (option == VP_OPT_FLAT_OPS && (value == 0 || value == 1)) { ctx->flat_ops = value; return VP_OK; }
     return vp_fail(ctx, VP_ERR_INVALID, "vp_set_option");
 }
 

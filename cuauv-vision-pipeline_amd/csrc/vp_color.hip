@@ -459,17 +459,142 @@ __global__ __launch_bounds__(256) void k_gray2bgr(const uint8_t* __restrict__ sr
     if (p2) p2[o] = v;
 }
 
+// Flat forms of the standalone conversions, on the pattern of k_color_thresh_flat: packed rows (stride == 3 w, so the image is one run
+// of pixels), every pointer 16-B aligned; one lane = 16 px = three 16-B loads, and per requested output 16-B stores (interleaved
+// image: three of them; a plane: one).  Only what is asked for is computed (NEED: bit c = channel c of the converted pixel is stored
+// somewhere) and stored.  The one-pixel-per-thread kernels above stay for strided views, unaligned planes and the last npx % 16 px.
+template <int CODE, int NEED>
+__global__ __launch_bounds__(256) void k_cvt_color_flat(const uint8_t* __restrict__ src, size_t ngroups, vp_tables tab, uint8_t* __restrict__ dst,
+                                                        uint8_t* __restrict__ p0, uint8_t* __restrict__ p1, uint8_t* __restrict__ p2)
+{
+    __shared__ typename ModeLds<CODE>::type s;
+    load_lds<CODE>(s, tab);
+    const size_t step = (size_t)gridDim.x * 256;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += step) {
+        const uint4* p = reinterpret_cast<const uint4*>(src + g * 48);
+        const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+        const u32 in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        u32 a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, c[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int bb = BYTE_OF(in, 3 * k), gg = BYTE_OF(in, 3 * k + 1), rr = BYTE_OF(in, 3 * k + 2);
+            int c0 = 0, c1 = 0, c2 = 0;
+            if constexpr (CODE == VP_BGR2GRAY) c0 = gray_px(bb, gg, rr);
+            else if constexpr (CODE == VP_BGR2LAB) lab_px<NEED>(s, bb, gg, rr, c0, c1, c2);
+            else if constexpr (CODE == VP_BGR2YCRCB) ycrcb_px(bb, gg, rr, c0, c1, c2);
+            else if constexpr (CODE == VP_BGR2HLS) hls_px(bb, gg, rr, c0, c1, c2);
+            else hsv_px(s, bb, gg, rr, c0, c1, c2);
+            a[k >> 2] |= (u32)c0 << (8 * (k & 3));
+            b[k >> 2] |= (u32)c1 << (8 * (k & 3));
+            c[k >> 2] |= (u32)c2 << (8 * (k & 3));
+        }
+        if constexpr (CODE == VP_BGR2GRAY) {
+            if (dst) vp_store16(dst + g * 16, a[0], a[1], a[2], a[3]);
+            if (p0) vp_store16(p0 + g * 16, a[0], a[1], a[2], a[3]);
+        } else {
+            if (dst) {
+                u32 d[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    d[(3 * k) >> 2] |= BYTE_OF(a, k) << (8 * ((3 * k) & 3));
+                    d[(3 * k + 1) >> 2] |= BYTE_OF(b, k) << (8 * ((3 * k + 1) & 3));
+                    d[(3 * k + 2) >> 2] |= BYTE_OF(c, k) << (8 * ((3 * k + 2) & 3));
+                }
+                vp_store16(dst + g * 48, d[0], d[1], d[2], d[3]);
+                vp_store16(dst + g * 48 + 16, d[4], d[5], d[6], d[7]);
+                vp_store16(dst + g * 48 + 32, d[8], d[9], d[10], d[11]);
+            }
+            if (p0) vp_store16(p0 + g * 16, a[0], a[1], a[2], a[3]);
+            if (p1) vp_store16(p1 + g * 16, b[0], b[1], b[2], b[3]);
+            if (p2) vp_store16(p2 + g * 16, c[0], c[1], c[2], c[3]);
+        }
+    }
+}
+
+// lane = 16 px = one 16-B load; the interleaved image takes three 16-B stores of byte triples, the planes are copies
+__global__ __launch_bounds__(256) void k_gray2bgr_flat(const uint8_t* __restrict__ src, size_t ngroups, uint8_t* __restrict__ dst, uint8_t* p0,
+                                                       uint8_t* p1, uint8_t* p2)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint4 v = reinterpret_cast<const uint4*>(src)[g];
+    const u32 a[4] = {v.x, v.y, v.z, v.w};
+    if (dst) {
+        u32 d[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) d[(3 * k + c) >> 2] |= BYTE_OF(a, k) << (8 * ((3 * k + c) & 3));
+        }
+        vp_store16(dst + g * 48, d[0], d[1], d[2], d[3]);
+        vp_store16(dst + g * 48 + 16, d[4], d[5], d[6], d[7]);
+        vp_store16(dst + g * 48 + 32, d[8], d[9], d[10], d[11]);
+    }
+    if (p0) vp_store16(p0 + g * 16, a[0], a[1], a[2], a[3]);
+    if (p1) vp_store16(p1 + g * 16, a[0], a[1], a[2], a[3]);
+    if (p2) vp_store16(p2 + g * 16, a[0], a[1], a[2], a[3]);
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <int CODE>
+static void launch_cvt_generic(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, uint8_t* d_dst, uint8_t* d_p0, uint8_t* d_p1, uint8_t* d_p2)
+{
+    hipLaunchKernelGGL((k_cvt_color<CODE>), dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst,
+                       d_p0, d_p1, d_p2);
+}
+
+template <int CODE>
+static void launch_cvt(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, uint8_t* d_dst, uint8_t* d_p0, uint8_t* d_p1, uint8_t* d_p2)
+{
+    const size_t npx = (size_t)w * h, ngroups = npx / 16;
+    const bool flat = ctx->flat_ops && (stride == (size_t)w * 3 || h == 1) && ngroups > 0 && aligned16(d_src) && aligned16(d_dst) && aligned16(d_p0) &&
+                      aligned16(d_p1) && aligned16(d_p2);
+    if (!flat) { launch_cvt_generic<CODE>(ctx, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); return; }
+    const dim3 grid((unsigned)std::min<size_t>((ngroups + 255) / 256, (size_t)ctx->num_cu * 32));
+    int need = d_dst ? 7 : ((d_p0 ? 1 : 0) | (d_p1 ? 2 : 0) | (d_p2 ? 4 : 0));
+    if constexpr (CODE == VP_BGR2LAB) {
+        switch (need) {       // every cube-root look-up that is not needed is a dependent LDS read less per pixel
+            case 1: hipLaunchKernelGGL((k_cvt_color_flat<CODE, 1>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+            case 2: hipLaunchKernelGGL((k_cvt_color_flat<CODE, 2>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+            case 4: hipLaunchKernelGGL((k_cvt_color_flat<CODE, 4>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+            default: hipLaunchKernelGGL((k_cvt_color_flat<CODE, 7>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
+        }
+    } else {
+        hipLaunchKernelGGL((k_cvt_color_flat<CODE, 7>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, ctx->tab, d_dst, d_p0, d_p1, d_p2);
+    }
+    const size_t done = ngroups * 16;
+    if (done < npx) {   // the last npx % 16 pixels, as a one-row image
+        const int dcn = CODE == VP_BGR2GRAY ? 1 : 3;
+        launch_cvt_generic<CODE>(ctx, d_src + done * 3, 0, (int)(npx - done), 1, d_dst ? d_dst + done * dcn : nullptr, d_p0 ? d_p0 + done : nullptr,
+                                 d_p1 ? d_p1 + done : nullptr, d_p2 ? d_p2 + done : nullptr);
+    }
+}
+
 int vpk_cvt_color(vp_ctx* ctx, int code, const uint8_t* d_src, size_t stride, int w, int h, uint8_t* d_dst, uint8_t* d_p0,
                   uint8_t* d_p1, uint8_t* d_p2)
 {
-    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
     switch (code) {
-        case VP_BGR2LAB: hipLaunchKernelGGL((k_cvt_color<VP_BGR2LAB>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
-        case VP_BGR2HSV: hipLaunchKernelGGL((k_cvt_color<VP_BGR2HSV>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
-        case VP_BGR2GRAY: hipLaunchKernelGGL((k_cvt_color<VP_BGR2GRAY>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
-        case VP_BGR2YCRCB: hipLaunchKernelGGL((k_cvt_color<VP_BGR2YCRCB>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
-        case VP_BGR2HLS: hipLaunchKernelGGL((k_cvt_color<VP_BGR2HLS>), grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, ctx->tab, d_dst, d_p0, d_p1, d_p2); break;
-        case VP_GRAY2BGR: hipLaunchKernelGGL(k_gray2bgr, grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2LAB: launch_cvt<VP_BGR2LAB>(ctx, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2HSV: launch_cvt<VP_BGR2HSV>(ctx, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2GRAY: launch_cvt<VP_BGR2GRAY>(ctx, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2YCRCB: launch_cvt<VP_BGR2YCRCB>(ctx, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_BGR2HLS: launch_cvt<VP_BGR2HLS>(ctx, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2); break;
+        case VP_GRAY2BGR: {
+            const size_t npx = (size_t)w * h, ngroups = npx / 16;
+            const bool flat = ctx->flat_ops && (stride == (size_t)w || h == 1) && ngroups > 0 && aligned16(d_src) && aligned16(d_dst) && aligned16(d_p0) &&
+                              aligned16(d_p1) && aligned16(d_p2);
+            if (!flat) {
+                hipLaunchKernelGGL(k_gray2bgr, dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, ctx->stream, d_src, stride, w, h, d_dst, d_p0, d_p1, d_p2);
+                break;
+            }
+            hipLaunchKernelGGL(k_gray2bgr_flat, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, ctx->stream, d_src, ngroups, d_dst, d_p0, d_p1, d_p2);
+            const size_t done = ngroups * 16;
+            if (done < npx)
+                hipLaunchKernelGGL(k_gray2bgr, dim3(1, 1), dim3(256), 0, ctx->stream, d_src + done, (size_t)0, (int)(npx - done), 1, d_dst ? d_dst + done * 3 : nullptr,
+                                   d_p0 ? d_p0 + done : nullptr, d_p1 ? d_p1 + done : nullptr, d_p2 ? d_p2 + done : nullptr);
+            break;
+        }
         default: return vp_fail(ctx, VP_ERR_INVALID, "conversion code");
     }
     VP_HIP(ctx, hipGetLastError());
@@ -500,10 +625,45 @@ __global__ __launch_bounds__(256) void k_inrange_f32(const float* __restrict__ s
     dst[(size_t)y * w + x] = (v >= lo && v <= hi) ? 255 : 0;
 }
 
+// Flat form: packed rows, 16-B aligned; lane = 16 px = CN 16-B loads and one 16-B store.  Per channel one unsigned comparison
+// (in_span); ranges are kernel arguments, so an empty one costs nothing per pixel.
+template <int CN>
+__global__ __launch_bounds__(256) void k_inrange_u8_flat(const uint8_t* __restrict__ src, size_t ngroups, vp_range3 q, uint8_t* __restrict__ dst)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    u32 in[4 * CN];
+#pragma unroll
+    for (int j = 0; j < CN; j++) {
+        const uint4 v = reinterpret_cast<const uint4*>(src + g * 16 * CN)[j];
+        in[4 * j] = v.x; in[4 * j + 1] = v.y; in[4 * j + 2] = v.z; in[4 * j + 3] = v.w;
+    }
+    u32 out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < CN; c++) ok = ok & in_span((int)BYTE_OF(in, CN * k + c), q.lo[c], q.hi[c]);
+        out[k >> 2] |= (ok ? 0xffu : 0u) << (8 * (k & 3));
+    }
+    vp_store16(dst + g * 16, out[0], out[1], out[2], out[3]);
+}
+
 int vpk_inrange_u8(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int cn, const vp_range3& q, uint8_t* d_dst)
 {
-    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-    hipLaunchKernelGGL(k_inrange_u8, grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, cn, q, d_dst);
+    const size_t npx = (size_t)w * h, ngroups = npx / 16;
+    const bool flat = ctx->flat_ops && (cn == 1 || cn == 3) && (stride == (size_t)w * cn || h == 1) && ngroups > 0 && aligned16(d_src) && aligned16(d_dst);
+    if (flat) {
+        const dim3 grid((unsigned)((ngroups + 255) / 256));
+        if (cn == 1) hipLaunchKernelGGL((k_inrange_u8_flat<1>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst);
+        else hipLaunchKernelGGL((k_inrange_u8_flat<3>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst);
+        const size_t done = ngroups * 16;
+        if (done < npx)
+            hipLaunchKernelGGL(k_inrange_u8, dim3(1, 1), dim3(256), 0, ctx->stream, d_src + done * cn, (size_t)0, (int)(npx - done), 1, cn, q, d_dst + done);
+    } else {
+        dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+        hipLaunchKernelGGL(k_inrange_u8, grid, dim3(256), 0, ctx->stream, d_src, stride, w, h, cn, q, d_dst);
+    }
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }

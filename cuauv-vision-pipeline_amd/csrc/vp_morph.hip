@@ -602,21 +602,23 @@ __global__ __launch_bounds__(256) void k_sub_sat_u8(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_add_weighted_u8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n, double alpha,
                                                          double beta, double gamma, uint8_t* __restrict__ dst)
 {
-    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    // lane = 16 bytes = one 16-B load per input and one 16-B store (aligned pointers; the last n % 16 bytes and unaligned images byte-wise)
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
     if (i0 >= n) return;
     auto one = [&](int x, int y) -> unsigned {
         const double v = __dadd_rn(__dadd_rn(__dmul_rn((double)x, alpha), __dmul_rn((double)y, beta)), gamma);
         const double r = rint(v);
         return (unsigned)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
     };
-    if (i0 + 4 <= n && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst) & 3u) == 0) {
-        const unsigned va = *reinterpret_cast<const unsigned*>(a + i0), vb = *reinterpret_cast<const unsigned*>(b + i0);
-        unsigned out = 0;
+    if (i0 + 16 <= n && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst) & 15u) == 0) {
+        const uint4 qa = *reinterpret_cast<const uint4*>(a + i0), qb = *reinterpret_cast<const uint4*>(b + i0);
+        const unsigned va[4] = {qa.x, qa.y, qa.z, qa.w}, vb[4] = {qb.x, qb.y, qb.z, qb.w};
+        unsigned out[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 4; k++) out |= one((int)((va >> (8 * k)) & 255u), (int)((vb >> (8 * k)) & 255u)) << (8 * k);
-        *reinterpret_cast<unsigned*>(dst + i0) = out;
+        for (int k = 0; k < 16; k++) out[k >> 2] |= one((int)((va[k >> 2] >> (8 * (k & 3))) & 255u), (int)((vb[k >> 2] >> (8 * (k & 3))) & 255u)) << (8 * (k & 3));
+        vp_store16(dst + i0, out[0], out[1], out[2], out[3]);
     } else {
-        for (size_t i = i0; i < n && i < i0 + 4; i++) dst[i] = (uint8_t)one(a[i], b[i]);
+        for (size_t i = i0; i < n && i < i0 + 16; i++) dst[i] = (uint8_t)one(a[i], b[i]);
     }
 }
 
@@ -654,7 +656,7 @@ int vpk_draw_stamps(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int
 
 int vpk_add_weighted_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double alpha, double beta, double gamma, uint8_t* dst)
 {
-    hipLaunchKernelGGL(k_add_weighted_u8, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, ctx->stream, a, b, n, alpha, beta, gamma, dst);
+    hipLaunchKernelGGL(k_add_weighted_u8, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, a, b, n, alpha, beta, gamma, dst);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }

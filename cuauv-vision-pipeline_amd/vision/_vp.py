@@ -25,6 +25,7 @@ CHAIN_MAX_MORPH = 8
 OPT_CHAIN_STREAMS = 1
 OPT_CCL_LEVELS = 2
 OPT_CCL_MERGE_CAP = 3
+OPT_FLAT_OPS = 4
 PROF_KERNELS = 15
 
 

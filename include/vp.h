@@ -66,8 +66,10 @@ int vp_synchronize(vp_ctx* ctx);
  * VP_OPT_CCL_LEVELS (1 or 2, default 2): 2 = strip-local components merged by one block per frame, frames that do not fit
  * finished by the one-level kernels; 1 = one-level kernels only.  Results are identical.
  * VP_OPT_CCL_MERGE_CAP (-1 = capacity of the merge block, or a smaller count): strip components per frame above which a frame
- * is handed to the one-level kernels (test hook: 0 sends every non-empty frame there). */
-enum { VP_OPT_CHAIN_STREAMS = 1, VP_OPT_CCL_LEVELS = 2, VP_OPT_CCL_MERGE_CAP = 3 };
+ * is handed to the one-level kernels (test hook: 0 sends every non-empty frame there).
+ * VP_OPT_FLAT_OPS (0 or 1, default 1): the per-operator kernels (vp_cvt_color_*, vp_inrange_u8_*) use their 16-pixels-per-lane forms
+ * whenever rows are packed and pointers 16-B aligned; 0 forces the generic one-pixel-per-thread kernels (the tests run both). */
+enum { VP_OPT_CHAIN_STREAMS = 1, VP_OPT_CCL_LEVELS = 2, VP_OPT_CCL_MERGE_CAP = 3, VP_OPT_FLAT_OPS = 4 };
 int vp_set_option(vp_ctx* ctx, int option, int value);
 /* HIP-event stopwatch on the context's stream (bench.py: roofline.achieved). */
 int vp_timer_start(vp_ctx* ctx);
