@@ -127,6 +127,7 @@ int vp_destroy(vp_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     vp_post_teardown(ctx);
     if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->c3_acc) hipFree(ctx->c3_acc);
     if (ctx->hstage) hipHostFree(ctx->hstage);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     hipEventDestroy(ctx->ev0);

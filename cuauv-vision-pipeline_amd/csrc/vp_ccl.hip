@@ -48,6 +48,16 @@ struct ccl_acc {   // 48 B
 
 struct contrib { u32 area; int minx, maxx, miny, maxy; u32 pad; u64 sx, sy; };
 
+// every entry "empty": what acc_commit expects to add to
+__global__ __launch_bounds__(256) void k_ccl3_acc_init(ccl_acc* __restrict__ acc, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        ccl_acc z;
+        z.area = 0; z.minx = INT_MAX; z.miny = INT_MAX; z.maxx = INT_MIN; z.maxy = INT_MIN; z.pad = 0; z.sx = 0; z.sy = 0;
+        acc[i] = z;
+    }
+}
+
 #define RK_PARTS 8
 #define BG_PARTS 8
 #define C2_RC 128              // two-level labelling (vp_ccl2.inl): stride of the per-strip component tables
@@ -731,14 +741,38 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
         VP_HIP(ctx, hipGetLastError());
         static const int c3_dbg = getenv("VP_CCL3_DBG") ? atoi(getenv("VP_CCL3_DBG")) : 0;   // timing experiments only: parts of the kernels skipped
         static const int c3_dry = getenv("VP_CCL3_DRY") ? atoi(getenv("VP_CCL3_DRY")) : 0;   // experiments: 1 no launches, 2 no link, 3 no label
+        // Accumulators of the components that span strips, indexed by label: a set of the context's own that is all "empty" between
+        // calls - k_ccl3_rows resets exactly the entries it reads - so that no launch writes max_labels entries per frame (268 MB per 128
+        // frames with 65,536 labels allowed: a quarter of what k_ccl3_link stored).  Sub-batches on several streams would share it: they
+        // keep the per-call workspace and its clearing.
+        ccl_acc* acc3 = (ccl_acc*)ws.acc;
+        bool acc3_own = false;
+        if (P3.ok && c3_dry != 1 && ctx->chain_streams == 1) {
+            const size_t need = sizeof(ccl_acc) * (size_t)max_labels * (size_t)n;
+            if (need > ctx->c3_acc_bytes) {
+                VP_HIP(ctx, hipStreamSynchronize(s));
+                if (ctx->c3_acc) { (void)hipFree(ctx->c3_acc); ctx->c3_acc = nullptr; ctx->c3_acc_bytes = 0; }
+                if (hipMalloc(&ctx->c3_acc, need) == hipSuccess) { ctx->c3_acc_bytes = need; ctx->c3_acc_dirty = 1; }
+                else (void)hipGetLastError();                  // no memory for it: the workspace's set, cleared per call
+            }
+            if (ctx->c3_acc && need <= ctx->c3_acc_bytes) {
+                if (ctx->c3_acc_dirty) {
+                    const size_t entries = ctx->c3_acc_bytes / sizeof(ccl_acc);
+                    hipLaunchKernelGGL(k_ccl3_acc_init, dim3((unsigned)std::min<size_t>((entries + 255) / 256, 65535)), dim3(256), 0, s, (ccl_acc*)ctx->c3_acc, entries);
+                }
+                ctx->c3_acc_dirty = 1;                         // until k_ccl3_rows of this call has been queued
+                acc3 = (ccl_acc*)ctx->c3_acc;
+                acc3_own = true;
+            }
+        }
         if (P3.ok && c3_dry != 1) {
             // two launches that read the list of handed-over frames and leave at once when it is empty (the usual case)
             if (c3_dry != 2) { vp_prof_scope ps(ctx, VPK_CCL_LOCAL);
               static const int lgrid = getenv("VP_C3_LGRID") ? atoi(getenv("VP_C3_LGRID")) : 16;
               if (c3_tall) hipLaunchKernelGGL(k_ccl3_link<2 * C3_LINK_THREADS>, dim3((unsigned)(ctx->num_cu * lgrid)), dim3(2 * C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, (ccl_acc*)ws.acc, max_labels, c3_dbg);
+                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, acc3, max_labels, acc3_own ? 0 : 1, c3_dbg);
               else hipLaunchKernelGGL(k_ccl3_link<C3_LINK_THREADS>, dim3((unsigned)(ctx->num_cu * lgrid)), dim3(C3_LINK_THREADS), lds3a, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, (ccl_acc*)ws.acc, max_labels, c3_dbg); }
+                                 ws.flags, ws.c3_child, ws.c3_lroot, ws.seglabel, acc3, max_labels, acc3_own ? 0 : 1, c3_dbg); }
             { vp_prof_scope ps(ctx, VPK_CCL_BOUNDARY);
               const size_t span = (size_t)2 * G.wb + 4;     // u16 roots of the two rows (row pairs) that meet: span entries each
               static const int bgrid = getenv("VP_C3_BGRID") ? atoi(getenv("VP_C3_BGRID")) : 64;   // blocks per CU in the grid: items differ a lot in cost, the dispatcher balances
@@ -749,15 +783,17 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
             if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
               static const int agrid = getenv("VP_C3_AGRID") ? atoi(getenv("VP_C3_AGRID")) : 2;
               if (c3_tall) hipLaunchKernelGGL(k_ccl3_label<2 * C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(2 * C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
+                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, acc3, max_labels, d_labels, d_stats,
                                  d_centroids, c3_dbg);
               else hipLaunchKernelGGL(k_ccl3_label<C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, (ccl_acc*)ws.acc, max_labels, d_labels, d_stats,
+                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, acc3, max_labels, d_labels, d_stats,
                                  d_centroids, c3_dbg); }
-            if (d_stats || d_centroids) {
+            if (d_stats || d_centroids || acc3_own) {
                 vp_prof_scope ps(ctx, VPK_CCL_FINAL);
                 hipLaunchKernelGGL(k_ccl3_rows, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.c3_child, ws.prefix,
-                                   ws.c3_barr, (const c3_state*)ws.c3_state, (const contrib*)ws.c3_tot, (int)c3_strips_cap(h), (const ccl_acc*)ws.acc, max_labels, d_stats, d_centroids);
+                                   ws.c3_barr, (const c3_state*)ws.c3_state, (const contrib*)ws.c3_tot, (int)c3_strips_cap(h), acc3, max_labels, d_stats, d_centroids,
+                                   acc3_own ? 1 : 0);
+                if (acc3_own && c3_dry == 0 && c3_dbg == 0) ctx->c3_acc_dirty = 0;   // every entry the labelling launch touched has been handed back clean
             }
             VP_HIP(ctx, hipGetLastError());
         } else if (!P3.ok) {

@@ -287,7 +287,7 @@ template <int LT>
 __global__ __launch_bounds__(LT, 8) void k_ccl3_link(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
                                                                const u32* __restrict__ clist, u32* __restrict__ parent, u32* __restrict__ flags,
                                                                u32* __restrict__ child, u32* __restrict__ lrootbits, u32* __restrict__ root16,
-                                                               ccl_acc* __restrict__ acc, int max_labels, int dbg)
+                                                               ccl_acc* __restrict__ acc, int max_labels, int acc_clear, int dbg)
 {
     const u32 nc = *ncrowded;
     if (nc == 0) return;                                      // the common case: nothing was handed over
@@ -381,10 +381,12 @@ __global__ __launch_bounds__(LT, 8) void k_ccl3_link(const u64* __restrict__ bit
                 const u32 id = c3_rel(G, r, 64 * j + sb);
                 const u32 root = lds_root(lpar, id);
                 lpar[id] = root;
-                if (root == id) {
-                    atomicOr(lroots + (id >> 5), 1u << (id & 31));
-                    fpar[base + id] = base + id;
-                }
+                if (root == id) atomicOr(lroots + (id >> 5), 1u << (id & 31));
+                // The frame's union-find (k_ccl3_bound) only ever starts from roots of segments in a strip's first or last row, and only
+                // roots it united are read back later (k_ccl3_rank, k_ccl3_label): the others need no entry in global memory.  (Every
+                // segment of such a row stores its root's entry: the same value from each, and 4-byte stores to scattered lines - one
+                // per local root, 170 k per frame of 10 % noise - were half of what this launch wrote.)
+                if (r == 0 || r == P.R - 1) fpar[base + root] = base + root;
             }
         }
         __syncthreads();
@@ -399,8 +401,9 @@ __global__ __launch_bounds__(LT, 8) void k_ccl3_link(const u64* __restrict__ bit
         }
         C3_PROBE(4);   // dump issued
         // this strip's share of the frame's accumulators, cleared for the labelling launch (only components that span strips use one,
-        // but which labels those are is not known before the ranks are)
-        {
+        // but which labels those are is not known before the ranks are).  Not in the usual case: the context keeps a set of accumulators
+        // that k_ccl3_rows hands back clean (acc_clear == 0), so nothing sized by max_labels is written per frame.
+        if (acc_clear) {
             const u32 wpe = (u32)(sizeof(ccl_acc) / 4);       // words per entry: area, minx, miny, maxx, maxy, pad, sx, sy
             const u64 words = (u64)max_labels * wpe;
             const u64 per = (words + (u64)P.strips - 1) / (u64)P.strips;
@@ -924,11 +927,11 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
 __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded, const u32* __restrict__ clist,
                                                    const u32* __restrict__ flags, const u32* __restrict__ child, const u32* __restrict__ prefix,
                                                    const u32* __restrict__ barr, const c3_state* __restrict__ state, const contrib* __restrict__ tot,
-                                                   int tot_stride, const ccl_acc* __restrict__ acc, int max_labels, int32_t* __restrict__ stats,
-                                                   double* __restrict__ cent)
+                                                   int tot_stride, ccl_acc* __restrict__ acc, int max_labels, int32_t* __restrict__ stats,
+                                                   double* __restrict__ cent, int acc_clean)
 {
     const u32 nc = *ncrowded;
-    if (nc == 0 || (!stats && !cent)) return;
+    if (nc == 0 || (!stats && !cent && !acc_clean)) return;
     __shared__ u32 sbase[C3_MAX_STRIPS + 2];
     __shared__ u32 red[256 / 64 + 1];
     const int NT = 256, tid = threadIdx.x;
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const 
         const u32* ffl = flags + (size_t)f * G.nw32;
         const u32* fch = child + (size_t)f * G.nw32;
         const u32* fpf = prefix + (size_t)f * G.nw32;
-        const ccl_acc* facc = acc + (size_t)f * max_labels;
+        ccl_acc* facc = acc + (size_t)f * max_labels;
         __syncthreads();
         c3_strip_bases<256>(P, barr + (size_t)f * 3 * (P.strips + 1) + 2 * (P.strips + 1), sbase, red);
         const u32 k0 = (u32)s * (P.ids / 32), k1 = (s == P.strips - 1) ? G.nw32 : min(k0 + P.ids / 32, G.nw32);
@@ -952,6 +955,11 @@ __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const 
                 const u32 label = sbase[s] + fpf[k] + (u32)__popc(fl & ((1u << b) - 1u)) + 1u;
                 if (label >= (u32)max_labels) continue;
                 const ccl_acc a = facc[label];
+                if (acc_clean) {      // hand the entry back as the next call expects it (only entries of components that span strips were ever touched)
+                    ccl_acc z;
+                    z.area = 0; z.minx = INT_MAX; z.miny = INT_MAX; z.maxx = INT_MIN; z.maxy = INT_MIN; z.pad = 0; z.sx = 0; z.sy = 0;
+                    facc[label] = z;
+                }
                 const size_t o = (size_t)f * max_labels + label;
                 if (stats) {
                     int32_t* sp = stats + o * 5;

@@ -53,6 +53,9 @@ struct vp_ctx {
     u32* cb_folds_own;            // context-owned device word the counter is copied to (the workspace it is made in is carved anew per call)
     int ccl_levels;               // 2: two-level labelling with the one-level kernels as fallback (default); 1: one-level only
     size_t c3_lds_set[4];         // dynamic LDS the crowded-frame kernels have been allowed on THIS device (link, label; short and tall strips): the attribute is per device
+    void* c3_acc;                 // crowded-frame labelling: accumulators of components that span strips, all empty between calls (vp_ccl.hip)
+    size_t c3_acc_bytes;
+    int c3_acc_dirty;             // a call was cut short after its labelling launch: reinitialise before the next use
     int flat_ops;                 // 1 (default): the per-operator kernels take their 16-px-per-lane forms when rows are packed and pointers aligned; 0: always the generic kernels (tests)
     int ccl_mcap;                 // components per frame the merge block accepts (-1: its LDS capacity); tests lower it to force the fallback
     vp_prof prof;
