@@ -73,6 +73,8 @@ size_t vp_ccl_nids(int w, int h)
 static size_t c2_strips_max(int h) { return (size_t)(h + 7) / 8; }
 static size_t c3_strips_cap(int h) { return (size_t)(h + 1) / 2 + 2; }   // vp_ccl3.inl: strips of at least 2 rows, + 1 boundary slot
 #define C3_STATE_BYTES 48
+// which of the two labelling launches takes a strip (vp_ccl3.inl): one byte per (frame, strip)
+static size_t c3_items_bytes(int n, int h) { return (size_t)n * c3_strips_cap(h); }
 
 size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
 {
@@ -82,7 +84,7 @@ size_t vp_ccl_ws_bytes(int w, int h, int n, int max_labels)
            vp_align((size_t)n * h * vp_ww(w) * 4) + vp_align(sizeof(contrib) * BG_PARTS * (size_t)n) +
            vp_align(ns * 4) + vp_align(ns * C2_RC * sizeof(contrib)) + vp_align(ns * sizeof(c2_box)) + vp_align(ns * C2_RC * 4) +
            vp_align((size_t)n * 4) + 2 * vp_align(nids / 8 * n) + vp_align((size_t)n * 4) + 256 + vp_align((size_t)n * C3_STATE_BYTES) +
-           vp_align((size_t)n * c3_strips_cap(h) * 12) + vp_align((size_t)n * c3_strips_cap(h) * 40) + 4096;
+           vp_align((size_t)n * c3_strips_cap(h) * 12) + vp_align((size_t)n * c3_strips_cap(h) * 40) + vp_align(c3_items_bytes(n, h)) + 4096 + 1024;
 }
 
 void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws* out)
@@ -108,12 +110,13 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
     out->c3_state = vp_ws_take(ctx, (size_t)n * C3_STATE_BYTES);
     out->c3_tot = vp_ws_take(ctx, (size_t)n * c3_strips_cap(h) * 40);              // sizeof(contrib)
     out->c3_barr = (u32*)vp_ws_take(ctx, (size_t)n * c3_strips_cap(h) * 12);   // per frame: boundary arrivals | boundaries done per strip | roots per strip
+    out->c3_items = (unsigned char*)vp_ws_take(ctx, c3_items_bytes(n, h));     // per (handed-over frame, strip): 1 = light labelling launch, 2 = heavy
 }
 
 bool vp_ccl_ws_ok(const vp_ccl_ws& ws)
 {
     return ws.parent && ws.seglabel && ws.flags && ws.prefix && ws.acc && ws.wordlabel && ws.bgpart && ws.c2_ncomp && ws.c2_recs &&
-           ws.c2_bgbox && ws.c2_label && ws.c2_crowded && ws.c3_child && ws.c3_lroot && ws.c3_clist && ws.c3_ncrowded && ws.c3_state && ws.c3_barr && ws.c3_tot;
+           ws.c2_bgbox && ws.c2_label && ws.c2_crowded && ws.c3_child && ws.c3_lroot && ws.c3_clist && ws.c3_ncrowded && ws.c3_state && ws.c3_barr && ws.c3_tot && ws.c3_items;
 }
 
 // ---- whole-image global-memory path (fallback for images too wide for the LDS strip kernel) ---------------
@@ -709,27 +712,39 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
         c3_plan P3 = c3_make_plan(G, std::min<u32>(c3_max_ids, C3_IDS));
         const bool c3_tall = P3.ids > 8192;           // taller strips: twice the threads per block (one word per thread still)
         static const bool c3_off = getenv("VP_CCL3") && atoi(getenv("VP_CCL3")) == 0;
-        size_t lds3a = 0, lds3b = 0;
+        size_t lds3a = 0, lds3b = 0, lds3c = 0;
         if (P3.ok && !c3_off && (size_t)P3.strips + 1 <= c3_strips_cap(h) && sizeof(c3_state) == C3_STATE_BYTES) {
             lds3a = c3_link_lds(G, P3);
-            lds3b = c3_label_lds(G, P3);
+            lds3b = c3_label_lds(G, P3, 0, C3_ACC);
+            lds3c = c3_label_lds(G, P3, C3_LIGHT_ROOTS, C3_LIGHT_ACC);
             // (grow-only; kernels accept more dynamic LDS than the 64 KB default once told so - per device, hence kept in the context)
             const void* fa_ = c3_tall ? (const void*)k_ccl3_link<2 * C3_LINK_THREADS> : (const void*)k_ccl3_link<C3_LINK_THREADS>;
-            const void* fb_ = c3_tall ? (const void*)k_ccl3_label<2 * C3_LABEL_THREADS> : (const void*)k_ccl3_label<C3_LABEL_THREADS>;
-            size_t& ra = ctx->c3_lds_set[c3_tall ? 2 : 0]; size_t& rb = ctx->c3_lds_set[c3_tall ? 3 : 1];
+            const void* fb_ = c3_tall ? (const void*)k_ccl3_label<2 * C3_LABEL_THREADS, 0, C3_ACC> : (const void*)k_ccl3_label<C3_LABEL_THREADS, 0, C3_ACC>;
+            const void* fc_ = (const void*)k_ccl3_label<C3_LABEL_THREADS, C3_LIGHT_ROOTS, C3_LIGHT_ACC>;
+            size_t& ra = ctx->c3_lds_set[c3_tall ? 2 : 0]; size_t& rb = ctx->c3_lds_set[c3_tall ? 3 : 1]; size_t& rc_ = ctx->c3_lds_set[4];
             if (lds3a > ra) { if (hipFuncSetAttribute(fa_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3a) == hipSuccess) ra = lds3a; else { (void)hipGetLastError(); P3.ok = 0; } }
             if (P3.ok && lds3b > rb) { if (hipFuncSetAttribute(fb_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3b) == hipSuccess) rb = lds3b; else { (void)hipGetLastError(); P3.ok = 0; } }
+            if (P3.ok && lds3c > rc_) { if (hipFuncSetAttribute(fc_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3c) == hipSuccess) rc_ = lds3c; else { (void)hipGetLastError(); P3.ok = 0; } }
         } else {
             P3.ok = 0;
         }
         const int c3_strips = P3.ok ? P3.strips : 0;
         if (P3.ok && getenv("VP_CCL3_OCC")) {   // diagnosis: blocks per CU the runtime grants the crowded-frame kernels
-            int oa = 0, ob = 0;
-            if (c3_tall) { hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link<2 * C3_LINK_THREADS>, 2 * C3_LINK_THREADS, lds3a); hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label<2 * C3_LABEL_THREADS>, 2 * C3_LABEL_THREADS, lds3b); }
-            else { hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link<C3_LINK_THREADS>, C3_LINK_THREADS, lds3a); hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label<C3_LABEL_THREADS>, C3_LABEL_THREADS, lds3b); }
-            hipFuncAttributes fa, fb2;
-            hipFuncGetAttributes(&fa, c3_tall ? (const void*)k_ccl3_link<2 * C3_LINK_THREADS> : (const void*)k_ccl3_link<C3_LINK_THREADS>); hipFuncGetAttributes(&fb2, c3_tall ? (const void*)k_ccl3_label<2 * C3_LABEL_THREADS> : (const void*)k_ccl3_label<C3_LABEL_THREADS>);
-            fprintf(stderr, "ccl3 occupancy: link %d blocks/CU (LDS %zu + %zu static, %d regs), label %d blocks/CU (LDS %zu + %zu static, %d regs), CUs %d\n", oa, lds3a, fa.sharedSizeBytes, fa.numRegs, ob, lds3b, fb2.sharedSizeBytes, fb2.numRegs, ctx->num_cu);
+            int oa = 0, ob = 0, oc = 0;
+            if (c3_tall) {
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link<2 * C3_LINK_THREADS>, 2 * C3_LINK_THREADS, lds3a);
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label<2 * C3_LABEL_THREADS, 0, C3_ACC>, 2 * C3_LABEL_THREADS, lds3b);
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ccl3_label<C3_LABEL_THREADS, C3_LIGHT_ROOTS, C3_LIGHT_ACC>, C3_LABEL_THREADS, lds3c);
+            } else {
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_ccl3_link<C3_LINK_THREADS>, C3_LINK_THREADS, lds3a);
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_ccl3_label<C3_LABEL_THREADS, 0, C3_ACC>, C3_LABEL_THREADS, lds3b);
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ccl3_label<C3_LABEL_THREADS, C3_LIGHT_ROOTS, C3_LIGHT_ACC>, C3_LABEL_THREADS, lds3c);
+            }
+            hipFuncAttributes fb2, fc2;
+            hipFuncGetAttributes(&fb2, c3_tall ? (const void*)k_ccl3_label<2 * C3_LABEL_THREADS, 0, C3_ACC> : (const void*)k_ccl3_label<C3_LABEL_THREADS, 0, C3_ACC>);
+            hipFuncGetAttributes(&fc2, (const void*)k_ccl3_label<C3_LABEL_THREADS, C3_LIGHT_ROOTS, C3_LIGHT_ACC>);
+            fprintf(stderr, "ccl3 occupancy: link %d blocks/CU (LDS %zu), label heavy %d blocks/CU (LDS %zu + %zu static, %d regs), light %d blocks/CU (LDS %zu + %zu static, %d regs), CUs %d\n",
+                    oa, lds3a, ob, lds3b, fb2.sharedSizeBytes, fb2.numRegs, oc, lds3c, fc2.sharedSizeBytes, fc2.numRegs, ctx->num_cu);
         }
         { vp_prof_scope ps(ctx, VPK_CCL2_LOCAL);
           hipLaunchKernelGGL(k_ccl2_local, dim3((unsigned)((size_t)n * strips)), dim3(256), lds2, s, d_bits, G, strips, (int)cap2, (int)rc, (int)tail_words, ws.c2_ncomp,
@@ -779,15 +794,20 @@ int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, 
               hipLaunchKernelGGL(k_ccl3_bound, dim3((unsigned)(ctx->num_cu * bgrid)), dim3(256), span * 4 + 16, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent, ws.flags,
                                  ws.c3_child, ws.seglabel, c3_dbg); }
             { vp_prof_scope ps(ctx, VPK_CCL_RANK);
-              hipLaunchKernelGGL(k_ccl3_rank, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.prefix, ws.c3_barr, ws.c3_lroot, ws.parent); }
+              hipLaunchKernelGGL(k_ccl3_rank, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.prefix, ws.c3_barr, ws.c3_lroot, ws.parent,
+                                 ws.c3_items); }
             if (c3_dry != 3) { vp_prof_scope ps(ctx, VPK_CCL_STATS);
+              // two instantiations, each taking the strips k_ccl3_rank marked for it: LIGHT first - two blocks per CU - then HEAVY
               static const int agrid = getenv("VP_C3_AGRID") ? atoi(getenv("VP_C3_AGRID")) : 2;
-              if (c3_tall) hipLaunchKernelGGL(k_ccl3_label<2 * C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(2 * C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, acc3, max_labels, d_labels, d_stats,
-                                 d_centroids, c3_dbg);
-              else hipLaunchKernelGGL(k_ccl3_label<C3_LABEL_THREADS>, dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, d_bits, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.parent,
-                                 ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, acc3, max_labels, d_labels, d_stats,
-                                 d_centroids, c3_dbg); }
+              static const int agrid_light = getenv("VP_C3_AGRID_LIGHT") ? atoi(getenv("VP_C3_AGRID_LIGHT")) : 4;
+#define C3_LABEL_ARGS d_bits, G, P3, ws.c3_ncrowded, ws.c3_items, ws.c3_clist, ws.parent, ws.flags, ws.c3_child, ws.prefix, ws.c3_lroot, ws.seglabel, ws.c3_barr, \
+                             (c3_state*)ws.c3_state, (contrib*)ws.c3_tot, (int)c3_strips_cap(h), d_nlabels, acc3, max_labels, d_labels, d_stats, d_centroids, c3_dbg
+              // (the light instantiation always with 512 threads: at ~120 registers a CU holds 16 waves, i.e. two blocks of eight)
+              hipLaunchKernelGGL((k_ccl3_label<C3_LABEL_THREADS, C3_LIGHT_ROOTS, C3_LIGHT_ACC>), dim3((unsigned)(ctx->num_cu * agrid_light)), dim3(C3_LABEL_THREADS), lds3c, s, C3_LABEL_ARGS);
+              if (c3_tall) hipLaunchKernelGGL((k_ccl3_label<2 * C3_LABEL_THREADS, 0, C3_ACC>), dim3((unsigned)(ctx->num_cu * agrid)), dim3(2 * C3_LABEL_THREADS), lds3b, s, C3_LABEL_ARGS);
+              else hipLaunchKernelGGL((k_ccl3_label<C3_LABEL_THREADS, 0, C3_ACC>), dim3((unsigned)(ctx->num_cu * agrid)), dim3(C3_LABEL_THREADS), lds3b, s, C3_LABEL_ARGS);
+#undef C3_LABEL_ARGS
+            }
             if (d_stats || d_centroids || acc3_own) {
                 vp_prof_scope ps(ctx, VPK_CCL_FINAL);
                 hipLaunchKernelGGL(k_ccl3_rows, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, G, P3, ws.c3_ncrowded, ws.c3_clist, ws.flags, ws.c3_child, ws.prefix,

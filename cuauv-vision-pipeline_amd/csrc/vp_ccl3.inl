@@ -30,6 +30,8 @@
 #define C3_LINK_THREADS 512    // k_ccl3_link, strips of up to 8192 ids; twice that for taller ones: a thread per 32-bit HALF of a word
 #define C3_LABEL_THREADS 512   // k_ccl3_label, likewise
 #define C3_ACC 2304            // local components whose statistics are accumulated per pass over the strip (the labelling launch has a CU's LDS to itself either way: one pass for raw noise at 10 % and 50 %)
+#define C3_LIGHT_ROOTS 1024    // strips with at most this many local roots are labelled by the LIGHT instantiation of k_ccl3_label: tables for that many roots
+#define C3_LIGHT_ACC 768       // ... and accumulators for that many per pass: ~72 KB of LDS, two blocks per CU hide each other's fixed latencies
 #define C3_TAB 128             // entries of a strip's table of partial components (beyond it: straight to global memory)
 #define C3_MAX_STRIPS 512      // per-strip root counts of a frame are scanned in LDS by every block of the later launches
 
@@ -518,13 +520,18 @@ __global__ __launch_bounds__(256) void k_ccl3_bound(const u64* __restrict__ bits
 // ---- ranks: one item per (handed-over frame, strip) once every boundary of the launch above is through ---------------------------------
 // ... and every local root that was absorbed gets the frame's root as its parent (the unions are complete, so that is final): the
 // labelling launch then finds the label of such a component's pieces with one look-up instead of a walk.
+// ... and the strip is marked for the labelling launch that suits it: LIGHT (few local roots: raw noise at 2 % and at 50 %, where
+// most of a strip is one component) or HEAVY.  klass[item] = 1 / 2; each labelling launch walks all items and takes its own (work lists
+// appended to with atomics were tried: thousands of blocks on one counter queue up at the memory side - this launch took 110 us
+// instead of 37 - and 64 sublists with a prefix per labelling block cost the labelling kernels registers they do not have).
 __global__ __launch_bounds__(256) void k_ccl3_rank(ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded, const u32* __restrict__ clist,
                                                    const u32* __restrict__ flags, u32* __restrict__ prefix, u32* __restrict__ barr,
-                                                   const u32* __restrict__ lrootbits, u32* __restrict__ parent)
+                                                   const u32* __restrict__ lrootbits, u32* __restrict__ parent, unsigned char* __restrict__ klass)
 {
     const u32 nc = *ncrowded;
     if (nc == 0) return;
     __shared__ u32 red[256 / 64 + 1];
+    __shared__ u32 nlocal;
     const u32 total = nc * (u32)P.strips;
     for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
         const u32 f = clist[item / (u32)P.strips];
@@ -535,6 +542,14 @@ __global__ __launch_bounds__(256) void k_ccl3_rank(ccl_geom G, c3_plan P, const 
             const u32* flr = lrootbits + (size_t)f * G.nw32;
             u32* fpar = parent + (size_t)f * G.nids;
             const u32 k0 = (u32)s * (P.ids / 32), k1 = (s == P.strips - 1) ? G.nw32 : min(k0 + P.ids / 32, G.nw32);
+            if (threadIdx.x == 0) nlocal = 0u;
+            __syncthreads();
+            u32 mine = 0;
+            for (u32 k = k0 + threadIdx.x; k < k1; k += 256) mine += (u32)__popc(flr[k]);
+            mine = c3_wave_add(mine);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&nlocal, mine);
+            __syncthreads();
+            if (threadIdx.x == 0) klass[item] = nlocal <= (u32)C3_LIGHT_ROOTS ? (unsigned char)1 : (unsigned char)2;
             for (u32 k = k0 + threadIdx.x; k < k1; k += 256) {
                 u32 m = flr[k] & ~ffl[k];                    // local roots of the strip that are no longer roots of the frame
                 while (m) {
@@ -555,9 +570,12 @@ __global__ __launch_bounds__(256) void k_ccl3_rank(ccl_geom G, c3_plan P, const 
 // One item per (handed-over frame, strip).  Everything about the strip is in LDS: its bits, the local rank of every segment's root
 // (u16; the link launch left root ids, rewritten here once the roots are ranked), the label and the id of every local root by rank,
 // the strip's slices of the bitmaps, statistics accumulators for C3_ACC components at a time, a small table of partial components.
-// dynamic LDS: lbits[R * ww] u64 | lab[ids / 2] u32 | lr16[ids] u16 | rid[ids / 2] u16 | lrb, lrp, gfl, gpf, gch [ids / 32] u32 | 6 x C3_ACC u32
-template <int AT>
+// dynamic LDS: lbits[R * ww] u64 | lab[nrmax] u32 | lr16[ids] u16 | rid[nrmax] u16 | lrb, lrp, gfl, gpf, gch [ids / 32] u32 | 5 x ACCN u32
+// Two instantiations share the items (k_ccl3_rank sorts the strips into two lists): NRCAP = 0 / ACCN = C3_ACC holds any strip (nrmax =
+// ids / 2 roots; a CU's LDS to itself), NRCAP = C3_LIGHT_ROOTS / ACCN = C3_LIGHT_ACC holds strips with few local roots in half the LDS.
+template <int AT, int NRCAP, int ACCN>
 __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bits, ccl_geom G, c3_plan P, const u32* __restrict__ ncrowded,
+                                                                 const unsigned char* __restrict__ klass,
                                                                  const u32* __restrict__ clist, const u32* __restrict__ parent,
                                                                  const u32* __restrict__ flags, const u32* __restrict__ child,
                                                                  const u32* __restrict__ prefix, const u32* __restrict__ lrootbits,
@@ -569,6 +587,7 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
 {
     const u32 nc = *ncrowded;
     if (nc == 0) return;
+    const u32 total = nc * (u32)P.strips;
     extern __shared__ __attribute__((aligned(16))) u64 c3_lds[];
     __shared__ u32 red[AT / 64 + 1];
     __shared__ u32 sbase[C3_MAX_STRIPS + 2];                   // roots in the strips before each strip
@@ -578,7 +597,7 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
     const int NT = AT;
     const int ww = G.ww, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwmax = P.R * ww;
-    const u32 nsl = P.ids / 32, nrmax = P.ids / 2;
+    const u32 nsl = P.ids / 32, nrmax = NRCAP ? (u32)NRCAP : P.ids / 2;
     u64* lbits = c3_lds;
     u32* lab = reinterpret_cast<u32*>(c3_lds + nwmax);
     unsigned short* lr16 = reinterpret_cast<unsigned short*>(lab + nrmax);
@@ -591,14 +610,19 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
     // area | sum of y | sum of x of a local component in ONE 64-bit word (16 | 20 | 28 bits: a strip holds at most 32,768 pixels in at
     // most 32 rows of at most 4,096 columns - c3_make_plan), so that a segment costs one LDS add for the three
     unsigned long long* a_pack = reinterpret_cast<unsigned long long*>(gch + nsl + (nsl & 1u));   // (five bitmaps of nsl words before it: an odd nsl leaves a gap of one word)
-    u32* a_minx = reinterpret_cast<u32*>(a_pack + C3_ACC);
-    u32* a_maxx = a_minx + C3_ACC;
-    u32* a_rows = a_maxx + C3_ACC;
+    u32* a_minx = reinterpret_cast<u32*>(a_pack + ACCN);
+    u32* a_maxx = a_minx + ACCN;
+    u32* a_rows = a_maxx + ACCN;
     const u64 lastmask = (G.w & 63) ? ((1ull << (G.w & 63)) - 1ull) : ~0ull;
     const u32 gpr = (u32)((G.w + 3) / 4);
-    const u32 total = nc * (u32)P.strips;
     C3_PROBE_DECL;
-    for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+    // The block's items, 64 at a time: every wave reads the classes of the same 64 (one round trip instead of one per item) and all of
+    // them walk the ones marked for this instantiation.
+    for (u32 it0 = blockIdx.x; it0 < total; it0 += 64u * gridDim.x)
+    for (unsigned long long todo = __ballot(it0 + (u32)(threadIdx.x & 63) * gridDim.x < total &&
+                                            klass[min(it0 + (u32)(threadIdx.x & 63) * gridDim.x, total - 1u)] == (NRCAP ? 1 : 2));
+         todo; todo &= todo - 1ull) {
+        const u32 item = it0 + (u32)(__ffsll((long long)todo) - 1) * gridDim.x;
         const u32 f = clist[item / (u32)P.strips];
         const int s = (int)(item % (u32)P.strips);
         const int y0 = s * P.R;
@@ -748,11 +772,11 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
         }
         __syncthreads();
         C3_PROBE(2);   // ranks in place of root ids
-        // ---- statistics per local component, C3_ACC components per pass ---------------------------------------------------------------
+        // ---- statistics per local component, ACCN components per pass ---------------------------------------------------------------
         contrib tot_c;
         contrib_zero(tot_c);
-        for (u32 c0 = 0; c0 < nroots && !(dbg & 8); c0 += C3_ACC) {
-            for (u32 k = tid; k < C3_ACC; k += NT) { a_pack[k] = 0ull; a_minx[k] = 0xffffffffu; a_maxx[k] = 0; a_rows[k] = 0; }
+        for (u32 c0 = 0; c0 < nroots && !(dbg & 8); c0 += ACCN) {
+            for (u32 k = tid; k < ACCN; k += NT) { a_pack[k] = 0ull; a_minx[k] = 0xffffffffu; a_maxx[k] = 0; a_rows[k] = 0; }
             __syncthreads();
             // Every segment adds to its component's accumulators.  A wave's lanes mostly name the same component when one is large (half
             // the pixels of 50 % noise belong to one): 64 LDS atomics on one word take 64 turns, so the lanes that agree with the first
@@ -772,7 +796,7 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
                         rem &= rem - 1;
                         const int eb = c3_run_end(w, sb);
                         k = (u32)lr16[c3_rel(G, r, 64 * j + sb)] - c0;
-                        act = k < (u32)C3_ACC;
+                        act = k < (u32)ACCN;
                         len = (u32)(eb - sb + 1);
                         xs = (u32)(64 * j + sb); xe = (u32)(64 * j + eb);
                         sxv = len * (xs + xe) / 2u; syv = len * (u32)r; rowbit = 1u << r;
@@ -804,13 +828,13 @@ __global__ __launch_bounds__(AT, 4) void k_ccl3_label(const u64* __restrict__ bi
             // join its label's entry of the strip's table, lanes of a wave that carry the same label combined with shuffles first (at
             // 50 % noise a strip holds about a thousand fragments of the one big component); the table goes to the frame's accumulators
             // once per strip, not once per fragment.
-            for (u32 kb = 0; kb < (u32)C3_ACC; kb += NT) {
+            for (u32 kb = 0; kb < (u32)ACCN; kb += NT) {
                 const u32 k = kb + (u32)tid;
                 bool commit = false;
                 u32 label = 0;
                 contrib c;
                 contrib_zero(c);
-                if (k < (u32)C3_ACC && c0 + k < nroots) {
+                if (k < (u32)ACCN && c0 + k < nroots) {
                     const u32 id = rid[c0 + k];
                     const u32 bit = 1u << (id & 31);
                     const unsigned long long pk = a_pack[k];
@@ -1017,7 +1041,8 @@ __global__ __launch_bounds__(256) void k_ccl3_rows(ccl_geom G, c3_plan P, const 
 }
 
 static size_t c3_link_lds(const ccl_geom& G, const c3_plan& P) { return (size_t)P.R * G.ww * 8 + (size_t)P.ids * 4 + (size_t)P.ids / 32 * 4; }
-static size_t c3_label_lds(const ccl_geom& G, const c3_plan& P)
+static size_t c3_label_lds(const ccl_geom& G, const c3_plan& P, size_t nrcap, size_t accn)
 {
-    return (size_t)P.R * G.ww * 8 + (size_t)P.ids / 2 * 4 + (size_t)P.ids * 2 + (size_t)P.ids / 2 * 2 + (size_t)P.ids / 32 * 4 * 5 + 8 + (size_t)C3_ACC * 4 * 5;
+    const size_t nrmax = nrcap ? nrcap : (size_t)P.ids / 2;
+    return (size_t)P.R * G.ww * 8 + nrmax * 4 + (size_t)P.ids * 2 + nrmax * 2 + (size_t)P.ids / 32 * 4 * 5 + 8 + accn * 4 * 5;
 }

@@ -52,7 +52,7 @@ struct vp_ctx {
     const u32* cb_folds_dev;      // colour balance: device counter of tiles whose running mean had to be folded (last call); null or cb_folds_own
     u32* cb_folds_own;            // context-owned device word the counter is copied to (the workspace it is made in is carved anew per call)
     int ccl_levels;               // 2: two-level labelling with the one-level kernels as fallback (default); 1: one-level only
-    size_t c3_lds_set[4];         // dynamic LDS the crowded-frame kernels have been allowed on THIS device (link, label; short and tall strips): the attribute is per device
+    size_t c3_lds_set[6];         // dynamic LDS the crowded-frame kernels have been allowed on THIS device (link, label; short and tall strips): the attribute is per device
     void* c3_acc;                 // crowded-frame labelling: accumulators of components that span strips, all empty between calls (vp_ccl.hip)
     size_t c3_acc_bytes;
     int c3_acc_dirty;             // a call was cut short after its labelling launch: reinitialise before the next use
@@ -179,6 +179,7 @@ struct vp_ccl_ws {           // per-batch scratch, all device pointers
     u32* c3_clist;           // [n]                    the frames handed over, in no particular order
     u32* c3_ncrowded;        // [1]                    their number
     void* c3_state;          // [n]                    per-frame counters and totals
+    unsigned char* c3_items; // [n * strips]: which labelling launch takes the strip (vp_ccl3.inl)
     u32* c3_barr;            // [n][strips + 1]        arrivals at every strip boundary
     void* c3_tot;            // [n][strips]            per strip: foreground sums and the box of its zero pixels (for the background row)
 };
