@@ -52,6 +52,14 @@ def lazy_enabled() -> bool:
     return _lazy
 
 
+def _prod(shape):
+    """Number of elements of a shape tuple (np.prod costs 2.5 us a call, and an image asks a dozen times per operator chain)."""
+    n = 1
+    for v in shape:
+        n *= v
+    return n
+
+
 class _Pool:
     """Free lists of device buffers of one context, by size class (hipMalloc / hipFree synchronise: never on the per-frame path).
     Everything on a context runs on its one stream, so a buffer released by the garbage collector can be handed to the next
@@ -136,7 +144,7 @@ class DeviceMat:
         self._ctx = ctx
         self._shape = tuple(int(s) for s in shape)
         self._dtype = np.dtype(dtype)
-        self._buf = _DevBuf(ctx, int(np.prod(self._shape)) * self._dtype.itemsize)
+        self._buf = _DevBuf(ctx, _prod(self._shape) * self._dtype.itemsize)
         self._off = 0                       # byte offset of this image inside its device allocation (planes of one frame share one)
         self._host = None
         self._dev_ok = True
@@ -175,7 +183,7 @@ class DeviceMat:
             self._pending = None
             if not self._ctx.handle:
                 raise _vp.VpError("the context that owns this image was closed before the image was computed")
-            self._buf = _DevBuf(self._ctx, int(np.prod(self._shape)) * self._dtype.itemsize)
+            self._buf = _DevBuf(self._ctx, _prod(self._shape) * self._dtype.itemsize)
             run(self)
 
     def _before_write(self):
@@ -290,8 +298,8 @@ class DeviceMat:
     shape = property(lambda self: self._shape)
     dtype = property(lambda self: self._dtype)
     ndim = property(lambda self: len(self._shape))
-    size = property(lambda self: int(np.prod(self._shape)))
-    nbytes = property(lambda self: int(np.prod(self._shape)) * self._dtype.itemsize)
+    size = property(lambda self: _prod(self._shape))
+    nbytes = property(lambda self: _prod(self._shape) * self._dtype.itemsize)
     itemsize = property(lambda self: self._dtype.itemsize)
 
     def __len__(self):

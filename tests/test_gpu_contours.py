@@ -359,3 +359,53 @@ def test_chain_contours_from_the_chains_own_labelling(vp, oracle, max_labels, nu
             exp, eh = oracle.find_contours(cl, mode, 2, with_holes=True)
             got, gh = out["contours"][f]
             assert _same(got, exp) and np.array_equal(gh, eh), (max_labels, mode, f, len(got), len(exp))
+
+
+def test_many_contours_come_back_lazily_and_are_traced_once(vp, oracle):
+    """A mask with thousands of contours (raw speckle: modules/red_buoy.py:38 runs findContours on the un-cleaned threshold mask): the
+    result is the same sequence of (N, 1, 2) views as the tuple for small masks - len, indexing, negative indices, slices, iteration,
+    max(key=) - made on demand, and from the second call on the buffers are large enough the first time (no second trace)."""
+    from vision.utils import feature
+    rng = np.random.default_rng(21)
+    mask = (rng.random((270, 480)) < 0.03).astype(np.uint8) * 255
+    exp = oracle.find_contours(mask, oracle.RETR_EXTERNAL, oracle.CHAIN_APPROX_SIMPLE)
+    assert len(exp) > feature.LazyContourList.THRESHOLD
+    feature._capacity.pop(mask.shape, None)
+    got = feature.outer_contours(mask)
+    assert isinstance(got, feature.LazyContourList) and len(got) == len(exp)
+    assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[-1], exp[-1]) and np.array_equal(got[len(exp) // 2], exp[len(exp) // 2])
+    assert got[0].shape[1:] == (1, 2) and got[0].dtype == np.int32
+    assert all(np.array_equal(a, b) for a, b in zip(got[3:9], exp[3:9])) and isinstance(got[3:9], tuple)
+    with pytest.raises(IndexError):
+        got[len(exp)]
+    big = max(got, key=feature.contour_area)
+    assert feature.contour_area(big) == max(feature.contour_area(c) for c in exp)
+    cap = feature._capacity[mask.shape]
+    assert cap[0] >= len(exp) and cap[1] >= sum(len(c) for c in exp)
+    calls = []
+    real = vp.lib().vp_find_contours_u8
+
+    class Counting:
+        def __getattr__(self, name):
+            if name == "vp_find_contours_u8":
+                def f(*a):
+                    calls.append(1)
+                    return real(*a)
+                return f
+            return getattr(vp.lib(), name)
+    import unittest.mock as mock
+    with mock.patch.object(feature._vp, "lib", lambda: Counting()):
+        again = feature.outer_contours(mask)
+    assert len(calls) == 1 and len(again) == len(exp)
+    # the overlay reads the point block of either kind of list
+    from vision.utils.draw import draw_contours
+    a, b = np.zeros((270, 480, 3), np.uint8), np.zeros((270, 480, 3), np.uint8)
+    draw_contours(a, got, thickness=1)
+    draw_contours(b, exp, thickness=1)
+    assert np.array_equal(a, b)
+    # a small mask afterwards: the tuple again, and the memory of the big one is dropped
+    small = np.zeros((270, 480), np.uint8)
+    small[10:20, 10:20] = 255
+    out = feature.outer_contours(small)
+    assert isinstance(out, tuple) and len(out) == 1 and mask.shape not in feature._capacity
