@@ -35,6 +35,9 @@ KERNEL_BYTES_PER_PX = {
     "k_morph_bits": 1.0 / 8 + 1 + 1.0 / 8,  # read bits, write cleaned mask + cleaned bits
     "k_ccl_write": 1.0 / 8 + 4,             # read bits, write int32 labels
 }
+# the same kernels by SURVEY 8d's own count (the images of the reference's pipeline only: 3 R + 1 W + 1 W + 4 W = 9 B/px; the bit planes
+# are this implementation's intermediates and are not in it) - reported beside the figure above as frac_8d
+KERNEL_BYTES_PER_PX_8D = {"k_color_thresh": 3 + 1, "k_morph_bits": 1, "k_ccl_write": 4}
 
 
 def parse():
@@ -51,7 +54,7 @@ def parse():
     ap.add_argument("--regions", type=int, default=5,
                     help="timed regions of exactly --steps steps each (every one bracketed by barrier + synchronize, MAX over ranks); "
                          "`value` comes from the median region (SURVEY 8d: median of 5)")
-    ap.add_argument("--traffic-file", default=os.path.join("profiles", "r03", "traffic.json"),
+    ap.add_argument("--traffic-file", default=os.path.join("profiles", "r04", "traffic.json"),
                     help="rocprofv3 --pmc summary (tools/pmc_traffic.py) to take roofline.traffic from; used only when its recorded "
                          "source digest equals the running build and it holds the exact kernel instantiation that was timed")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -104,6 +107,55 @@ def timed_steps(step_fn, sync_fn, steps, dist, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def host_fed_leg(dist, rank, world, device, width, height, batch=32, batches=8, ring=4, make_runner=None, chain=None, bind_numa=True):
+    """The host-fed form of the path on N ranks (BASELINE config 4; reference capture_sources/video.py:9-29 fans decoded frames out):
+    after a barrier EVERY rank feeds its slice `shard_of(batch, rank, world)` of each batch from host memory through pinned staging into
+    its own GPU (vision.dispatch.BatchDispatcher, feeder threads bound to the CPUs of that GPU's NUMA node) - the form in which host
+    memory bandwidth, PCIe and NUMA placement, not HBM, decide how N GPUs scale.  -> this rank's record; rank 0 also gets every
+    rank's record and the aggregate under "ranks" / "aggregate_frames_per_s".  `make_runner` replaces the device chain (CPU tests)."""
+    from vision import dispatch as D
+    frames = np.empty((batch, height, width, 3), np.uint8)
+    frames[:] = (np.arange(batch, dtype=np.uint8) * 7 + 1)[:, None, None, None]
+    chain = chain or {}
+    with D.BatchDispatcher([device], batch, height, width, chain=chain, rank=rank, world=world, ring=ring, make_runner=make_runner,
+                           bind_numa=bind_numa) as d:
+        lo, hi = d.slices[0]
+        d.submit(frames); d.collect()                     # contexts, staging, first launch
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        inflight = 0
+        for _ in range(batches):
+            d.submit(frames); inflight += 1
+            if inflight > ring:
+                d.collect(); inflight -= 1
+        while inflight:
+            d.collect(); inflight -= 1
+        dt = time.perf_counter() - t0
+        cpus = sorted(d.bound_cpus.get(device, ()))
+    node = None
+    try:
+        import ctypes as C_
+        from vision import _vp
+        buf = C_.create_string_buffer(32)
+        if make_runner is None and _vp.lib().vp_device_pci_bus_id(int(device), buf, 32) == 0:
+            node = D.numa_node_of_pci(buf.value.decode())
+    except Exception:
+        node = None
+    mine = {"rank": rank, "device": device, "frames_of_each_batch": [lo, hi], "frames_per_s": round(batches * (hi - lo) / dt, 1),
+            "pcie_GBps": round(batches * (hi - lo) * width * height * 3 / dt / 1e9, 2), "seconds": round(dt, 3), "numa_node": node,
+            "feeder_cpus_bound": len(cpus), "first_cpus": cpus[:4]}
+    if dist is None:
+        return dict(mine, ranks=[mine], aggregate_frames_per_s=mine["frames_per_s"], batches_per_s=round(batches / dt, 2))
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    if rank == 0:
+        slow = max(r["seconds"] for r in every)           # a batch is done when its slowest slice is
+        return dict(mine, ranks=every, aggregate_frames_per_s=round(batches * batch / slow, 1), batches_per_s=round(batches / slow, 2),
+                    aggregate_pcie_GBps=round(sum(r["pcie_GBps"] for r in every), 2))
+    return mine
 
 
 def main():
@@ -254,6 +306,11 @@ def main():
                 # the reference's default mode: every post() published for the GUI (core/base.py:846-876; --enable-performance is opt-in)
                 extras["runtime_e2e_red_buoy_posts_on"] = MH.runtime_rate("buoy", seconds=3.0, flags=())
                 extras["runtime_e2e_bins"] = MH.runtime_rate("bins", seconds=2.0)
+                # findContours of ONE image, the call modules/red_buoy.py:38 makes on the un-cleaned mask: clean and speckled masks
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import exp_contours_single
+                extras["contours_single_image"] = dict(exp_contours_single.measure(100), what="cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) of one "
+                                                       "1080p device image, contour list out: ms per call through vision.utils.feature.outer_contours, and of the C-ABI call alone")
                 up = MH.pcie_upload_rate(ctx)
                 for tag, (fw, fh, nb) in (("host_fed_1080p", (1920, 1080, 10)), ("host_fed_4k", (3840, 2160, 4))):
                     r = MH.host_fed_rate(fw, fh, batch=32, batches=nb, ring=4)
@@ -262,6 +319,20 @@ def main():
                     extras[tag] = r
         except Exception as e:   # a side measurement must not take the headline down with it; the failure is reported as such
             extras["runtime_rates_error"] = repr(e)
+
+    # N > 1: the host-fed leg on every rank at once (its own GPU, feeders on that GPU's NUMA node) - where scaling would bend first.
+    # `value` stays the resident-batch number.
+    if not args.no_extras and n_gpus > 1:
+        try:
+            chain = dict(color_mode=_vp.BGR2LAB, lo=(0, 150, 0), hi=(255, 255, 255), morph=morph, ccl=1, max_labels=args.max_labels, want=("stats",))
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):
+                leg = host_fed_leg(dist, rank, n_gpus, local_rank, 3840, 2160, batch=32, batches=6, ring=4, chain=chain)
+            if rank == 0:
+                extras["host_fed_4k_all_ranks"] = dict(leg, what="config 4: 32 4K frames per batch from host memory, frames [lo, hi) of every batch "
+                                                       "to rank r's GPU, statistics back; every rank at once after a barrier")
+        except Exception as e:
+            extras["host_fed_all_ranks_error"] = repr(e)
 
     # HBM-side bytes per launch (rocprofv3 PMC passes of THIS command with --no-extras --no-cpu-baseline: FETCH_SIZE and WRITE_SIZE in
     # separate runs, corrected as MI355X_MICROARCH.md prescribes, tools/pmc_traffic.py).  The file is named on the command line and is
@@ -299,8 +370,11 @@ def main():
         kb = KERNEL_BYTES_PER_PX[dom] * W * H * B
         achieved = kb / avg_s / 1e9
         inst, traffic = traffic_of(dom)
+        kb8 = KERNEL_BYTES_PER_PX_8D[dom] * W * H * B
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "achieved_8d": round(kb8 / avg_s / 1e9, 1), "frac_8d": round(kb8 / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_px": KERNEL_BYTES_PER_PX[dom], "bytes_per_px_8d": KERNEL_BYTES_PER_PX_8D[dom],
                 "traffic": traffic, "traffic_kernel": inst, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(kb), "avg_launch_us": round(1e6 * avg_s, 2),
                 "chain_achieved_GBps": round(alg_bytes_step / (1e-3 * ms_per_step) / 1e9, 1),

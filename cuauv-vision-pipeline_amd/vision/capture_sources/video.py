@@ -2,8 +2,10 @@
 """Plays a frame stack into one or more directions at the stack's frame rate.
 
 Mirror of the reference capture_sources/video.py:9-39 (one decoded frame per tick, fanned out to every listed
-direction).  cv2.VideoCapture is not available in this image, so the "video" is an `.npy` array (n, h, w, 3)
-(memory-mapped, so a 4K clip does not have to fit in RAM) or a directory of images."""
+direction).  DECODING IS THE CALLER'S: the reference opens the file with cv2.VideoCapture (capture_sources/video.py:14-20, a CPU
+decoder outside the measured path); no video decoder exists in this image, so this source plays frames that are already decoded - an
+`.npy` array (n, h, w, 3), memory-mapped so that a 4K clip does not have to fit in RAM.  Everything after the decoder - pacing, fan-out
+to the listed directions, the block writes - is the reference's behaviour."""
 import argparse
 
 import numpy as np

@@ -55,6 +55,80 @@ def test_config3_two_directions_two_streams(vp, oracle):
         assert np.array_equal(r["cleaned"][i], ref["cleaned"]) and np.array_equal(r["labels"][i], ref["labels"])
 
 
+def test_config3_bins_and_gate_modules_on_two_directions(vp, oracle, capsys):
+    """BASELINE config 3 with the modules themselves: the bins harness (modules/bins.py:11-81) on one camera direction and the gate
+    harness (modules/gate.py:8-21: post + normalize + latency) on another, both on the runtime at the same time, 1080p - every module's
+    loop thread has its own libvp context, i.e. its own HIP stream; bins' masks and contours equal the oracle's, the gate's post
+    (a device image, published by DMA) comes back bit-equal through a reference-layout reader."""
+    import glob
+    import os
+    import time
+    import module_harness as MH
+    from vision import cv2_facade
+    from vision.core.bindings.camera_message_framework import BlockAccessor
+    had_cv2 = sys.modules.get("cv2")
+    cv2_facade.install()
+    MH.module_argv()
+    W, H = 1920, 1080
+    pid = os.getpid()
+    d_bins, d_gate = f"pytc3bins{pid}", f"pytc3gate{pid}"
+    bins_frame, gate_frame = F.s2_bins(1, W, H), F.s1_buoy(1, W, H)
+    seen = {"bins": [], "gate": []}
+    streams = {}
+
+    def on_bins(mod, direction, img, out):
+        streams["bins"] = vp.lib().vp_get_stream(vp.default_context().handle)
+        cleaned, contours, valid, overlayed = out
+        seen["bins"].append((np.array(cleaned, copy=True), [np.array(c, copy=True) for c in contours], len(valid)))
+
+    def on_gate(mod, direction, image, norm, lat):
+        streams["gate"] = vp.lib().vp_get_stream(vp.default_context().handle)
+        seen["gate"].append(norm)
+
+    try:
+        with BlockAccessor(d_bins, max_entry_size_bytes=bins_frame.nbytes) as wb, BlockAccessor(d_gate, max_entry_size_bytes=gate_frame.nbytes) as wg:
+            bins_mod = MH.bins_module(on_bins)([d_bins], [])
+            gate_mod = MH.gate_module(on_gate)([d_gate], MH.gate_tuners())
+            bins_mod._fps = gate_mod._fps = 500
+            runners = [threading.Thread(target=bins_mod), threading.Thread(target=gate_mod)]
+            [t.start() for t in runners]
+            post = None
+            try:
+                t0 = time.time()
+                while (len(seen["bins"]) < 3 or len(seen["gate"]) < 3) and time.time() - t0 < 60:
+                    now = int(time.monotonic() * 1000)
+                    wb.write_frame(now, bins_frame)
+                    wg.write_frame(now, gate_frame)
+                    time.sleep(0.01)
+                hits = glob.glob(f"/dev/shm/auv_visiond_module_{gate_mod._name}_post%*%post_{d_gate}#BGR")
+                assert hits, "the gate module published no post block"
+                with BlockAccessor(hits[0][len("/dev/shm/auv_visiond_"):]) as rd:
+                    t0 = time.time()
+                    while post is None and time.time() - t0 < 5:
+                        st, data, _ = rd.read_frame()
+                        if data is not None:
+                            post = np.array(data, copy=True)
+                        time.sleep(0.005)
+            finally:
+                bins_mod.stop()
+                gate_mod.stop()
+                [t.join(15) for t in runners]
+    finally:
+        if had_cv2 is None:
+            sys.modules.pop("cv2", None)
+    capsys.readouterr()
+    assert len(seen["bins"]) >= 3 and len(seen["gate"]) >= 3
+    assert streams["bins"] != streams["gate"], "the two modules share a HIP stream"
+    th = oracle.inrange(oracle.bgr2hsv(bins_frame), (10, 20, 60), (30, 100, 255))
+    cl = oracle.morph(oracle.OPEN, th, np.ones((5, 5), np.uint8), fast=True)
+    exp = oracle.find_contours(cl, oracle.RETR_EXTERNAL, oracle.CHAIN_APPROX_SIMPLE)
+    cleaned, contours, nvalid = seen["bins"][-1]
+    assert np.array_equal(cleaned, cl) and len(contours) == len(exp) and all(np.array_equal(a, b) for a, b in zip(contours, exp))
+    assert seen["gate"][-1] == ((600 - H / 2) / W, (800 - W / 2) / W)
+    assert post is not None and np.array_equal(post, gate_frame)
+    assert gate_mod._posts.dma_posts >= 3 and gate_mod._posts.host_posts == 0
+
+
 def test_config4_4k_batch_shard(vp, oracle):
     sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
     import bench
