@@ -449,7 +449,8 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     __shared__ u32 par[C2_MCAP];
     __shared__ u32 lab[C2_MCAP];
     __shared__ u32 key[C2_MCAP];    // numbering key (smallest segment id); after the unions a root's entry holds its component's
-    __shared__ u32 rkeys[C2_MCAP];  // keys of the roots, compacted
+    __shared__ u32 rkeys[C2_MCAP];  // keys of the roots, compacted (few roots) or grouped by the strip their key lies in (many)
+    __shared__ u32 bbase[C2_MAXSTRIPS + 1], bfill[C2_MAXSTRIPS + 1];   // roots per key strip: exclusive prefix, fill pointer
     __shared__ u32 a_area[C2_MCAP];
     __shared__ int a_minx[C2_MCAP], a_maxx[C2_MCAP], a_miny[C2_MCAP], a_maxy[C2_MCAP];
     __shared__ u64 a_sx[C2_MCAP], a_sy[C2_MCAP];
@@ -598,23 +599,63 @@ __global__ __launch_bounds__(C2_THREADS) void k_ccl2_merge(const u64* __restrict
     }
     u32 R;
     u32 pos = c2_block_scan_excl(nroot_mine, wtot, &R);   // (its barriers also complete the keys)
+    // cv2's label of a component = 1 + number of components with a smaller key (keys are distinct).  With a handful of roots every
+    // root counts over all keys.  A speckled frame has hundreds (S1 with a loose threshold: 600 - 970), and R x R comparisons were 24 us
+    // of this launch: a key is a segment id, ids grow with the row, so the keys are grouped by the strip they lie in first - a root
+    // then counts the roots of earlier strips (a prefix) plus the smaller keys of its own group (R / strips of them).
+    const bool grouped = R > 64u;                        // block-uniform
+    const u32 ips = (u32)G.rows * (u32)G.wb;              // segment ids per strip, in either numbering
+    if (!grouped) {
 #pragma unroll
-    for (int q = 0; q < C2_PER; q++) {
-        const u32 i = (u32)tid + (u32)q * C2_THREADS;
-        if (i < C && root[q] == i) rkeys[pos++] = key[i];
-    }
-    __syncthreads();
-    C2_PROBE(1, 3);   // roots, keys, compacted
-    // cv2's label of a component = 1 + number of components with a smaller key (keys are distinct)
+        for (int q = 0; q < C2_PER; q++) {
+            const u32 i = (u32)tid + (u32)q * C2_THREADS;
+            if (i < C && root[q] == i) rkeys[pos++] = key[i];
+        }
+        __syncthreads();
+        C2_PROBE(1, 3);   // roots, keys, compacted
 #pragma unroll
-    for (int q = 0; q < C2_PER; q++) {
-        const u32 i = (u32)tid + (u32)q * C2_THREADS;
-        const bool isroot = i < C && root[q] == i;
-        if (__any(isroot)) {
-            const u32 mine = isroot ? key[i] : 0u;
-            u32 cnt = 0;
-            for (u32 j = 0; j < R; j++) cnt += rkeys[j] < mine ? 1u : 0u;
-            if (isroot) lab[i] = cnt + 1u;
+        for (int q = 0; q < C2_PER; q++) {
+            const u32 i = (u32)tid + (u32)q * C2_THREADS;
+            const bool isroot = i < C && root[q] == i;
+            if (__any(isroot)) {
+                const u32 mine = isroot ? key[i] : 0u;
+                u32 cnt = 0;
+                for (u32 j = 0; j < R; j++) cnt += rkeys[j] < mine ? 1u : 0u;
+                if (isroot) lab[i] = cnt + 1u;
+            }
+        }
+    } else {
+        for (int k = tid; k <= strips; k += C2_THREADS) bfill[k] = 0u;
+        __syncthreads();
+        u32 grp[C2_PER];
+#pragma unroll
+        for (int q = 0; q < C2_PER; q++) {
+            const u32 i = (u32)tid + (u32)q * C2_THREADS;
+            grp[q] = 0xffffffffu;
+            if (i < C && root[q] == i) { grp[q] = min(key[i] / ips, (u32)strips - 1u); atomicAdd(bfill + grp[q], 1u); }
+        }
+        __syncthreads();
+        u32 tot_unused;
+        const u32 cnt_mine = tid < strips ? bfill[tid] : 0u;          // (strips <= C2_MAXSTRIPS <= C2_THREADS)
+        const u32 ex2 = c2_block_scan_excl(cnt_mine, wtot, &tot_unused);
+        if (tid <= strips) { bbase[tid] = ex2; bfill[tid] = ex2; }    // tid == strips: the total
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < C2_PER; q++) {
+            const u32 i = (u32)tid + (u32)q * C2_THREADS;
+            if (grp[q] != 0xffffffffu) rkeys[atomicAdd(bfill + grp[q], 1u)] = key[i];
+        }
+        __syncthreads();
+        C2_PROBE(1, 3);   // roots, keys, grouped by strip
+#pragma unroll
+        for (int q = 0; q < C2_PER; q++) {
+            const u32 i = (u32)tid + (u32)q * C2_THREADS;
+            if (grp[q] != 0xffffffffu) {
+                const u32 mine = key[i], j0 = bbase[grp[q]], j1 = bbase[grp[q] + 1];
+                u32 cnt = j0;
+                for (u32 j = j0; j < j1; j++) cnt += rkeys[j] < mine ? 1u : 0u;
+                lab[i] = cnt + 1u;
+            }
         }
     }
     __syncthreads();
