@@ -98,9 +98,15 @@ __device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, con
     }
     if (!vert || y == 0) return;
     const u64 um = ccl_word(G, fb, idx - G.ww, j);
-    const u64 ul = (j > 0 && !G.conn4) ? ccl_word(G, fb, idx - G.ww - 1, j - 1) : 0ull;
+    const u64 ulw = j > 0 ? ccl_word(G, fb, idx - G.ww - 1, j - 1) : 0ull;
+    const u64 ul = G.conn4 ? 0ull : ulw;
     const u64 ur = (j + 1 < G.ww && !G.conn4) ? ccl_word(G, fb, idx - G.ww + 1, j + 1) : 0ull;
     if (!(um | (ul >> 63) | (ur & 1ull))) return;
+    // A run of this row that comes in from the word to the left, under a run of the row above that comes in from the left as well:
+    // the word to the left meets the same two runs at its bit 63 (and the runs are one component each once their rows' horizontal
+    // unions are made), so this word leaves the pair alone.  A row-wide run - the inverted mask of a contour pass is mostly that -
+    // otherwise costs one global union per word on one and the same pair of components.
+    const bool left_made_it = (w & 1ull) && (um & 1ull) && j > 0 && (ulw >> 63) && (ccl_word(G, fb, idx - 1, j - 1) >> 63);
     u64 rem = w;
     while (rem) {
         const int s = __ffsll((long long)rem) - 1;
@@ -109,6 +115,7 @@ __device__ __forceinline__ void global_link_word(const u64* __restrict__ fb, con
         rem &= ~S;
         const u32 me = seg_id(G, y, 64 * j + s);
         u64 c = um & (G.conn4 ? S : (S | (S << 1) | (S >> 1)));
+        if (s == 0 && left_made_it) c &= ~bit_range(0, run_end(um, 0));
         while (c) {
             const int b = __ffsll((long long)c) - 1;
             const int st = run_start(um, b), en = run_end(um, b);
