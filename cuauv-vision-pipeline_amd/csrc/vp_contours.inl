@@ -480,9 +480,10 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             }
             R = ct_ring(T, y, x);
         }
-        // (the successor's terminal mark is added by k_ct_jump: this pass needs the heads only, not the starts, so it can run beside
-        // the union-finds the starts come from)
-        if (!WRITE) nd[k] = ((unsigned long long)succ << 32) | cnt;
+        if (!WRITE) {
+            const u32 term = (hr[succ] != CT_NONE) ? CT_TERM : 0u;
+            nd[k] = ((unsigned long long)(succ | term) << 32) | cnt;
+        }
     }
 }
 
@@ -544,19 +545,14 @@ __device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, const ct_aux*
 __global__ __launch_bounds__(1024) void k_ct_jump(ccl_geom G, const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, size_t hcap,
                                                   const u32* __restrict__ starts, const u32* __restrict__ shead, int32_t* __restrict__ counts,
                                                   uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
-                                                  ct_frame_out* __restrict__ out, int max_contours, long long max_points, const u32* __restrict__ hrank)
+                                                  ct_frame_out* __restrict__ out, int max_contours, long long max_points)
 {
     __shared__ unsigned long long tab[CTJ_LDS];
     const int f = blockIdx.x;
     const u32 H = aux[f].nheads;
     unsigned long long* nd = node + (size_t)f * hcap;
-    const u32* hr = hrank + (size_t)f * hcap;
-    // a successor that is a terminal (k_ct_starts marked the head that owns a border's start state) ends the jumping there
-    auto with_term = [&](unsigned long long v) -> unsigned long long {
-        return (hr[(u32)(v >> 32)] != CT_NONE) ? (v | ((unsigned long long)CT_TERM << 32)) : v;
-    };
     if (H <= CTJ_LDS) {
-        for (u32 k = threadIdx.x; k < H; k += 1024) tab[k] = with_term(nd[k]);
+        for (u32 k = threadIdx.x; k < H; k += 1024) tab[k] = nd[k];
         __syncthreads();
         for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
             int changed = 0;
@@ -572,9 +568,6 @@ __global__ __launch_bounds__(1024) void k_ct_jump(ccl_geom G, const ct_aux* __re
         }
         for (u32 k = threadIdx.x; k < H; k += 1024) nd[k] = tab[k];
     } else {
-        for (u32 k = threadIdx.x; k < H; k += 1024) nd[k] = with_term(nd[k]);
-        __threadfence_block();
-        __syncthreads();
         for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
             int changed = 0;
             for (u32 k = threadIdx.x; k < H; k += 1024) {
@@ -750,15 +743,8 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
     const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
     hipStream_t side = ctx->fb_stream;
-    // A third branch when the call is small (a module's one image: every launch is a few microseconds of latency, not work): the head
-    // bitmaps, their prefix and the first follower pass need the mask only - not the union-finds - and run on a stream of their own
-    // beside both of them.  Batches keep them on the context's stream (large launches take turns on the chip, they do not overlap).
-    static const int third_env = getenv("VP_CT_THIRD") ? atoi(getenv("VP_CT_THIRD")) : -1;
-    const bool third = ctx->chain_streams == 1 && (third_env >= 0 ? third_env != 0 : (size_t)n * nwords <= (size_t)4 * 1080 * 30);   // (aux[0] serves sub-batches otherwise)
-    hipStream_t hs = third ? ctx->aux[0] : s;
     VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s));
     VP_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fb_fork, 0));
-    if (third) VP_HIP(ctx, hipStreamWaitEvent(hs, ctx->ev_fb_fork, 0));
     ctx->stream = side;
     int rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags, nullptr, outside);   // (clears `outside` on the way)
     ctx->stream = s;
@@ -767,14 +753,6 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     }
     // join whatever was queued on the side stream, also after an error
     const hipError_t j1 = hipEventRecord(ctx->ev_fb_join, side);
-    auto heads = [&]() {
-        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, hs, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2);
-        hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, hs, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
-        hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, hs, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
-                           max_contours, max_points);
-    };
-    if (third) heads();                                   // queued before the foreground's union-find so that all three branches start together
-    const hipError_t j3 = third ? hipEventRecord(ctx->ev_join[0], hs) : hipSuccess;
     {
         // the foreground's root bitmap: from the caller's labelling of the same mask when there is one (frames it could not hold keep
         // the union-find through its per-frame switch), otherwise the union-find for every frame
@@ -783,7 +761,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
         const bool use_known = known && !known_off && known->labels && known->stats && known->nlabels && known->max_labels >= 2 && known->max_labels <= 4096 &&
                                ccl_local_lds(Gf, cap_unused) <= 64 * 1024;
         if (rc == VP_OK && use_known) {
-            // (no early return in here: the side streams are joined below whatever happens, and the caller reuses the scratch after an error)
+            // (no early return in here: the side stream is joined below whatever happens, and the caller reuses the scratch after an error)
             u32* only = (u32*)vp_ws_take(ctx, (size_t)n * 4);
             if (!only) rc = vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
             if (rc == VP_OK) {
@@ -799,19 +777,22 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
             rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
         }
     }
-    if (!third) heads();
+    if (rc == VP_OK) {
+        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2);
+        hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
+    }
     const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_fb_join, 0) : j1;
-    const hipError_t j4 = (third && j3 == hipSuccess) ? hipStreamWaitEvent(s, ctx->ev_join[0], 0) : j3;
     if (rc != VP_OK) return rc;
     if (j1 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", j1);
     if (j2 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", j2);
-    if (j4 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "joining the head branch", j4);
     hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
                        outside, mode, startmap, holemap, selmap, partsum2, (int)nparts);
     hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, partsum2, &aux->nsel, hmaps, hbase, hrank, hcap, starts,
                        shead, max_contours);
+    hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
+                       max_contours, max_points);
     hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), 0, s, Gf, aux, node, hcap, starts, shead, d_counts, d_is_hole, d_offsets, d_points, info,
-                       max_contours, max_points, hrank);
+                       max_contours, max_points);
     hipLaunchKernelGGL((k_ct_seg<true>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
                        max_contours, max_points);
     VP_HIP(ctx, hipGetLastError());
