@@ -1363,11 +1363,30 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
             if (d->ccl == 1) ccl_bits = bits_a;
         }
     }
+    // Contours of a mask the chain also labels: the background half of the contour pass (the inverted mask's union-find: the long
+    // half, and latency-bound) needs the mask only, so it is queued on the side stream NOW and runs beside the chain's own labelling
+    // and its label write (bandwidth-bound) instead of after them.  Only when one pass takes the whole batch (the scratch is carved once).
+    void* early = nullptr;
+    const u64* csrc = cd ? (cd->source == 1 ? clean_bits : bits_t) : nullptr;
+    static const bool early_off = getenv("VP_CT_EARLY") && atoi(getenv("VP_CT_EARLY")) == 0;
+    if (cd && d->ccl && !early_off && ctx->chain_streams == 1 && ct_group_for(w, h, cd->max_contours) >= n)
+        VP_TRY(vpk_contours_begin(ctx, csrc, w, h, n, cd->max_contours, &early));
     if (d->ccl) {
-        VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
-                       b->nlabels ? b->nlabels : d_nl));
+        const int rc_ccl = vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
+                                   b->nlabels ? b->nlabels : d_nl);
+        if (rc_ccl != VP_OK) {
+            if (early) (void)vpk_contours_finish(ctx, early, csrc, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr);   // join the side stream
+            return rc_ccl;
+        }
     }
-    if (cd) {
+    if (cd && early) {
+        vp_known_labels kn = {nullptr, nullptr, nullptr, 0};
+        const bool same_mask = ccl_bits == csrc && b->labels && b->stats;
+        if (same_mask) { kn.labels = b->labels; kn.stats = b->stats; kn.nlabels = b->nlabels ? b->nlabels : d_nl; kn.max_labels = d->max_labels; }
+        VP_TRY(vpk_contours_finish(ctx, early, csrc, cd->mode, cd->method, cb->counts, cb->is_hole, cb->offsets, cb->points, cd->max_contours, cd->max_points,
+                                   cb->info, same_mask ? &kn : nullptr));
+        if (cb->features) VP_TRY(vpk_contour_features(ctx, cb->info, cb->counts, cb->offsets, cb->points, n, cd->max_contours, cd->max_points, cb->features));
+    } else if (cd) {
         const u64* src = cd->source == 1 ? clean_bits : bits_t;
         const size_t fw = (size_t)h * vp_ww(w);
         const size_t mc = (size_t)cd->max_contours;

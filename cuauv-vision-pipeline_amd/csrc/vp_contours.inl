@@ -685,15 +685,31 @@ __global__ __launch_bounds__(256) void k_ct_roots_from_labels(ccl_geom G, const 
     }
 }
 
-// d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
-// stored in discovery order (raster order of the start pixel); cv2 returns them reversed - the caller reverses.
-int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
-                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
-{
-    if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
-    if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
-    if ((size_t)w * h >= (1u << 29)) return vp_fail(ctx, VP_ERR_INVALID, "contours: image too large");
+// A contour pass in three steps, so that a caller with other work for the context's stream (the chain: its own labelling and the
+// label write, 260 us per 128 frames) can put it between the second and the third:
+//   ct_pass_setup        geometry, scratch carved from the workspace
+//   ct_pass_background   the background half - 4-connected union-find of the inverted mask, which regions reach the frame - queued
+//                        on the context's SIDE stream behind everything queued so far on its own stream
+//   ct_pass_finish       the foreground half, the join, seeds, starts, follower passes on the context's stream
+// vpk_find_contours runs the three back to back.
+struct ct_pass {
     ccl_geom Gf, Gb;
+    int w, h, n, nwords;
+    size_t hcap, nparts, mstride;
+    u32 *fg_parent, *bg_parent, *fg_flags, *bg_flags, *outside, *hbase, *head_pix, *hrank, *starts, *shead, *partsum, *partsum2;
+    u64 *maps3, *hmaps;
+    unsigned long long* node;
+    ct_aux* aux;
+    hipError_t bg_join;        // result of recording the side stream's end event
+    bool bg_queued;
+    int rc_bg;                 // what queueing the background half returned (vpk_contours_begin / _finish)
+};
+
+static int ct_pass_setup(vp_ctx* ctx, int w, int h, int n, int max_contours, ct_pass* P)
+{
+    if ((size_t)w * h >= (1u << 29)) return vp_fail(ctx, VP_ERR_INVALID, "contours: image too large");
+    ccl_geom& Gf = P->Gf;
+    ccl_geom& Gb = P->Gb;
     ccl_make_geom(Gf, w, h, VP_CCL_PIXEL, 0, 0);
     ccl_make_geom(Gb, w, h, VP_CCL_PIXEL, 1, 1);
     // One image (a module's findContours call) leaves most of the chip idle with 32-row strips (34 blocks at 1080p), and a block's
@@ -703,56 +719,83 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     if (!getenv("VP_CL_ROWS"))
         for (int r = 8; r < Gf.rows; r *= 2)
             if (((u32)r * (u32)Gf.wb) % 32u == 0 && (size_t)n * ((h + r - 1) / r) <= (size_t)2 * ctx->num_cu) { Gf.rows = Gb.rows = r; break; }
+    P->w = w; P->h = h; P->n = n;
     const size_t nids = Gf.nids;
-    const int nwords = h * Gf.ww;
-    const size_t words = (size_t)n * nwords;
-    const size_t hcap = ct_hcap(w, h);
-    u32* fg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
-    u32* bg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
-    u32* fg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
-    u32* bg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
-    u32* outside = (u32*)vp_ws_take(ctx, nids / 8 * n);
-    u64* maps3 = (u64*)vp_ws_take(ctx, 3 * vp_align(words * 8));   // startmap, holemap, selmap: cleared together
-    u64* hmaps = (u64*)vp_ws_take(ctx, words * 32);
-    u32* hbase = (u32*)vp_ws_take(ctx, words * 4);
+    P->nwords = h * Gf.ww;
+    const size_t words = (size_t)n * P->nwords;
+    P->hcap = ct_hcap(w, h);
+    P->fg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
+    P->bg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
+    P->fg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    P->bg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    P->outside = (u32*)vp_ws_take(ctx, nids / 8 * n);
+    P->maps3 = (u64*)vp_ws_take(ctx, 3 * vp_align(words * 8));   // startmap, holemap, selmap: cleared together
+    P->hmaps = (u64*)vp_ws_take(ctx, words * 32);
+    P->hbase = (u32*)vp_ws_take(ctx, words * 4);
     u32* sbase = (u32*)vp_ws_take(ctx, words * 4);   // (no longer written: k_ct_starts ranks the starts itself; kept so that the scratch layout stays as sized)
-    u32* head_pix = (u32*)vp_ws_take(ctx, hcap * n * 4);
-    u32* hrank = (u32*)vp_ws_take(ctx, hcap * n * 4);
-    unsigned long long* node = (unsigned long long*)vp_ws_take(ctx, hcap * n * 8);
-    u32* starts = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
-    u32* shead = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
-    ct_aux* aux = (ct_aux*)vp_ws_take(ctx, sizeof(ct_aux) * n);
-    const size_t nparts = (size_t)(nwords + 255) / 256;
-    u32* partsum = (u32*)vp_ws_take(ctx, nparts * n * 4);
-    u32* partsum2 = (u32*)vp_ws_take(ctx, nparts * n * 4);
-    if (!partsum || !partsum2 || !fg_parent || !bg_parent || !fg_flags || !bg_flags || !outside || !maps3 || !hmaps || !hbase || !sbase || !head_pix || !hrank || !node ||
-        !starts || !shead || !aux)
+    P->head_pix = (u32*)vp_ws_take(ctx, P->hcap * n * 4);
+    P->hrank = (u32*)vp_ws_take(ctx, P->hcap * n * 4);
+    P->node = (unsigned long long*)vp_ws_take(ctx, P->hcap * n * 8);
+    P->starts = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
+    P->shead = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
+    P->aux = (ct_aux*)vp_ws_take(ctx, sizeof(ct_aux) * n);
+    P->nparts = (size_t)(P->nwords + 255) / 256;
+    P->partsum = (u32*)vp_ws_take(ctx, P->nparts * n * 4);
+    P->partsum2 = (u32*)vp_ws_take(ctx, P->nparts * n * 4);
+    if (!P->partsum || !P->partsum2 || !P->fg_parent || !P->bg_parent || !P->fg_flags || !P->bg_flags || !P->outside || !P->maps3 || !P->hmaps || !P->hbase ||
+        !sbase || !P->head_pix || !P->hrank || !P->node || !P->starts || !P->shead || !P->aux)
         return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
-    const size_t mstride = vp_align(words * 8) / 8;
+    P->mstride = vp_align(words * 8) / 8;
+    P->bg_queued = false;
+    P->bg_join = hipSuccess;
+    return VP_OK;
+}
+
+// Background regions (4-connected union-find, then which of them reach the frame) on the context's side stream.  Always leaves the
+// side stream's end recorded in ev_fb_join (also after an error), for ct_pass_finish to wait on.
+static int ct_pass_background(vp_ctx* ctx, const u64* d_bits, ct_pass* P)
+{
+    hipStream_t s = ctx->stream;
+    hipStream_t side = ctx->fb_stream;
+    VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s));
+    VP_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fb_fork, 0));
+    ctx->stream = side;
+    int rc = ccl_roots(ctx, d_bits, P->Gb, P->n, P->bg_parent, P->bg_flags, nullptr, P->outside);   // (clears `outside` on the way)
+    ctx->stream = s;
+    if (rc == VP_OK)
+        hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * P->Gb.ww + 2 * P->h + 255) / 256), (unsigned)P->n), dim3(256), 0, side, d_bits, P->Gb, P->bg_parent,
+                           P->outside);
+    P->bg_join = hipEventRecord(ctx->ev_fb_join, side);
+    P->bg_queued = true;
+    return rc;
+}
+
+// d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
+// stored in discovery order (raster order of the start pixel); cv2 returns them reversed - the caller reverses.
+// `rc_bg`: what ct_pass_background returned (the side stream is joined whatever happened).
+static int ct_pass_finish(vp_ctx* ctx, const u64* d_bits, ct_pass* P, int rc_bg, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
+                          int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
+{
+    const ccl_geom& Gf = P->Gf;
+    const ccl_geom& Gb = P->Gb;
+    const int n = P->n, w = P->w, nwords = P->nwords;
+    const size_t hcap = P->hcap, nparts = P->nparts, mstride = P->mstride;
+    u32 *fg_parent = P->fg_parent, *bg_parent = P->bg_parent, *fg_flags = P->fg_flags, *bg_flags = P->bg_flags, *outside = P->outside, *hbase = P->hbase,
+        *head_pix = P->head_pix, *hrank = P->hrank, *starts = P->starts, *shead = P->shead, *partsum = P->partsum, *partsum2 = P->partsum2;
+    u64 *maps3 = P->maps3, *hmaps = P->hmaps;
+    unsigned long long* node = P->node;
+    ct_aux* aux = P->aux;
     u64* startmap = maps3;
     u64* holemap = maps3 + mstride;
     u64* selmap = maps3 + 2 * mstride;
     hipStream_t s = ctx->stream;
     ct_frame_out* info = reinterpret_cast<ct_frame_out*>(d_info);
-    // Two independent halves up to the seeds: background regions (4-connected union-find, then which of them reach the frame) on the
-    // context's side stream, foreground components and the head bitmaps on its own stream.  Each half is a chain of short,
-    // latency-bound launches, so side by side they take the time of one (one 1080p frame: 0.19 -> 0.15 ms per call).
     vp_prof_scope ps(ctx, VPK_OTHER);
     const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
     // heads per frame are not known on the host: a fixed number of blocks per frame walks the head list (a real mask has a few
     // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
     const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
-    hipStream_t side = ctx->fb_stream;
-    VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s));
-    VP_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fb_fork, 0));
-    ctx->stream = side;
-    int rc = ccl_roots(ctx, d_bits, Gb, n, bg_parent, bg_flags, nullptr, outside);   // (clears `outside` on the way)
-    ctx->stream = s;
-    if (rc == VP_OK) {
-        hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * Gb.ww + 2 * h + 255) / 256), (unsigned)n), dim3(256), 0, side, d_bits, Gb, bg_parent, outside);
-    }
-    // join whatever was queued on the side stream, also after an error
-    const hipError_t j1 = hipEventRecord(ctx->ev_fb_join, side);
+    int rc = rc_bg;
     {
         // the foreground's root bitmap: from the caller's labelling of the same mask when there is one (frames it could not hold keep
         // the union-find through its per-frame switch), otherwise the union-find for every frame
@@ -781,7 +824,10 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
         hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2);
         hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
     }
-    const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_fb_join, 0) : j1;
+    // join whatever was queued on the side stream, also after an error
+    const hipError_t j1 = P->bg_queued ? P->bg_join : hipSuccess;
+    const hipError_t j2 = (P->bg_queued && j1 == hipSuccess) ? hipStreamWaitEvent(s, ctx->ev_fb_join, 0) : j1;
+    P->bg_queued = false;
     if (rc != VP_OK) return rc;
     if (j1 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", j1);
     if (j2 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", j2);
@@ -797,4 +843,51 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
                        max_contours, max_points);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
+}
+
+// The same in two calls, for a caller that has other work for the context's stream in between (vp_api.hip chain_core: the background
+// half is queued as soon as the mask exists and runs beside the chain's own labelling and label write).  `*pass` is owned by the pair:
+// vpk_contours_finish frees it (also on failure); a caller that cannot reach finish calls it with d_counts == NULL to join and free.
+int vpk_contours_begin(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int max_contours, void** pass)
+{
+    ct_pass* P = new (std::nothrow) ct_pass();
+    if (!P) return vp_fail(ctx, VP_ERR_NOMEM, "contour pass");
+    int rc = ct_pass_setup(ctx, w, h, n, max_contours, P);
+    if (rc != VP_OK) { delete P; *pass = nullptr; return rc; }
+    P->rc_bg = ct_pass_background(ctx, d_bits, P);
+    *pass = P;
+    return VP_OK;          // (a failure of the background half is reported by finish, after the join)
+}
+
+int vpk_contours_finish(vp_ctx* ctx, void* pass, const u64* d_bits, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole, int32_t* d_offsets,
+                        int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
+{
+    ct_pass* P = static_cast<ct_pass*>(pass);
+    if (!P) return vp_fail(ctx, VP_ERR_INVALID, "contour pass");
+    int rc;
+    if (!d_counts) {       // abandoned: only the join
+        rc = (P->bg_queued && P->bg_join == hipSuccess && hipStreamWaitEvent(ctx->stream, ctx->ev_fb_join, 0) != hipSuccess) ? VP_ERR_HIP : VP_OK;
+    } else if ((mode != 0 && mode != 1) || (method != 1 && method != 2)) {
+        (void)(P->bg_queued && P->bg_join == hipSuccess && hipStreamWaitEvent(ctx->stream, ctx->ev_fb_join, 0));
+        rc = vp_fail(ctx, VP_ERR_INVALID, "contour mode / approximation");
+    } else {
+        rc = ct_pass_finish(ctx, d_bits, P, P->rc_bg, mode, method, d_counts, d_is_hole, d_offsets, d_points, max_contours, max_points, d_info, known);
+    }
+    delete P;
+    return rc;
+}
+
+int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
+                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
+{
+    if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
+    if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
+    ct_pass P;
+    const int rc_setup = ct_pass_setup(ctx, w, h, n, max_contours, &P);
+    if (rc_setup != VP_OK) return rc_setup;
+    // Two independent halves up to the seeds: background regions on the context's side stream, foreground components and the head
+    // bitmaps on its own stream.  Each half is a chain of short, latency-bound launches, so side by side they take the time of one
+    // (one 1080p frame: 0.19 -> 0.15 ms per call).
+    const int rc_bg = ct_pass_background(ctx, d_bits, &P);
+    return ct_pass_finish(ctx, d_bits, &P, rc_bg, mode, method, d_counts, d_is_hole, d_offsets, d_points, max_contours, max_points, d_info, known);
 }

@@ -197,6 +197,11 @@ struct vp_known_labels { const int32_t* labels; const int32_t* stats; const int3
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info,
                       const struct vp_known_labels* known = nullptr);
+// the same in two calls: begin queues the background half on the context's side stream, finish does the rest on its own stream (and
+// frees *pass; d_counts == NULL: join and free only)
+int vpk_contours_begin(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int max_contours, void** pass);
+int vpk_contours_finish(vp_ctx* ctx, void* pass, const u64* d_bits, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole, int32_t* d_offsets,
+                        int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known);
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
             int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels);
 
