@@ -339,3 +339,53 @@ def test_a_module_that_keeps_many_frames_still_gets_new_ones(vp):
         assert r._feeder is not None and r._feeder.out <= 2
         for k, img in enumerate(held):
             assert np.array_equal(np.asarray(img), frames[k]), f"held frame {k} changed"
+
+
+def test_posts_of_frame_planes_smaller_images_and_grey(vp):
+    """Shapes a module can post: a plane of a multi-plane frame (an image at an OFFSET inside the frame's one device allocation), a
+    2-D mask, an image smaller than the one the block was made for (the block keeps its size, the frame's metadata follow the image),
+    and an int16 device image (not uint8: converted on the host like any other array, as the reference's np.array(image, np.uint8))."""
+    from vision.devmat import DeviceMat
+    ctx = vp.default_context()
+    d = f"pytplanes{PID}"
+    a = F.s1_buoy(0, 320, 200)
+    depth = (np.arange(200 * 320, dtype=np.uint8).reshape(200, 320, 1) * 3).astype(np.uint8)
+    me = MH.PlainSelf((200, 320), True, tag="PostPlanes")
+    try:
+        with BlockAccessor(d, max_entry_size_bytes=a.nbytes + depth.nbytes) as w, BlockAccessor(d) as r:
+            w.write_frame(3, [("forward", a), ("depth", depth)])
+            t0 = time.time()
+            while True:
+                st, data, _, _ = r.read_frame_device()
+                if st == ReadStatus.SUCCESS or time.time() - t0 > 2:
+                    break
+                time.sleep(0.001)
+            assert st == ReadStatus.SUCCESS
+            fwd, dep = data
+            assert isinstance(dep, DeviceMat) and dep._off == a.nbytes          # the second plane starts behind the first
+            me.post("plane", dep, "GRAY")
+            me.post("whole", fwd)
+            me.flush(wait=True)
+            got, _ = _read(me.block_names()["plane#GRAY"])
+            assert got.shape == (200, 320, 1) and np.array_equal(got, depth)
+            assert np.array_equal(_read(me.block_names()["whole#BGR"])[0], a)
+        # a smaller image into the same block, then a 2-D one
+        small = DeviceMat.from_host(ctx, np.ascontiguousarray(a[:50, :64]))
+        me.post("whole", small)
+        me.flush(wait=True)
+        got, _ = _read(me.block_names()["whole#BGR"])
+        assert got.shape == (50, 64, 3) and np.array_equal(got, a[:50, :64])
+        mask = DeviceMat.from_host(ctx, np.ascontiguousarray(a[:, :, 0]))
+        me.post("whole", mask)
+        me.flush(wait=True)
+        got, _ = _read(me.block_names()["whole#BGR"])
+        assert got.shape == (200, 320, 1) and np.array_equal(got[:, :, 0], a[:, :, 0])
+        # not uint8 on the device: the host conversion path
+        i16 = DeviceMat.from_host(ctx, (a[:, :, 0].astype(np.int16) - 3))
+        before = me.queue.host_posts
+        me.post("i16", i16)
+        me.flush(wait=True)
+        assert me.queue.host_posts == before + 1
+        assert np.array_equal(_read(me.block_names()["i16#BGR"])[0][:, :, 0], np.array(a[:, :, 0].astype(np.int16) - 3, np.uint8))
+    finally:
+        me.close()
