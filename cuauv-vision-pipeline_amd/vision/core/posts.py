@@ -60,7 +60,10 @@ class _DmaPost:
         self._release_event()
         self.event, self.ctx, self.shape, self.keep = done.value, ctx, image.shape, image._buf
         self._pending = True
-        image._consumers.append(weakref.ref(self))
+        cs = image._consumers
+        if len(cs) > 8:                                         # an image posted over and over (a static overlay): drop what has long been published
+            cs[:] = [r for r in cs if (c := r()) is not None and c._pending is not None]
+        cs.append(weakref.ref(self))
 
     def _force(self):
         """Something is about to overwrite the image: the module's stream waits for the copy (DeviceMat._before_write)."""

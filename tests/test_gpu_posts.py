@@ -389,3 +389,19 @@ def test_posts_of_frame_planes_smaller_images_and_grey(vp):
         assert np.array_equal(_read(me.block_names()["i16#BGR"])[0][:, :, 0], np.array(a[:, :, 0].astype(np.int16) - 3, np.uint8))
     finally:
         me.close()
+
+
+def test_an_image_posted_over_and_over_does_not_collect_readers(vp):
+    """A long-lived image posted at every iteration (a static overlay) must not accumulate pending-reader entries."""
+    from vision.devmat import DeviceMat
+    ctx = vp.default_context()
+    img = DeviceMat.from_host(ctx, F.s1_buoy(0, 320, 200))
+    me = MH.PlainSelf((200, 320), True, tag="PostStatic")
+    try:
+        for _ in range(200):
+            me.post("s", img)
+            me.flush(wait=True)
+        assert len(img._consumers) <= 10
+        assert np.array_equal(_read(me.block_names()["s#BGR"])[0], F.s1_buoy(0, 320, 200)) and _uid(me.block_names()["s#BGR"]) == 200
+    finally:
+        me.close()
