@@ -188,6 +188,26 @@ def test_seqlock_under_thread_sanitizer(tmp_path):
     assert "bad 0" in run.stdout
 
 
+def test_seqlock_under_address_and_ub_sanitizers(tmp_path):
+    """The same harness (plain and deferred writes, aborts, three kinds of reader) built with -fsanitize=address,undefined: no
+    out-of-bounds access into the mapping or the frame buffers, no leak, no undefined behaviour (CPU build only: the GPU pool runs no
+    sanitizers)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is needed for the sanitizer build"
+    exe = str(tmp_path / "cmf_asan")
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-I" + os.path.join(root, "include"), os.path.join(root, "cuauv-vision-pipeline_amd", "csrc", "cmf.cpp"),
+                            os.path.join(root, "tests", "native", "cmf_tsan_main.cpp"), "-o", exe, "-lpthread", "-lrt"],
+                           capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "8000"], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert "Sanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-4000:]
+    assert run.returncode == 0 and "bad 0" in run.stdout, (run.returncode, run.stdout[-500:], run.stderr[-2000:])
+
+
 def test_reader_supplied_buffer():
     """cmf_frame_set_buffer (an addition to the reference's ABI): read_frame copies straight into memory the reader owns, refuses a
     buffer below the block's entry size without touching it, and goes back to a buffer of its own on request."""
