@@ -1369,7 +1369,10 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
     void* early = nullptr;
     const u64* csrc = cd ? (cd->source == 1 ? clean_bits : bits_t) : nullptr;
     static const bool early_off = getenv("VP_CT_EARLY") && atoi(getenv("VP_CT_EARLY")) == 0;
-    if (cd && d->ccl && !early_off && ctx->chain_streams == 1 && ct_group_for(w, h, cd->max_contours) >= n)
+    // (not when the contour pass may skip the background altogether: RETR_EXTERNAL of the very mask the chain labels, with its label
+    // image and statistics among the outputs - that decision needs the labelling, so the pass runs after it: vpk_find_contours)
+    const bool may_skip_bg = cd && d->ccl && cd->mode == VP_RETR_EXTERNAL && ccl_bits == csrc && b->labels && b->stats && d->max_labels >= 2 && d->max_labels <= 4096;
+    if (cd && d->ccl && !early_off && !may_skip_bg && ctx->chain_streams == 1 && ct_group_for(w, h, cd->max_contours) >= n)
         VP_TRY(vpk_contours_begin(ctx, csrc, w, h, n, cd->max_contours, &early));
     if (d->ccl) {
         const int rc_ccl = vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,

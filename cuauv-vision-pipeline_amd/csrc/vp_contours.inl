@@ -23,10 +23,12 @@ struct ct_frame_out {      // per frame, device
 };
 
 // outside[] bit per background root: the region touches the image frame
-__global__ __launch_bounds__(256) void k_ct_outside(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent, u32* __restrict__ outside)
+__global__ __launch_bounds__(256) void k_ct_outside(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent, u32* __restrict__ outside,
+                                                    const u32* __restrict__ only)
 {
     // one thread per frame-border word: rows 0 and h-1 fully, columns 0 and ww-1 of the other rows
     const int f = blockIdx.y;
+    if (only && !only[f]) return;                            // this frame's background was not resolved: nobody will ask
     const int nborder = 2 * G.ww + 2 * G.h;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nborder) return;
@@ -72,11 +74,14 @@ __device__ __forceinline__ void ct_root_pixel(const ccl_geom& G, const u64* __re
 __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, ccl_geom Gf, ccl_geom Gb, const u32* __restrict__ fg_flags,
                                                   const u32* __restrict__ bg_flags, const u32* __restrict__ bg_parent,
                                                   const u32* __restrict__ outside, int mode, u64* __restrict__ startmap, u64* __restrict__ holemap,
-                                                  u64* __restrict__ selmap, u32* __restrict__ partsum2, int nparts)
+                                                  u64* __restrict__ selmap, u32* __restrict__ partsum2, int nparts, const u32* __restrict__ bg_only)
 {
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (t >= Gf.nw32) return;
     const int f = blockIdx.y;
+    // RETR_EXTERNAL of a frame in which no component's box lies strictly inside another's (k_ct_needs_bg): every outer border is
+    // external and no hole border is asked for, so the background arrays of this frame were never made and are not looked at
+    const bool nobg = bg_only && !bg_only[f];
     const size_t fo = (size_t)f * Gf.h * Gf.ww;
     const u64* fb = bits + fo;
     u64* sm = startmap + fo;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
         int y, x;
         ct_root_pixel(Gf, fb, t * 32 + b, y, x);
         bool keep = true;
-        if (mode == 0 && x > 0) {   // RETR_EXTERNAL: the region left of the first pixel must reach the frame
+        if (mode == 0 && x > 0 && !nobg) {   // RETR_EXTERNAL: the region left of the first pixel must reach the frame
             const int xl = x - 1, j = xl >> 6;
             const u64 wb = ccl_word(Gb, fb, y * Gb.ww + j, j);
             u32 r = seg_id(Gb, y, 64 * j + run_start(wb, xl & 63));
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
         atomicOr((unsigned long long*)&sm[wi], 1ull << (x & 63));
         if (keep) select(wi, x & 63);
     }
-    u32 hb = bg_flags[(size_t)f * Gb.nw32 + t] & ~out[t];   // hole borders: background regions that do not reach the frame
+    u32 hb = nobg ? 0u : (bg_flags[(size_t)f * Gb.nw32 + t] & ~out[t]);   // hole borders: background regions that do not reach the frame
     while (hb) {
         const int b = __ffs((int)hb) - 1;
         hb &= hb - 1;
@@ -551,10 +556,13 @@ __global__ __launch_bounds__(1024) void k_ct_jump(ccl_geom G, const ct_aux* __re
     const int f = blockIdx.x;
     const u32 H = aux[f].nheads;
     unsigned long long* nd = node + (size_t)f * hcap;
+    // A cycle that holds a terminal is through after ceil(log2(its heads)) rounds; a cycle without one (a hole border whose start was not
+    // looked for: k_ct_seeds with `nobg`) never is - so the rounds are bounded by the head count, not only by "nothing changed".
+    const int max_rounds = min(CT_JUMP_ROUNDS, 34 - __clz((int)(H | 1u)));
     if (H <= CTJ_LDS) {
         for (u32 k = threadIdx.x; k < H; k += 1024) tab[k] = nd[k];
         __syncthreads();
-        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
+        for (int round = 0; round < max_rounds; round++) {
             int changed = 0;
             for (u32 k = threadIdx.x; k < H; k += 1024) {
                 const unsigned long long v = tab[k];
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(1024) void k_ct_jump(ccl_geom G, const ct_aux* __re
         }
         for (u32 k = threadIdx.x; k < H; k += 1024) nd[k] = tab[k];
     } else {
-        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
+        for (int round = 0; round < max_rounds; round++) {
             int changed = 0;
             for (u32 k = threadIdx.x; k < H; k += 1024) {
                 const unsigned long long v = __hip_atomic_load(nd + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -685,6 +693,30 @@ __global__ __launch_bounds__(256) void k_ct_roots_from_labels(ccl_geom G, const 
     }
 }
 
+// RETR_EXTERNAL with the components' boxes at hand (the chain has just labelled this mask): a component inside a hole of another one
+// has that one's pixels on all four sides, so its box lies STRICTLY inside the other's.  A frame without such a pair of boxes has only
+// external components: its background - the long half of a contour pass - is not needed at all.  bg_only[f] = 1: resolve it (a pair
+// exists, or the statistics table did not hold all labels, or there are too many labels to compare in passing).  grid n x 256.
+#define CT_NEEDS_BG_MAX 512
+__global__ __launch_bounds__(256) void k_ct_needs_bg(const int32_t* __restrict__ stats, const int32_t* __restrict__ nlabels, int max_labels,
+                                                     u32* __restrict__ bg_only)
+{
+    const int f = blockIdx.x;
+    const int nl = nlabels[f];
+    if (nl > max_labels || nl > CT_NEEDS_BG_MAX) { if (threadIdx.x == 0) bg_only[f] = 1u; return; }
+    const int32_t* st = stats + (size_t)f * max_labels * 5;
+    int found = 0;
+    for (int a = 1 + (int)threadIdx.x; a < nl && !found; a += 256) {
+        const int ax0 = st[a * 5], ay0 = st[a * 5 + 1], ax1 = ax0 + st[a * 5 + 2] - 1, ay1 = ay0 + st[a * 5 + 3] - 1;
+        for (int b = 1; b < nl; b++) {
+            const int bx0 = st[b * 5], by0 = st[b * 5 + 1], bx1 = bx0 + st[b * 5 + 2] - 1, by1 = by0 + st[b * 5 + 3] - 1;
+            if (bx0 < ax0 && by0 < ay0 && bx1 > ax1 && by1 > ay1) { found = 1; break; }
+        }
+    }
+    const int any = __syncthreads_or(found);
+    if (threadIdx.x == 0) bg_only[f] = any ? 1u : 0u;
+}
+
 // A contour pass in three steps, so that a caller with other work for the context's stream (the chain: its own labelling and the
 // label write, 260 us per 128 frames) can put it between the second and the third:
 //   ct_pass_setup        geometry, scratch carved from the workspace
@@ -692,6 +724,14 @@ __global__ __launch_bounds__(256) void k_ct_roots_from_labels(ccl_geom G, const 
 //                        on the context's SIDE stream behind everything queued so far on its own stream
 //   ct_pass_finish       the foreground half, the join, seeds, starts, follower passes on the context's stream
 // vpk_find_contours runs the three back to back.
+static bool ct_known_usable(const vp_known_labels* known, const ccl_geom& Gf)
+{
+    size_t cap_unused;
+    static const bool known_off = getenv("VP_CT_KNOWN") && atoi(getenv("VP_CT_KNOWN")) == 0;
+    return known && !known_off && known->labels && known->stats && known->nlabels && known->max_labels >= 2 && known->max_labels <= 4096 &&
+           ccl_local_lds(Gf, cap_unused) <= 64 * 1024;
+}
+
 struct ct_pass {
     ccl_geom Gf, Gb;
     int w, h, n, nwords;
@@ -700,6 +740,7 @@ struct ct_pass {
     u64 *maps3, *hmaps;
     unsigned long long* node;
     ct_aux* aux;
+    u32* bg_only;              // nullable, per frame: 1 = the background is resolved, 0 = not needed (k_ct_needs_bg)
     hipError_t bg_join;        // result of recording the side stream's end event
     bool bg_queued;
     int rc_bg;                 // what queueing the background half returned (vpk_contours_begin / _finish)
@@ -746,6 +787,7 @@ static int ct_pass_setup(vp_ctx* ctx, int w, int h, int n, int max_contours, ct_
         !sbase || !P->head_pix || !P->hrank || !P->node || !P->starts || !P->shead || !P->aux)
         return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
     P->mstride = vp_align(words * 8) / 8;
+    P->bg_only = nullptr;
     P->bg_queued = false;
     P->bg_join = hipSuccess;
     return VP_OK;
@@ -760,11 +802,11 @@ static int ct_pass_background(vp_ctx* ctx, const u64* d_bits, ct_pass* P)
     VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s));
     VP_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fb_fork, 0));
     ctx->stream = side;
-    int rc = ccl_roots(ctx, d_bits, P->Gb, P->n, P->bg_parent, P->bg_flags, nullptr, P->outside);   // (clears `outside` on the way)
+    int rc = ccl_roots(ctx, d_bits, P->Gb, P->n, P->bg_parent, P->bg_flags, P->bg_only, P->outside);   // (clears `outside` on the way)
     ctx->stream = s;
     if (rc == VP_OK)
         hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * P->Gb.ww + 2 * P->h + 255) / 256), (unsigned)P->n), dim3(256), 0, side, d_bits, P->Gb, P->bg_parent,
-                           P->outside);
+                           P->outside, P->bg_only);
     P->bg_join = hipEventRecord(ctx->ev_fb_join, side);
     P->bg_queued = true;
     return rc;
@@ -799,10 +841,7 @@ static int ct_pass_finish(vp_ctx* ctx, const u64* d_bits, ct_pass* P, int rc_bg,
     {
         // the foreground's root bitmap: from the caller's labelling of the same mask when there is one (frames it could not hold keep
         // the union-find through its per-frame switch), otherwise the union-find for every frame
-        size_t cap_unused;
-        static const bool known_off = getenv("VP_CT_KNOWN") && atoi(getenv("VP_CT_KNOWN")) == 0;
-        const bool use_known = known && !known_off && known->labels && known->stats && known->nlabels && known->max_labels >= 2 && known->max_labels <= 4096 &&
-                               ccl_local_lds(Gf, cap_unused) <= 64 * 1024;
+        const bool use_known = ct_known_usable(known, Gf);
         if (rc == VP_OK && use_known) {
             // (no early return in here: the side stream is joined below whatever happens, and the caller reuses the scratch after an error)
             u32* only = (u32*)vp_ws_take(ctx, (size_t)n * 4);
@@ -832,7 +871,7 @@ static int ct_pass_finish(vp_ctx* ctx, const u64* d_bits, ct_pass* P, int rc_bg,
     if (j1 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", j1);
     if (j2 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", j2);
     hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
-                       outside, mode, startmap, holemap, selmap, partsum2, (int)nparts);
+                       outside, mode, startmap, holemap, selmap, partsum2, (int)nparts, P->bg_only);
     hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, partsum2, &aux->nsel, hmaps, hbase, hrank, hcap, starts,
                        shead, max_contours);
     hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
@@ -888,6 +927,13 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     // Two independent halves up to the seeds: background regions on the context's side stream, foreground components and the head
     // bitmaps on its own stream.  Each half is a chain of short, latency-bound launches, so side by side they take the time of one
     // (one 1080p frame: 0.19 -> 0.15 ms per call).
+    static const bool skip_off = getenv("VP_CT_SKIP_BG") && atoi(getenv("VP_CT_SKIP_BG")) == 0;
+    if (mode == 0 && !skip_off && ct_known_usable(known, P.Gf)) {
+        // RETR_EXTERNAL of a mask whose components' boxes are known: frames without nested boxes skip the background half
+        P.bg_only = (u32*)vp_ws_take(ctx, (size_t)n * 4);
+        if (!P.bg_only) return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
+        hipLaunchKernelGGL(k_ct_needs_bg, dim3((unsigned)n), dim3(256), 0, ctx->stream, known->stats, known->nlabels, known->max_labels, P.bg_only);
+    }
     const int rc_bg = ct_pass_background(ctx, d_bits, &P);
     return ct_pass_finish(ctx, d_bits, &P, rc_bg, mode, method, d_counts, d_is_hole, d_offsets, d_points, max_contours, max_points, d_info, known);
 }

@@ -409,3 +409,49 @@ def test_many_contours_come_back_lazily_and_are_traced_once(vp, oracle):
     small[10:20, 10:20] = 255
     out = feature.outer_contours(small)
     assert isinstance(out, tuple) and len(out) == 1 and mask.shape not in feature._capacity
+
+
+def test_external_contours_of_nested_components_from_the_chains_labelling(vp, oracle):
+    """RETR_EXTERNAL when the chain has labelled the same mask: frames in which no component's box lies strictly inside another's skip
+    the background half of the contour pass (every component is external then); frames WITH such a pair resolve it as before - a blob
+    inside the hole of a ring is not external, a blob inside the BOX of an L-shaped component but outside its pixels is.  Both kinds in
+    one batch, with holes that are never asked for; against the oracle."""
+    from vision import _vp
+    from vision.utils import chain
+    h, w = 160, 256
+    red, black = (0, 0, 255), (0, 0, 0)                      # LAB a = 208 / 128: foreground / background of a[150, 255]
+
+    def frame(draw):
+        m = np.zeros((h, w), bool)
+        draw(m)
+        f = np.zeros((h, w, 3), np.uint8)
+        f[m] = red
+        return f
+
+    def ring_with_blob(m):                                    # nested: the inner blob is NOT external
+        m[20:120, 30:200] = True; m[35:105, 45:185] = False; m[60:80, 100:130] = True
+
+    def ring_with_ring_with_blob(m):                          # two levels: only the outermost ring is external
+        m[10:150, 10:240] = True; m[20:140, 20:230] = False
+        m[40:120, 60:200] = True; m[50:110, 70:190] = False; m[70:90, 120:140] = True
+
+    def l_shape_and_blob(m):                                  # the blob's box lies inside the L's box, the blob itself outside the L: external
+        m[20:140, 20:40] = True; m[120:140, 20:220] = True; m[40:70, 100:160] = True
+
+    def apart(m):                                             # no nested boxes: the background half is skipped (holes exist, nobody asks)
+        m[10:60, 10:90] = True; m[25:45, 30:60] = False; m[90:150, 120:240] = True; m[100:110, 130:140] = False; m[70:75, 5:9] = True
+
+    def touching_frame(m):
+        m[0:30, 0:50] = True; m[h - 20:h, w - 60:w] = True; m[60:100, 100:160] = True; m[70:90, 115:145] = False; m[76:84, 125:135] = True
+
+    frames = np.stack([frame(d) for d in (ring_with_blob, apart, ring_with_ring_with_blob, l_shape_and_blob, touching_frame, apart)])
+    for max_labels in (64, 3):
+        out = chain.run_chain(frames, _vp.BGR2LAB, (0, 150, 0), (255, 255, 255), (), ccl=1, max_labels=max_labels, want=("threshed", "labels", "stats"),
+                              contours=dict(source="threshed", mode=0, method=2, max_contours=64, max_points=1 << 13))
+        for f in range(len(frames)):
+            th = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(frames[f])[:, :, 1]), 150, 255)
+            assert np.array_equal(out["threshed"][f], th)
+            exp, eh = oracle.find_contours(th, 0, 2, with_holes=True)
+            got, gh = out["contours"][f]
+            assert _same(got, exp) and np.array_equal(gh, eh), (max_labels, f, len(got), len(exp))
+    assert len(out["contours"][0][0]) == 1 and len(out["contours"][2][0]) == 1 and len(out["contours"][3][0]) == 2 and len(out["contours"][1][0]) == 3
