@@ -189,7 +189,7 @@ __device__ __forceinline__ void ct_block_sum(u32 c, u32* __restrict__ partsum)
 // (also clears this word of the three seed bitmaps and the block's entry of the selected-start partial sums, which k_ct_seeds fills
 // afterwards: one launch instead of a memset, this one and a counting pass)
 __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps, u32* __restrict__ partsum,
-                                                     u64* __restrict__ maps3, size_t mstride, u32* __restrict__ partsum2)
+                                                     u64* __restrict__ maps3, size_t mstride, u32* __restrict__ partsum2, uint8_t* __restrict__ cnt8)
 {
     const int nwords = G.h * G.ww;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -211,10 +211,15 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
             hn = c & ~n[2] & el & (n[1] | n[0]);
             hs = c & ~n[6] & el & (n[5] | n[4]);
         }
-        ulonglong2* o = reinterpret_cast<ulonglong2*>(hmaps + ((size_t)f * nwords + idx) * 4);
-        o[0] = make_ulonglong2(hw, he);
-        o[1] = make_ulonglong2(hn, hs);
         cnt = (u32)(__popcll(hw) + __popcll(he) + __popcll(hn) + __popcll(hs));
+        // The bitmaps are only ever read back for words that hold a head (the head list, ct_head_index); every word's COUNT is what the
+        // prefix needs.  A mask is mostly words without heads: 1 byte per word instead of 32 (132 -> 4 MB per 128 frames of 1080p).
+        cnt8[(size_t)f * nwords + idx] = (uint8_t)cnt;       // (at most 4 x 64 heads, and a word with 256 would need every pixel to be two heads)
+        if (cnt) {
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(hmaps + ((size_t)f * nwords + idx) * 4);
+            o[0] = make_ulonglong2(hw, he);
+            o[1] = make_ulonglong2(hn, hs);
+        }
     }
     ct_block_sum(cnt, partsum);
 }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
 // grid (ceil(nwords/256), n): block b adds up the block sums before it, then scans its 256 words.
 __global__ __launch_bounds__(256) void k_ct_prefix(const u64* __restrict__ maps, int nm, int nwords, const u32* __restrict__ partsum,
                                                    u32* __restrict__ base, u32* __restrict__ total_out, int tstride, int w, int ww,
-                                                   u32* __restrict__ head_pix, u32* __restrict__ hrank, size_t hcap)
+                                                   u32* __restrict__ head_pix, u32* __restrict__ hrank, size_t hcap, const uint8_t* __restrict__ cnt8)
 {
     __shared__ u32 wsum[4], wtot[4];
     const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -235,8 +240,10 @@ __global__ __launch_bounds__(256) void k_ct_prefix(const u64* __restrict__ maps,
     if (lane == 0) wtot[wv] = c;
     const int i = blockIdx.x * 256 + tid;
     u32 cnt = 0;
-    if (i < nwords)
-        for (int t = 0; t < nm; t++) cnt += (u32)__popcll(maps[((size_t)f * nwords + i) * nm + t]);
+    if (i < nwords) {
+        if (cnt8) cnt = cnt8[(size_t)f * nwords + i];         // the counts k_ct_headmaps left (the bitmaps of words without heads were never stored)
+        else for (int t = 0; t < nm; t++) cnt += (u32)__popcll(maps[((size_t)f * nwords + i) * nm + t]);
+    }
     u32 inc = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
@@ -737,6 +744,7 @@ struct ct_pass {
     int w, h, n, nwords;
     size_t hcap, nparts, mstride;
     u32 *fg_parent, *bg_parent, *fg_flags, *bg_flags, *outside, *hbase, *head_pix, *hrank, *starts, *shead, *partsum, *partsum2;
+    uint8_t* cnt8;             // heads per word
     u64 *maps3, *hmaps;
     unsigned long long* node;
     ct_aux* aux;
@@ -773,7 +781,8 @@ static int ct_pass_setup(vp_ctx* ctx, int w, int h, int n, int max_contours, ct_
     P->maps3 = (u64*)vp_ws_take(ctx, 3 * vp_align(words * 8));   // startmap, holemap, selmap: cleared together
     P->hmaps = (u64*)vp_ws_take(ctx, words * 32);
     P->hbase = (u32*)vp_ws_take(ctx, words * 4);
-    u32* sbase = (u32*)vp_ws_take(ctx, words * 4);   // (no longer written: k_ct_starts ranks the starts itself; kept so that the scratch layout stays as sized)
+    u32* sbase = (u32*)vp_ws_take(ctx, words * 4);   // (the first quarter holds the per-word head counts; the rest is unused since k_ct_starts ranks the starts itself)
+    P->cnt8 = reinterpret_cast<uint8_t*>(sbase);
     P->head_pix = (u32*)vp_ws_take(ctx, P->hcap * n * 4);
     P->hrank = (u32*)vp_ws_take(ctx, P->hcap * n * 4);
     P->node = (unsigned long long*)vp_ws_take(ctx, P->hcap * n * 8);
@@ -860,8 +869,8 @@ static int ct_pass_finish(vp_ctx* ctx, const u64* d_bits, ct_pass* P, int rc_bg,
         }
     }
     if (rc == VP_OK) {
-        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2);
-        hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap);
+        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2, P->cnt8);
+        hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap, P->cnt8);
     }
     // join whatever was queued on the side stream, also after an error
     const hipError_t j1 = P->bg_queued ? P->bg_join : hipSuccess;
