@@ -1094,6 +1094,17 @@ int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, int 
     return vpk_inrange_u8(ctx, d_src, src_stride, w, h, cn, q, d_dst);
 }
 
+int vp_inrange_u8_bits_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, int w, int h, int cn, const int32_t* lo, const int32_t* hi, uint8_t* d_dst,
+                           unsigned long long* d_bits, int* made_bits)
+{
+    VP_TRY(check_ctx(ctx));
+    if (!d_src || !d_dst || !lo || !hi || w <= 0 || h <= 0 || h > 65535 || (cn != 1 && cn != 3) || src_stride < (size_t)w * cn)
+        return vp_fail(ctx, VP_ERR_INVALID, "vp_inrange_u8_bits_dev arguments");
+    vp_range3 q;
+    norm_range(cn, lo, hi, &q);
+    return vpk_inrange_u8(ctx, d_src, src_stride, w, h, cn, q, d_dst, reinterpret_cast<u64*>(d_bits), made_bits);
+}
+
 // The polylines of vp_draw_polylines_u8 drawn into a packed device image (bins.py draws its rectangles into an overlay that only ever
 // leaves the device when it is posted).  Points and counts are host arrays; the same pixels as the host rasteriser.
 int vp_draw_polylines_dev(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* pts, const int32_t* counts, int npolys, int closed,
@@ -1192,13 +1203,13 @@ int vp_ccl_u8(vp_ctx* ctx, const uint8_t* src, size_t src_stride, int w, int h, 
     return vp_synchronize(ctx);
 }
 
-// src: host image (uploaded) or, with src_on_device, a device image read in place
+// src: host image (uploaded) or, with src_on_device, a device image read in place; or (bits_in) its bit-packed form, already on the device
 static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_device, size_t src_stride, int w, int h, int mode, int method,
                               int32_t* points, int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours,
-                              int64_t* n_points)
+                              int64_t* n_points, const u64* bits_in = nullptr)
 {
     VP_TRY(check_ctx(ctx));
-    if (!src || w <= 0 || h <= 0 || src_stride < (size_t)w || !n_contours || !n_points || max_contours < 0 || max_points < 0)
+    if ((!src && !bits_in) || w <= 0 || h <= 0 || (!bits_in && src_stride < (size_t)w) || !n_contours || !n_points || max_contours < 0 || max_points < 0)
         return vp_fail(ctx, VP_ERR_INVALID, "vp_find_contours arguments");
     const size_t npx = (size_t)w * h;
     const size_t bitbytes = (size_t)h * vp_ww(w) * 8;
@@ -1218,10 +1229,15 @@ static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_devic
     int32_t* d_counts = reinterpret_cast<int32_t*>(d_hdr + 16);
     int32_t* d_offsets = d_counts + mc;
     uint8_t* d_hole = reinterpret_cast<uint8_t*>(d_offsets + mc);
-    if (src_on_device) { d_src = src; d_stride = src_stride; }
-    else VP_TRY(h2d_rows(ctx, d_stage, (size_t)w, src, src_stride, (size_t)w, h));
-    VP_TRY(vpk_pack_bits(ctx, d_src, d_stride, w, h, 1, d_bits, nullptr));
-    VP_TRY(vpk_find_contours(ctx, d_bits, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info));
+    const u64* bits_use = d_bits;
+    if (bits_in) {
+        bits_use = bits_in;                               // the caller made the bit plane with the mask (vp_inrange_u8_bits_dev): no packing launch
+    } else {
+        if (src_on_device) { d_src = src; d_stride = src_stride; }
+        else VP_TRY(h2d_rows(ctx, d_stage, (size_t)w, src, src_stride, (size_t)w, h));
+        VP_TRY(vpk_pack_bits(ctx, d_src, d_stride, w, h, 1, d_bits, nullptr));
+    }
+    VP_TRY(vpk_find_contours(ctx, bits_use, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info));
     // the header and the first points come back under one synchronisation; longer point lists take a second copy
     const size_t spec_pts = points ? (size_t)std::min<long long>(mp, 8192) : 0;
     const size_t hdr_pad = vp_align(hdr_bytes);
@@ -1279,6 +1295,13 @@ int vp_find_contours_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, i
                          int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours, int64_t* n_points)
 {
     return find_contours_impl(ctx, d_src, true, src_stride, w, h, mode, method, points, max_points, counts, is_hole, max_contours, n_contours, n_points);
+}
+
+int vp_find_contours_bits_dev(vp_ctx* ctx, const unsigned long long* d_bits, int w, int h, int mode, int method, int32_t* points, int64_t max_points,
+                              int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours, int64_t* n_points)
+{
+    return find_contours_impl(ctx, nullptr, true, 0, w, h, mode, method, points, max_points, counts, is_hole, max_contours, n_contours, n_points,
+                              reinterpret_cast<const u64*>(d_bits));
 }
 
 // ---- chain -------------------------------------------------------------------------------------------

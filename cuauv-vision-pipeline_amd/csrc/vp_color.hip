@@ -627,8 +627,11 @@ __global__ __launch_bounds__(256) void k_inrange_f32(const float* __restrict__ s
 
 // Flat form: packed rows, 16-B aligned; lane = 16 px = CN 16-B loads and one 16-B store.  Per channel one unsigned comparison
 // (in_span); ranges are kernel arguments, so an empty one costs nothing per pixel.
-template <int CN>
-__global__ __launch_bounds__(256) void k_inrange_u8_flat(const uint8_t* __restrict__ src, size_t ngroups, vp_range3 q, uint8_t* __restrict__ dst)
+// WBITS: also the bit-packed mask (w % 64 == 0, so the four 16-px groups of a word are four neighbouring lanes that leave together):
+// what the contour pass and the bit-plane morphology would otherwise make with a launch of their own (k_pack_bits).
+template <int CN, bool WBITS>
+__global__ __launch_bounds__(256) void k_inrange_u8_flat(const uint8_t* __restrict__ src, size_t ngroups, vp_range3 q, uint8_t* __restrict__ dst,
+                                                         u64* __restrict__ bits)
 {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= ngroups) return;
@@ -647,16 +650,30 @@ __global__ __launch_bounds__(256) void k_inrange_u8_flat(const uint8_t* __restri
         out[k >> 2] |= (ok ? 0xffu : 0u) << (8 * (k & 3));
     }
     vp_store16(dst + g * 16, out[0], out[1], out[2], out[3]);
+    if constexpr (WBITS) {
+        u32 m = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m |= ((out[k >> 2] >> (8 * (k & 3))) & 1u) << k;
+        u64 wv = (u64)m << (16 * (threadIdx.x & 3));
+        wv |= __shfl_xor(wv, 1);
+        wv |= __shfl_xor(wv, 2);
+        if ((threadIdx.x & 3) == 0) bits[g >> 2] = wv;
+    }
 }
 
-int vpk_inrange_u8(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int cn, const vp_range3& q, uint8_t* d_dst)
+// d_bits (nullable): the bit-packed mask as well, when the flat form runs and w % 64 == 0; *made_bits tells whether it was written
+int vpk_inrange_u8(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int cn, const vp_range3& q, uint8_t* d_dst, u64* d_bits, int* made_bits)
 {
     const size_t npx = (size_t)w * h, ngroups = npx / 16;
     const bool flat = ctx->flat_ops && (cn == 1 || cn == 3) && (stride == (size_t)w * cn || h == 1) && ngroups > 0 && aligned16(d_src) && aligned16(d_dst);
+    const bool wbits = flat && d_bits && (w % 64) == 0;
+    if (made_bits) *made_bits = wbits ? 1 : 0;
     if (flat) {
         const dim3 grid((unsigned)((ngroups + 255) / 256));
-        if (cn == 1) hipLaunchKernelGGL((k_inrange_u8_flat<1>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst);
-        else hipLaunchKernelGGL((k_inrange_u8_flat<3>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst);
+        if (cn == 1 && wbits) hipLaunchKernelGGL((k_inrange_u8_flat<1, true>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst, d_bits);
+        else if (cn == 1) hipLaunchKernelGGL((k_inrange_u8_flat<1, false>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst, (u64*)nullptr);
+        else if (wbits) hipLaunchKernelGGL((k_inrange_u8_flat<3, true>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst, d_bits);
+        else hipLaunchKernelGGL((k_inrange_u8_flat<3, false>), grid, dim3(256), 0, ctx->stream, d_src, ngroups, q, d_dst, (u64*)nullptr);
         const size_t done = ngroups * 16;
         if (done < npx)
             hipLaunchKernelGGL(k_inrange_u8, dim3(1, 1), dim3(256), 0, ctx->stream, d_src + done * cn, (size_t)0, (int)(npx - done), 1, cn, q, d_dst + done);

@@ -105,7 +105,7 @@ int vpk_color_thresh(vp_ctx* ctx, int mode, const uint8_t* d_bgr, size_t stride,
 int vpk_cvt_color(vp_ctx* ctx, int code, const uint8_t* d_src, size_t stride, int w, int h, uint8_t* d_dst,
                   uint8_t* d_p0, uint8_t* d_p1, uint8_t* d_p2);
 int vpk_inrange_u8(vp_ctx* ctx, const uint8_t* d_src, size_t stride, int w, int h, int cn, const vp_range3& r,
-                   uint8_t* d_dst);
+                   uint8_t* d_dst, u64* d_bits = nullptr, int* made_bits = nullptr);
 int vpk_inrange_f32(vp_ctx* ctx, const float* d_src, size_t stride_bytes, int w, int h, float lo, float hi,
                     uint8_t* d_dst);
 int vpk_kth_f32(vp_ctx* ctx, const float* d_src, size_t n, size_t k, u32* d_hist, float* out);

@@ -136,6 +136,9 @@ _SIGS = {
     "vp_post_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_post_fence": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_post_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vp_inrange_u8_bits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "vp_find_contours_bits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "vp_memcpy_d2d_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vp_draw_polylines_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),

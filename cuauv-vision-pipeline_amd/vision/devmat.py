@@ -138,7 +138,7 @@ class DeviceMat:
     """(h, w) or (h, w, c) image, tightly packed, whose authoritative copy may be on the device (`_dev_ok`), on the host
     (`_host` is not None and `_host_ok`), or both."""
     __array_priority__ = 100.0
-    __slots__ = ("_ctx", "_buf", "_off", "_shape", "_dtype", "_host", "_dev_ok", "_escaped", "binary", "_pending", "_consumers", "__weakref__")
+    __slots__ = ("_ctx", "_buf", "_off", "_shape", "_dtype", "_host", "_dev_ok", "_escaped", "binary", "_pending", "_consumers", "_bits", "__weakref__")
 
     def __init__(self, ctx, shape, dtype=np.uint8, binary=False):
         self._ctx = ctx
@@ -152,6 +152,7 @@ class DeviceMat:
         self.binary = bool(binary)          # known to hold only 0 / 255 (a mask made by this library)
         self._pending = None
         self._consumers = []                # shared with every reshaped() alias: pending operators that read this image
+        self._bits = None                   # a mask's bit-packed form, made with it (range_threshold); gone with the first write
 
     @classmethod
     def deferred(cls, ctx, shape, dtype, binary, inputs, run):
@@ -160,7 +161,7 @@ class DeviceMat:
         handed to the host for writing - so the result is always the one an immediate launch would have given."""
         m = object.__new__(cls)
         m._ctx, m._shape, m._dtype = ctx, tuple(int(s) for s in shape), np.dtype(dtype)
-        m._buf, m._off, m._host, m._dev_ok, m._escaped, m.binary, m._consumers = None, 0, None, True, False, bool(binary), []
+        m._buf, m._off, m._host, m._dev_ok, m._escaped, m.binary, m._consumers, m._bits = None, 0, None, True, False, bool(binary), [], None
         m._pending = run
         for x in inputs:
             if len(x._consumers) > 8:
@@ -174,7 +175,7 @@ class DeviceMat:
         moved out of its ring slot with one copy (vision.core.bindings.camera_message_framework.BlockAccessor.read_frame_device)."""
         m = object.__new__(cls)
         m._ctx, m._shape, m._dtype = ctx, tuple(int(s) for s in shape), np.dtype(dtype)
-        m._buf, m._off, m._host, m._dev_ok, m._escaped, m.binary, m._consumers, m._pending = buf, int(offset), None, True, False, False, [], None
+        m._buf, m._off, m._host, m._dev_ok, m._escaped, m.binary, m._consumers, m._pending, m._bits = buf, int(offset), None, True, False, False, [], None, None
         return m
 
     def _force(self):
@@ -189,6 +190,7 @@ class DeviceMat:
     def _before_write(self):
         """Pending operators that read this image run before its contents can change (host-side writes and in-place device writes
         alike; the list is shared by every reshaped() alias of the image)."""
+        self._bits = None                        # the bit plane describes the contents as they were
         cs = self._consumers
         if cs:
             pending = cs[:]
@@ -234,6 +236,7 @@ class DeviceMat:
         m = object.__new__(DeviceMat)
         m._ctx, m._buf, m._off, m._dtype, m._dev_ok, m.binary = self._ctx, self._buf, self._off, self._dtype, self._dev_ok, self.binary
         m._pending, m._consumers, m._escaped = None, self._consumers, self._escaped
+        m._bits = None                           # (an alias is not told when the image is written to: it does not inherit the bit plane)
         m._shape = tuple(int(x) for x in shape)
         m._host = None if self._host is None else self._host.reshape(m._shape)
         if not self._dev_ok and m._host is None:

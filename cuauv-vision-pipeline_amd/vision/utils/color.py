@@ -191,6 +191,17 @@ def range_threshold(mat: np.ndarray, min, max) -> np.ndarray:
     if on_device:
         try:
             out = DeviceMat(ctx, (h, w), binary=True)
+            if w % 64 == 0:
+                # the mask's bit-packed form comes out of the same launch (1/8 B/px more): the contour pass of this very mask
+                # (modules/red_buoy.py:38 outer_contours(threshed)) then needs no packing launch of its own
+                from vision.devmat import _DevBuf
+                bits = _DevBuf(ctx, h * (w // 64) * 8)
+                made = _vp.C.c_int(0)
+                _vp.check(_vp.lib().vp_inrange_u8_bits_dev(ctx.handle, mat.dev_ptr, w * cn, w, h, cn, _vp.ptr(lo), _vp.ptr(hi), out.dev_ptr, bits.ptr,
+                                                          _vp.C.byref(made)), ctx.handle)
+                if made.value:
+                    out._bits = bits
+                return out
             _vp.check(_vp.lib().vp_inrange_u8_dev(ctx.handle, mat.dev_ptr, w * cn, w, h, cn, _vp.ptr(lo), _vp.ptr(hi), out.dev_ptr), ctx.handle)
             return out
         finally:

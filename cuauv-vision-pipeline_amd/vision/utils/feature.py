@@ -204,7 +204,12 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
         counts = np.empty(max_c, np.int32)
         holes = np.empty(max_c, np.uint8)
         nc, npts = _vp.C.c_int32(0), _vp.C.c_int64(0)
-        if dev is not None:
+        bits = getattr(dev, "_bits", None) if dev is not None else None
+        if bits is not None and dev._dev_ok and dev._ctx is ctx:
+            # the mask came with its bit plane (range_threshold) and has not been written to since: no packing launch
+            _vp.check(_vp.lib().vp_find_contours_bits_dev(ctx.handle, bits.ptr, w, h, int(mode), int(method), _vp.ptr(pts), max_p,
+                                                          _vp.ptr(counts), _vp.ptr(holes), max_c, _vp.C.byref(nc), _vp.C.byref(npts)), ctx.handle)
+        elif dev is not None:
             _vp.check(_vp.lib().vp_find_contours_dev(ctx.handle, dev.dev_ptr, w, w, h, int(mode), int(method), _vp.ptr(pts), max_p,
                                                      _vp.ptr(counts), _vp.ptr(holes), max_c, _vp.C.byref(nc), _vp.C.byref(npts)), ctx.handle)
         else:

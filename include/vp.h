@@ -195,6 +195,12 @@ int vp_cvt_color_dev(vp_ctx* ctx, int code, const uint8_t* src_dev, size_t src_s
                      uint8_t* const* dst_planes_dev);
 int vp_inrange_u8_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, int w, int h, int cn, const int32_t* lo, const int32_t* hi,
                       uint8_t* dst_dev);
+/* vp_inrange_u8_dev that can also leave the mask's BIT-PACKED form ((h, ceil(w / 64)) u64, bit i of word j = pixel 64 j + i) in bits_dev
+ * (nullable): written when rows are packed, pointers 16-B aligned and w % 64 == 0 - *made_bits says whether (otherwise bits_dev is
+ * untouched).  vp_find_contours_bits_dev takes that plane in place of the image and saves the packing launch: the pair serves
+ * range_threshold -> outer_contours (modules/red_buoy.py:22, :38) when the mask has not been written to in between. */
+int vp_inrange_u8_bits_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, int w, int h, int cn, const int32_t* lo, const int32_t* hi,
+                           uint8_t* dst_dev, unsigned long long* bits_dev, int* made_bits);
 int vp_morph_u8_dev(vp_ctx* ctx, int op, const uint8_t* src_dev, int w, int h, int cn, const uint8_t* kernel, int kw, int kh,
                     int anchor_x, int anchor_y, int iterations, int binary_hint, uint8_t* dst_dev);
 /* vp_draw_polylines_u8 into a packed device image (points and counts are host arrays): the same pixels, written by the device, so
@@ -205,6 +211,9 @@ int vp_draw_polylines_dev(vp_ctx* ctx, uint8_t* img_dev, int w, int h, int cn, c
  * saturate(round-half-even(a*alpha + b*beta + gamma)) in correctly rounded doubles; dst may be one of the sources. */
 int vp_add_weighted_u8_dev(vp_ctx* ctx, const uint8_t* a_dev, double alpha, const uint8_t* b_dev, double beta, double gamma, size_t n,
                            uint8_t* dst_dev);
+int vp_find_contours_bits_dev(vp_ctx* ctx, const unsigned long long* bits_dev, int w, int h, int mode, int method, int32_t* points_host,
+                              int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours, int32_t* n_contours,
+                              int64_t* n_points);
 int vp_find_contours_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, int w, int h, int mode, int method,
                          int32_t* points_host, int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours,
                          int32_t* n_contours, int64_t* n_points);

@@ -455,3 +455,66 @@ def test_external_contours_of_nested_components_from_the_chains_labelling(vp, or
             got, gh = out["contours"][f]
             assert _same(got, exp) and np.array_equal(gh, eh), (max_labels, f, len(got), len(exp))
     assert len(out["contours"][0][0]) == 1 and len(out["contours"][2][0]) == 1 and len(out["contours"][3][0]) == 2 and len(out["contours"][1][0]) == 3
+
+
+def test_threshold_masks_carry_their_bit_plane_to_the_contour_pass(vp, oracle):
+    """range_threshold of a device image with w % 64 == 0 leaves the mask's bit-packed form with the mask; outer_contours of that very
+    mask takes it (vp_find_contours_bits_dev: no packing launch) - same contours as the oracle's; the plane is dropped by anything that
+    writes to the mask (an in-place draw on the device, a host-side write), after which the contours follow the new contents; other
+    widths and aliases never carry one."""
+    from vision.devmat import DeviceMat
+    from vision.utils import color, feature
+    from vision.utils.draw import draw_contours
+    ctx = vp.default_context()
+    calls = []
+    real = vp.lib().vp_find_contours_bits_dev
+
+    def count_bits_entry():
+        import unittest.mock as mock
+
+        class Counting:
+            def __getattr__(self, name):
+                if name == "vp_find_contours_bits_dev":
+                    def f(*a):
+                        calls.append(1)
+                        return real(*a)
+                    return f
+                return getattr(vp.lib(), name)
+        return mock.patch.object(feature._vp, "lib", lambda: Counting())
+
+    for w, h in ((1920, 1080), (640, 360), (64, 5)):
+        frame = F.s1_buoy(3, w, h)
+        a = color.bgr_to_lab(DeviceMat.from_host(ctx, frame))[1][1]
+        th = color.range_threshold(a, 150, 255)
+        assert isinstance(th, DeviceMat) and th._bits is not None and th._host is None
+        exp_mask = oracle.inrange(np.ascontiguousarray(oracle.bgr2lab(frame)[:, :, 1]), 150, 255)
+        del calls[:]
+        with count_bits_entry():
+            got = feature.outer_contours(th)
+        assert calls == [1], "the contour pass did not take the bit plane"
+        assert _same(got, oracle.find_contours(exp_mask, 0, 2)) and np.array_equal(np.asarray(th), exp_mask)
+        # three-channel inRange makes one too
+        hsv = color.bgr_to_hsv(DeviceMat.from_host(ctx, frame))[0]
+        m3 = color.range_threshold(hsv, (0, 30, 60), (180, 255, 255))
+        assert m3._bits is not None
+        assert _same(feature.all_contours(m3), oracle.find_contours(oracle.inrange(oracle.bgr2hsv(frame), (0, 30, 60), (180, 255, 255)), 1, 2))
+    # an in-place device write drops the plane; the contours are those of the new contents
+    frame = F.s1_buoy(1, 640, 360)
+    th = color.range_threshold(color.bgr_to_lab(DeviceMat.from_host(ctx, frame))[1][1], 150, 255)
+    box = [np.array([[100, 100], [300, 100], [300, 250], [100, 250]], np.int32).reshape(-1, 1, 2)]
+    draw_contours(th, box, color=255, thickness=3)
+    assert th._bits is None and th._host is None
+    now = np.asarray(th).copy()
+    assert now[100, 200] == 255
+    th2 = DeviceMat.from_host(ctx, now, binary=True)
+    assert _same(feature.outer_contours(th), oracle.find_contours(now, 0, 2)) and _same(feature.outer_contours(th2), oracle.find_contours(now, 0, 2))
+    # a host-side write likewise
+    th = color.range_threshold(color.bgr_to_lab(DeviceMat.from_host(ctx, frame))[1][1], 150, 255)
+    th[50:60, 50:70] = 255
+    assert th._bits is None
+    assert _same(feature.outer_contours(th), oracle.find_contours(np.asarray(th), 0, 2))
+    # widths that are not a multiple of 64, and reshaped aliases: no plane, the ordinary entry
+    th = color.range_threshold(color.bgr_to_lab(DeviceMat.from_host(ctx, F.s1_buoy(2, 250, 100)))[1][1], 150, 255)
+    assert th._bits is None
+    th = color.range_threshold(color.bgr_to_lab(DeviceMat.from_host(ctx, frame))[1][1], 150, 255)
+    assert th.reshaped((360, 640, 1))._bits is None
