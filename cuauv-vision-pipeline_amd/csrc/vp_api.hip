@@ -1237,7 +1237,13 @@ static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_devic
         else VP_TRY(h2d_rows(ctx, d_stage, (size_t)w, src, src_stride, (size_t)w, h));
         VP_TRY(vpk_pack_bits(ctx, d_src, d_stride, w, h, 1, d_bits, nullptr));
     }
-    VP_TRY(vpk_find_contours(ctx, bits_use, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info));
+    // one block does the bookkeeping between the two follower passes - unless the last pass of this context met a speckled mask
+    // (tens of thousands of border segments): then it is launched over the chip (VP_CT_MANY=0 / 1: never / always)
+    const char* many_s = getenv("VP_CT_MANY");
+    const int many_env = many_s ? atoi(many_s) : -1;
+    const bool many = many_env >= 0 ? many_env != 0 : ctx->ct_heads_hint > 16384u;
+    VP_TRY(vpk_find_contours(ctx, bits_use, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info, many,
+                             reinterpret_cast<uint32_t*>(d_info + 2)));
     // the header and the first points come back under one synchronisation; longer point lists take a second copy
     const size_t spec_pts = points ? (size_t)std::min<long long>(mp, 8192) : 0;
     const size_t hdr_pad = vp_align(hdr_bytes);
@@ -1251,6 +1257,7 @@ static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_devic
     }
     VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t* info = reinterpret_cast<const int32_t*>(hs);
+    ctx->ct_heads_hint = (uint32_t)info[2];
     const int K = info[0];
     const int64_t P = info[1];
     *n_contours = K;
@@ -1333,12 +1340,13 @@ static size_t chain_ws_bytes(const vp_chain_desc* d, int n)
 }
 
 // core: all pointers device; workspace already reserved and not yet carved past `ctx->ws_off`
-// frames per contour pass: the contour scratch is about 26 B/px per frame (50 MB at 1080p); a pass takes as many frames as fit
-// a budget of 8 GiB (VP_CT_SCRATCH_MB overrides) - measured at 1080p, batch 128: 16 frames per pass 2.26 ms, 64 1.57 ms, 128 1.40 ms
+// frames per contour pass: the contour scratch is about 41 B/px per frame (85 MB at 1080p: sized for the worst case of 1.25 heads per
+// pixel); a pass takes as many frames as fit a budget of 16 GiB (VP_CT_SCRATCH_MB overrides) - measured at 1080p, batch 128 (round 3): 16
+// frames per pass 2.26 ms, 64 1.57 ms, 128 1.40 ms
 static int ct_group_for(int w, int h, int max_contours)
 {
     const char* e = getenv("VP_CT_SCRATCH_MB");
-    long long budget = (e ? atoll(e) : 8192ll) << 20;
+    long long budget = (e ? atoll(e) : 16384ll) << 20;
     if (budget < (1ll << 20)) budget = 1ll << 20;
     const long long per = (long long)vp_contours_ws_bytes(w, h, 1, max_contours);
     return (int)std::max<long long>(1, std::min<long long>(budget / per, 1 << 20));
@@ -1386,33 +1394,10 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
             if (d->ccl == 1) ccl_bits = bits_a;
         }
     }
-    // Contours of a mask the chain also labels: the background half of the contour pass (the inverted mask's union-find: the long
-    // half, and latency-bound) needs the mask only, so it is queued on the side stream NOW and runs beside the chain's own labelling
-    // and its label write (bandwidth-bound) instead of after them.  Only when one pass takes the whole batch (the scratch is carved once).
-    void* early = nullptr;
-    const u64* csrc = cd ? (cd->source == 1 ? clean_bits : bits_t) : nullptr;
-    static const bool early_off = getenv("VP_CT_EARLY") && atoi(getenv("VP_CT_EARLY")) == 0;
-    // (not when the contour pass may skip the background altogether: RETR_EXTERNAL of the very mask the chain labels, with its label
-    // image and statistics among the outputs - that decision needs the labelling, so the pass runs after it: vpk_find_contours)
-    const bool may_skip_bg = cd && d->ccl && cd->mode == VP_RETR_EXTERNAL && ccl_bits == csrc && b->labels && b->stats && d->max_labels >= 2 && d->max_labels <= 4096;
-    if (cd && d->ccl && !early_off && !may_skip_bg && ctx->chain_streams == 1 && ct_group_for(w, h, cd->max_contours) >= n)
-        VP_TRY(vpk_contours_begin(ctx, csrc, w, h, n, cd->max_contours, &early));
     if (d->ccl) {
-        const int rc_ccl = vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels,
-                                   b->nlabels ? b->nlabels : d_nl);
-        if (rc_ccl != VP_OK) {
-            if (early) (void)vpk_contours_finish(ctx, early, csrc, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr);   // join the side stream
-            return rc_ccl;
-        }
+        VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels, b->nlabels ? b->nlabels : d_nl));
     }
-    if (cd && early) {
-        vp_known_labels kn = {nullptr, nullptr, nullptr, 0};
-        const bool same_mask = ccl_bits == csrc && b->labels && b->stats;
-        if (same_mask) { kn.labels = b->labels; kn.stats = b->stats; kn.nlabels = b->nlabels ? b->nlabels : d_nl; kn.max_labels = d->max_labels; }
-        VP_TRY(vpk_contours_finish(ctx, early, csrc, cd->mode, cd->method, cb->counts, cb->is_hole, cb->offsets, cb->points, cd->max_contours, cd->max_points,
-                                   cb->info, same_mask ? &kn : nullptr));
-        if (cb->features) VP_TRY(vpk_contour_features(ctx, cb->info, cb->counts, cb->offsets, cb->points, n, cd->max_contours, cd->max_points, cb->features));
-    } else if (cd) {
+    if (cd) {
         const u64* src = cd->source == 1 ? clean_bits : bits_t;
         const size_t fw = (size_t)h * vp_ww(w);
         const size_t mc = (size_t)cd->max_contours;
@@ -1421,16 +1406,9 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
         for (int f0 = 0; f0 < n; f0 += group) {
             const int g = std::min(group, n - f0);
             ctx->ws_off = mark;   // every group reuses the same scratch (stream order keeps them apart)
-            // the chain has just labelled this very mask: its label image and statistics give the contour pass every component's first pixel
-            vp_known_labels kn = {nullptr, nullptr, nullptr, 0};
-            const bool same_mask = d->ccl && ccl_bits == src && b->labels && b->stats;
-            if (same_mask) {
-                kn.labels = b->labels + (size_t)f0 * w * h; kn.stats = b->stats + (size_t)f0 * d->max_labels * 5;
-                kn.nlabels = (b->nlabels ? b->nlabels : d_nl) + f0; kn.max_labels = d->max_labels;
-            }
             VP_TRY(vpk_find_contours(ctx, src + (size_t)f0 * fw, w, h, g, cd->mode, cd->method, cb->counts + f0 * mc, cb->is_hole + f0 * mc,
                                      cb->offsets + f0 * mc, cb->points + 2 * (size_t)f0 * (size_t)cd->max_points, cd->max_contours,
-                                     cd->max_points, cb->info + 2 * (size_t)f0, same_mask ? &kn : nullptr));
+                                     cd->max_points, cb->info + 2 * (size_t)f0));
         }
         if (cb->features) VP_TRY(vpk_contour_features(ctx, cb->info, cb->counts, cb->offsets, cb->points, n, cd->max_contours, cd->max_points, cb->features));
     }

@@ -1,4 +1,4 @@
-// Contour extraction on the GPU (included by vp_ccl.hip; shares its union-find device code).
+// Contour extraction on the GPU (included by vp_ccl.hip).
 //
 // Replaces utils/feature.py:5-40 `outer_contours` / `all_contours` = cv2.findContours(RETR_EXTERNAL | RETR_LIST,
 // CHAIN_APPROX_SIMPLE | NONE).  OpenCV (imgproc/src/contours.cpp) finds borders with a sequential raster scan that
@@ -9,122 +9,31 @@
 //   * RETR_LIST returns all of them, RETR_EXTERNAL the outer borders of components that are not inside a hole;
 //   * order: by start pixel, raster order, newest (= last) first;
 //   * each border is the Suzuki-Abe trace from its start pixel, which depends on the binary image only.
-// So: two union-find passes (foreground 8-conn, background 4-conn, both with first-pixel ids = VP_CCL_PIXEL), a
-// bitmap of start pixels + popcount prefix for the order, and segment-parallel border following (below).
 //
-// RETR_EXTERNAL: OpenCV decides "inside a hole" from the sign of the last border mark left of a start pixel.  A mark is negative
-// exactly when the tracer examined the pixel's east neighbour as background, i.e. when the east crack belongs to the traced
-// border - and every crack belongs to exactly one border (see below) - so the mark rule and the topological rule used here
-// select the same borders (no difference on 460 noise / thin-wall masks: tests/test_gpu_contours.py, tools/exp_external_rule.py).
+// No labelling is needed for any of it (rounds 1-3 ran two union-finds, foreground and background, to find the start pixels;
+// they were two thirds of a contour pass).  A border is a cycle of follower states (below), every cycle of the follower map is a
+// border, and the cycle itself says which one:
+//   * Take the cycle's vertical cracks (edges between a foreground pixel and a background pixel left or right of it) and order them
+//     as the scan meets them: by row, then by the x of the crack.  The smallest one is either the W crack of the component's first
+//     pixel - every other crack of an outer border belongs to a later pixel of the component - or the E crack of the pixel left of the
+//     background region's first pixel - every other crack of a hole border touches a later pixel of the region.  So: smallest
+//     crack is a W crack = outer border, start = its pixel; an E crack = hole border, start = its (foreground) pixel.  The state that
+//     sweeps that crack is OpenCV's start state (icvFetchContour: first neighbour clockwise from W / from E).
+//   * Scan order of the cracks = raster order of the start pixels (an outer and a hole border never start at the same pixel).
+//   * RETR_EXTERNAL: a component is inside a hole iff the background region left of its first pixel does not reach the frame.  Walk
+//     left from the first pixel along its row: no foreground pixel = the region reaches the frame; otherwise the E crack of the first
+//     foreground pixel met belongs to a border of the SAME region: a hole border = inside a hole; the outer border of another
+//     component = that component lies in the same region, so the answer is its answer (a chain of "same as" that strictly
+//     decreases in scan order, resolved by pointer jumping).
+// OpenCV decides "inside a hole" from the sign of the last border mark left of a start pixel.  A mark is negative exactly when the
+// tracer examined the pixel's east neighbour as background, i.e. when the east crack belongs to the traced border - and every crack
+// belongs to exactly one border - so the mark rule and the rule above select the same borders (no difference on 460 noise /
+// thin-wall masks: tests/test_gpu_contours.py, tools/exp_external_rule.py).
 
 struct ct_frame_out {      // per frame, device
     int32_t n_contours;
     int32_t n_points;
 };
-
-// outside[] bit per background root: the region touches the image frame
-__global__ __launch_bounds__(256) void k_ct_outside(const u64* __restrict__ bits, ccl_geom G, const u32* __restrict__ parent, u32* __restrict__ outside,
-                                                    const u32* __restrict__ only)
-{
-    // one thread per frame-border word: rows 0 and h-1 fully, columns 0 and ww-1 of the other rows
-    const int f = blockIdx.y;
-    if (only && !only[f]) return;                            // this frame's background was not resolved: nobody will ask
-    const int nborder = 2 * G.ww + 2 * G.h;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nborder) return;
-    int y, j, which;   // which: 0 = every segment of the word, 1 = the one touching bit 0, 2 = the one touching the last valid bit
-    if (t < G.ww) { y = 0; j = t; which = 0; }
-    else if (t < 2 * G.ww) { y = G.h - 1; j = t - G.ww; which = 0; }
-    else if (t < 2 * G.ww + G.h) { y = t - 2 * G.ww; j = 0; which = 1; }
-    else { y = t - 2 * G.ww - G.h; j = G.ww - 1; which = 2; }
-    const u64* fb = bits + (size_t)f * G.h * G.ww;
-    const u64 w = ccl_word(G, fb, y * G.ww + j, j);
-    if (!w) return;
-    const u32* p = parent + (size_t)f * G.nids;
-    u32* o = outside + (size_t)f * G.nw32;
-    u64 rem = w;
-    if (which == 1) rem = (w & 1ull) ? bit_range(0, run_end(w, 0)) : 0ull;
-    if (which == 2) { const int last = ((G.w - 1) & 63); rem = ((w >> last) & 1ull) ? bit_range(run_start(w, last), last) : 0ull; }
-    while (rem) {
-        const int s = __ffsll((long long)rem) - 1;
-        const int e = run_end(rem, s);
-        rem &= ~bit_range(s, e);
-        const int st = run_start(w, s);   // `rem` may have been cut: the segment id comes from the real start
-        u32 r = seg_id(G, y, 64 * j + st);
-        for (u32 q = p[r]; q != r; q = p[r]) r = q;
-        // nearly every frame-touching segment belongs to the one big outside region: test before setting, or a couple of thousand
-        // atomics per frame queue up on a single word (28 us of a single-frame call were exactly that)
-        if (!((ld_rlx(o + (r >> 5)) >> (r & 31)) & 1u)) atomicOr(o + (r >> 5), 1u << (r & 31));
-    }
-}
-
-// root id (VP_CCL_PIXEL: y*wb + x/2) -> first pixel of the region
-__device__ __forceinline__ void ct_root_pixel(const ccl_geom& G, const u64* __restrict__ fb, u32 id, int& y, int& x)
-{
-    y = (int)(id / (u32)G.wb);
-    const int x2 = (int)(id - (u32)y * (u32)G.wb);
-    const int j = (2 * x2) >> 6;
-    const u64 w = ccl_word(G, fb, y * G.ww + j, j);
-    x = ((w >> ((2 * x2) & 63)) & 1ull) ? 2 * x2 : 2 * x2 + 1;
-}
-
-// seeds: bitmaps in the layout of a bit image.  startmap = start pixel of every border of the image (every cycle of the
-// border-following map gets exactly one), holemap = it is a hole border, selmap = the retrieval mode returns it.
-// grid (ceil(nw32/256), n): thread = one 32-bit word of the root bitmaps.
-__global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, ccl_geom Gf, ccl_geom Gb, const u32* __restrict__ fg_flags,
-                                                  const u32* __restrict__ bg_flags, const u32* __restrict__ bg_parent,
-                                                  const u32* __restrict__ outside, int mode, u64* __restrict__ startmap, u64* __restrict__ holemap,
-                                                  u64* __restrict__ selmap, u32* __restrict__ partsum2, int nparts, const u32* __restrict__ bg_only)
-{
-    const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= Gf.nw32) return;
-    const int f = blockIdx.y;
-    // RETR_EXTERNAL of a frame in which no component's box lies strictly inside another's (k_ct_needs_bg): every outer border is
-    // external and no hole border is asked for, so the background arrays of this frame were never made and are not looked at
-    const bool nobg = bg_only && !bg_only[f];
-    const size_t fo = (size_t)f * Gf.h * Gf.ww;
-    const u64* fb = bits + fo;
-    u64* sm = startmap + fo;
-    u64* hm = holemap + fo;
-    u64* sel = selmap + fo;
-    u32* ps2 = partsum2 + (size_t)f * nparts;      // selected starts per 256 words of the frame (k_ct_prefix scans them)
-    auto select = [&](size_t wi, int bit) {
-        const unsigned long long old = atomicOr((unsigned long long*)&sel[wi], 1ull << bit);
-        if (!((old >> bit) & 1ull)) atomicAdd(ps2 + (wi >> 8), 1u);
-    };
-    const u32* bp = bg_parent + (size_t)f * Gb.nids;
-    const u32* out = outside + (size_t)f * Gb.nw32;
-    u32 m = fg_flags[(size_t)f * Gf.nw32 + t];
-    while (m) {
-        const int b = __ffs((int)m) - 1;
-        m &= m - 1;
-        int y, x;
-        ct_root_pixel(Gf, fb, t * 32 + b, y, x);
-        bool keep = true;
-        if (mode == 0 && x > 0 && !nobg) {   // RETR_EXTERNAL: the region left of the first pixel must reach the frame
-            const int xl = x - 1, j = xl >> 6;
-            const u64 wb = ccl_word(Gb, fb, y * Gb.ww + j, j);
-            u32 r = seg_id(Gb, y, 64 * j + run_start(wb, xl & 63));
-            for (u32 q = bp[r]; q != r; q = bp[r]) r = q;
-            keep = (out[r >> 5] >> (r & 31)) & 1u;
-        }
-        const size_t wi = (size_t)y * Gf.ww + (x >> 6);
-        atomicOr((unsigned long long*)&sm[wi], 1ull << (x & 63));
-        if (keep) select(wi, x & 63);
-    }
-    u32 hb = nobg ? 0u : (bg_flags[(size_t)f * Gb.nw32 + t] & ~out[t]);   // hole borders: background regions that do not reach the frame
-    while (hb) {
-        const int b = __ffs((int)hb) - 1;
-        hb &= hb - 1;
-        int y, x;
-        ct_root_pixel(Gb, fb, t * 32 + b, y, x);
-        const int xs = x - 1;   // a hole never touches column 0
-        const size_t wi = (size_t)y * Gf.ww + (xs >> 6);
-        atomicOr((unsigned long long*)&sm[wi], 1ull << (xs & 63));
-        atomicOr((unsigned long long*)&hm[wi], 1ull << (xs & 63));
-        if (mode == 1) select(wi, xs & 63);
-    }
-}
 
 // ---- segment-parallel border following --------------------------------------------------------------------------------
 // A border is a cycle of states (pixel, s) of the Suzuki-Abe follower, s = direction of the pixel it came from; the next state
@@ -133,22 +42,26 @@ __global__ __launch_bounds__(256) void k_ct_seeds(const u64* __restrict__ bits, 
 // 4-adjacent background pixel) is swept by exactly one state of exactly one border, and that state can be written down from
 // the crack alone: s = first foreground neighbour clockwise from the crack's direction.  So the states that sweep a W or E
 // crack (and, to cut long flat edges, an N or S crack at x % 8 == 0) are enumerable with bit operations - the "heads" - and
-// they cut every border into short segments that are followed independently, one thread each:
-//   k_ct_headmaps   4 head bitmaps per word (a state that sweeps several eligible cracks belongs to the first one swept); clears the
-//                   seed bitmaps k_ct_seeds fills next
-//   k_ct_prefix     popcount prefix -> dense head index + head list (pixel, type), terminal marks cleared; the same kernel
-//                   ranks the selected start pixels (cv2's contour order)
-//   k_ct_starts     start pixel of every border -> its start state -> the head that owns it = the terminal of that cycle
-//   k_ct_seg<false> follow each segment to the next head: node[k] = (next head, points emitted)
-//   k_ct_jump       pointer jumping on (next, distance) pairs until every head points at its terminal; then per contour:
-//                   length = distance of the terminal around its cycle, exclusive scan -> offsets
-//   k_ct_seg<true>  follow each segment again, writing its points at offset[contour] + (length - distance to terminal)
-// OpenCV's start rule (icvFetchContour: first neighbour clockwise from W for an outer border, from E for a hole border) is
-// the head rule for the W / E crack of the start pixel, and its CHAIN_APPROX_SIMPLE filter (keep a point when the direction
-// changes) is local to a state: s' != s ^ 4.
+// they cut every border into short segments that are followed independently, one thread each.  A pixel without neighbours is a
+// border of its own: one head (listed with the W heads), one point.
+//   k_ct_headmaps   4 head bitmaps per word (a state that sweeps several eligible cracks belongs to the first one swept)
+//   k_ct_prefix     popcount prefix -> dense head index + head list (pixel, type)
+//   k_ct_seg<false> follow each segment to the next head: node[k] = (next head, points emitted); key[k] = the smallest vertical
+//                   crack the head's state sweeps (none: an N / S head); for RETR_EXTERNAL, where the row left of a possible first
+//                   pixel ends: the head that owns the E crack met, or the frame
+//   k_ct_jump       one block per frame.  (1) pointer jumping on (next, smallest key so far) until every head knows the head with
+//                   the smallest key of its cycle - the leader, whose state is the border's start state; (2) RETR_EXTERNAL: which
+//                   outer borders are external; (3) rank of the returned borders in scan order (head order is scan order up to the
+//                   order inside one 64-pixel word, which is settled by comparing keys) -> starts / terminal marks; (4) pointer
+//                   jumping on (next, distance) until every head points at its leader; (5) per contour: length, exclusive scan
+//                   -> offsets
+//   k_ct_seg<true>  follow each segment again, writing its points at offset[contour] + (length - distance to the leader)
+// CHAIN_APPROX_SIMPLE (keep a point when the direction changes) is local to a state: s' != s ^ 4.
 #define CT_TERM 0x80000000u
 #define CT_NONE 0xffffffffu
 #define CT_UNSEL 0xfffffffeu
+#define CT_FRAME 0xffffffffu      // ext[]: nothing but background left of the first pixel / the border is external
+#define CT_INSIDE 0xfffffffeu     // ext[]: inside a hole
 #define CT_EL_NS 0x0101010101010101ull   // N / S cracks are heads only in columns x % 8 == 0
 #define CT_JUMP_ROUNDS 40
 
@@ -186,19 +99,14 @@ __device__ __forceinline__ void ct_block_sum(u32 c, u32* __restrict__ partsum)
     if (threadIdx.x == 0) partsum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ws4[0] + ws4[1] + ws4[2] + ws4[3];
 }
 
-// (also clears this word of the three seed bitmaps and the block's entry of the selected-start partial sums, which k_ct_seeds fills
-// afterwards: one launch instead of a memset, this one and a counting pass)
 __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps, u32* __restrict__ partsum,
-                                                     u64* __restrict__ maps3, size_t mstride, u32* __restrict__ partsum2, uint8_t* __restrict__ cnt8)
+                                                     uint8_t* __restrict__ cnt8)
 {
     const int nwords = G.h * G.ww;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
     u32 cnt = 0;
-    if (threadIdx.x == 0) partsum2[(size_t)f * gridDim.x + blockIdx.x] = 0u;
     if (idx < nwords) {
-        const size_t wi = (size_t)f * nwords + idx;
-        maps3[wi] = 0ull; maps3[mstride + wi] = 0ull; maps3[2 * mstride + wi] = 0ull;
         const u64* fb = bits + (size_t)f * nwords;
         const int y = idx / G.ww, j = idx - y * G.ww;
         u64 c, n[8];
@@ -210,6 +118,7 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
             he = c & ~n[0] & (n[7] | n[6] | (~el & (n[5] | n[4])));
             hn = c & ~n[2] & el & (n[1] | n[0]);
             hs = c & ~n[6] & el & (n[5] | n[4]);
+            hw |= c & ~(n[0] | n[1] | n[2] | n[3] | n[4] | n[5] | n[6] | n[7]);      // a pixel on its own: one state, one head
         }
         cnt = (u32)(__popcll(hw) + __popcll(he) + __popcll(hn) + __popcll(hs));
         // The bitmaps are only ever read back for words that hold a head (the head list, ct_head_index); every word's COUNT is what the
@@ -228,7 +137,7 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
 // grid (ceil(nwords/256), n): block b adds up the block sums before it, then scans its 256 words.
 __global__ __launch_bounds__(256) void k_ct_prefix(const u64* __restrict__ maps, int nm, int nwords, const u32* __restrict__ partsum,
                                                    u32* __restrict__ base, u32* __restrict__ total_out, int tstride, int w, int ww,
-                                                   u32* __restrict__ head_pix, u32* __restrict__ hrank, size_t hcap, const uint8_t* __restrict__ cnt8)
+                                                   u32* __restrict__ head_pix, size_t hcap, const uint8_t* __restrict__ cnt8)
 {
     __shared__ u32 wsum[4], wtot[4];
     const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -253,19 +162,17 @@ __global__ __launch_bounds__(256) void k_ct_prefix(const u64* __restrict__ maps,
     u32 woff = 0;
     for (int k = 0; k < wv; k++) woff += wsum[k];
     if (i < nwords) base[(size_t)f * nwords + i] = carry + woff + inc - cnt;
-    if (head_pix && cnt) {   // head list: head_pix[k] = pixel index | type << 29; hrank[k] = CT_NONE (not a terminal)
+    if (head_pix && cnt) {   // head list: head_pix[k] = pixel index | type << 29
         const int y = i / ww, j = i - y * ww;
         const u32 pix0 = (u32)(y * w + 64 * j);
         u32 k = carry + woff + inc - cnt;
         u32* hp = head_pix + (size_t)f * hcap;
-        u32* hr = hrank + (size_t)f * hcap;
         for (int t = 0; t < 4; t++) {
             u64 m = maps[((size_t)f * nwords + i) * 4 + t];
             while (m) {
                 const int b = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 hp[k] = (pix0 + (u32)b) | ((u32)t << 29);
-                hr[k] = CT_NONE;
                 k++;
             }
         }
@@ -356,85 +263,43 @@ __device__ __forceinline__ int ct_head_type(int s, int t, int x)
     return type;
 }
 
-// start pixel of every border -> terminal head.  starts[r] = pixel | hole << 31 and shead[r] = head index (CT_NONE: single
-// pixel) for the selected borders in raster order; hrank[head] = r, or CT_UNSEL for a border the mode does not return.
-// (the rank of a word's first selected start = number of selected starts before it in raster order, from the per-block counts
-// k_ct_seeds made plus a scan of this block's words: cv2's contour order; the last block publishes the total)
-__global__ __launch_bounds__(256) void k_ct_starts(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ startmap,
-                                                   const u64* __restrict__ holemap, const u64* __restrict__ selmap, const u32* __restrict__ partsum2,
-                                                   u32* __restrict__ nsel_out, const u64* __restrict__ hmaps, const u32* __restrict__ hbase,
-                                                   u32* __restrict__ hrank, size_t hcap, u32* __restrict__ starts, u32* __restrict__ shead,
-                                                   int max_contours)
+// scan-order key of a vertical crack: W crack of pixel (y, x) = 2 * (y * (w + 1) + x), E crack = 2 * (y * (w + 1) + x + 1) + 1 (two
+// cracks never share a position, so the low bit - "hole border if this is the smallest of its cycle" - does not disturb the order)
+__device__ __forceinline__ u32 ct_key_w(const ccl_geom& G, int y, int x) { return ((u32)y * (u32)(G.w + 1) + (u32)x) << 1; }
+__device__ __forceinline__ u32 ct_key_e(const ccl_geom& G, int y, int x) { return (((u32)y * (u32)(G.w + 1) + (u32)x + 1u) << 1) | 1u; }
+
+// RETR_EXTERNAL: what lies left of a possible first pixel (y, x) in its row: CT_FRAME, or the head that owns the E crack of the first
+// foreground pixel met
+__device__ __forceinline__ u32 ct_left_of(const ccl_geom& G, const u64* __restrict__ fb, const u64* __restrict__ hm, const u32* __restrict__ hb,
+                                          int y, int x)
 {
-    __shared__ u32 wsum[4], wtot[4];
-    const int nwords = G.h * G.ww;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int idx = blockIdx.x * 256 + tid;
-    const int f = blockIdx.y;
-    const size_t fo = (size_t)f * nwords;
-    const bool valid = idx < nwords;
-    const u32* ps = partsum2 + (size_t)f * gridDim.x;
-    u32 c = 0;
-    for (int q = tid; q < (int)blockIdx.x; q += 256) c += ps[q];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-    if (lane == 0) wtot[wv] = c;
-    const u64 sel = valid ? selmap[fo + idx] : 0ull;
-    const u32 cnt = (u32)__popcll(sel);
-    u32 inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    const u32 carry = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    u32 woff = 0;
-    for (int k = 0; k < wv; k++) woff += wsum[k];
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) nsel_out[(size_t)f * 2] = carry + wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (!valid) return;
-    u64 sm = startmap[fo + idx];
-    if (!sm) return;
-    const u64 hm = holemap[fo + idx];
-    const u64* fb = bits + fo;
-    const int y = idx / G.ww, j = idx - y * G.ww;
-    u32 r = carry + woff + inc - cnt;
-    while (sm) {
-        const int b = __ffsll((long long)sm) - 1;
-        sm &= sm - 1;
-        const int x = 64 * j + b;
-        const bool hole = (hm >> b) & 1ull, selected = (sel >> b) & 1ull;
-        ct_tile T;
-        ct_tile_load(G, fb, y - 3, x - 3, T);
-        const u32 R = ct_ring(T, y, x);
-        u32 head = CT_NONE;
-        if (R) {
-            const int s = ct_first_cw(R, hole ? 0 : 4);
-            const u32 q = (R | (R << 8)) >> (s + 1);
-            const int t = __ffs((int)q) - 1;
-            const int type = ct_head_type(s, t, x);   // >= 0: the sweep crosses the W (outer) / E (hole) crack
-            if (type >= 0) {
-                head = ct_head_index(hmaps + fo * 4, hbase + fo, idx, b, type);
-                hrank[(size_t)f * hcap + head] = selected ? r : CT_UNSEL;
-            }
-        }
-        if (selected) {
-            if ((int)r < max_contours) {
-                starts[(size_t)f * max_contours + r] = (u32)(y * G.w + x) | (hole ? 0x80000000u : 0u);
-                shead[(size_t)f * max_contours + r] = head;
-            }
-            r++;
-        }
+    const u64* row = fb + (size_t)y * G.ww;
+    int j = x >> 6;
+    u64 m = row[j] & ((1ull << (x & 63)) - 1ull);
+    while (!m && j > 0) m = row[--j];
+    if (!m) return CT_FRAME;
+    const int xq = 64 * j + 63 - __clzll((long long)m);
+    ct_tile T;
+    ct_tile_load(G, fb, y - 3, xq - 3, T);
+    const u32 R = ct_ring(T, y, xq);
+    int type = 0;                                       // a pixel on its own: its one head is listed with the W heads
+    if (R) {
+        const int s = ct_first_cw(R, 0);
+        const int t = __ffs((int)((R | (R << 8)) >> (s + 1))) - 1;
+        type = ct_head_type(s, t, xq);                  // >= 0: the sweep crosses the E crack
     }
+    return ct_head_index(hm, hb, y * G.ww + (xq >> 6), xq & 63, type);
 }
 
 // one thread per head: follow the border from the head's state to the next head.
-//   !WRITE: node[k] = (next head | CT_TERM if that is a terminal) << 32 | points emitted
+//   !WRITE: node[k] = next head << 32 | points emitted; key[k]; ext[k] (mode 0)
 //    WRITE: the points go to their final place (see ct_offsets_body)
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ hmaps, const u32* __restrict__ hbase,
                                                 const u32* __restrict__ head_pix, const u32* __restrict__ hrank, size_t hcap,
-                                                const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, int method,
-                                                const int32_t* __restrict__ offsets, int32_t* __restrict__ points, int max_contours,
-                                                long long max_points)
+                                                const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, u32* __restrict__ hkey,
+                                                u32* __restrict__ hext, int mode, int method, const int32_t* __restrict__ offsets,
+                                                int32_t* __restrict__ points, int max_contours, long long max_points)
 {
     const int f = blockIdx.y;
     const int nwords = G.h * G.ww;
@@ -466,7 +331,23 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
         ct_tile T;
         ct_tile_load(G, fb, y - 3, x - 3, T);
         u32 R = ct_ring(T, y, x);
+        if (!R) {                                        // a pixel on its own: a border of one point, its own successor
+            if (WRITE) { out[0] = x; out[1] = y; }
+            else {
+                nd[k] = ((unsigned long long)k << 32) | 1u;
+                hkey[(size_t)f * hcap + k] = ct_key_w(G, y, x);
+                if (mode == 0) hext[(size_t)f * hcap + k] = ct_left_of(G, fb, hm, hb, y, x);
+            }
+            continue;
+        }
         int s = ct_first_cw(R, type == 0 ? 4 : (type == 1 ? 0 : (type == 2 ? 2 : 6)));
+        if (!WRITE) {
+            const int t0 = __ffs((int)((R | (R << 8)) >> (s + 1))) - 1;
+            const bool sw = ((3 - s) & 7) < t0, se = ((7 - s) & 7) < t0;        // the state sweeps the pixel's W / E crack
+            hkey[(size_t)f * hcap + k] = sw ? ct_key_w(G, y, x) : (se ? ct_key_e(G, y, x) : CT_NONE);
+            // a component's first pixel has nothing above it: only such a W crack can turn out to be the smallest of its cycle
+            if (mode == 0) hext[(size_t)f * hcap + k] = (sw && !(R & 0xeu)) ? ct_left_of(G, fb, hm, hb, y, x) : CT_INSIDE;
+        }
         u32 cnt = 0, succ = k;
         bool first = true;
         // a border visits a pixel at most once per incoming direction: bound the walk so that a corrupted image cannot
@@ -492,21 +373,14 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             }
             R = ct_ring(T, y, x);
         }
-        if (!WRITE) {
-            const u32 term = (hr[succ] != CT_NONE) ? CT_TERM : 0u;
-            nd[k] = ((unsigned long long)(succ | term) << 32) | cnt;
-        }
+        if (!WRITE) nd[k] = ((unsigned long long)succ << 32) | cnt;
     }
 }
 
-// per frame: pointer jumping.  node = (J, D): D points lie between this head and head J along the border.  A pair read in one
-// 64-bit load is always a consistent (older or newer) statement of that invariant, so the rounds need no double buffering.
-// Up to CTJ_LDS heads the table lives in LDS for the rounds.
-#define CTJ_LDS 8192
 // per frame: contour lengths from the terminals, exclusive scan -> offsets, total -> out[f].n_points; single-pixel contours are
 // written here.  All NT threads of the block take part.
 template <int NT>
-__device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, const ct_aux* __restrict__ aux, const u32* __restrict__ starts,
+__device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, int nsel, const u32* __restrict__ starts,
                                                 const u32* __restrict__ shead, const unsigned long long* __restrict__ node, size_t hcap,
                                                 int32_t* __restrict__ counts, uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets,
                                                 int32_t* __restrict__ points, ct_frame_out* __restrict__ out, int max_contours, long long max_points)
@@ -514,7 +388,6 @@ __device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, const ct_aux*
     __shared__ u32 wsum[NT / 64];
     __shared__ u32 carry;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nsel = (int)aux[f].nsel;
     const int K = min(nsel, max_contours);
     if (tid == 0) carry = 0;
     __syncthreads();
@@ -552,53 +425,359 @@ __device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, const ct_aux*
     if (tid == 0) { out[f].n_contours = nsel; out[f].n_points = (int32_t)carry; }
 }
 
-// One block per frame: pointer jumping over the (next head, distance) pairs until every head points at its terminal, then the
-// contour lengths / offsets from the terminals (what used to be a launch of its own).
-__global__ __launch_bounds__(1024) void k_ct_jump(ccl_geom G, const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, size_t hcap,
-                                                  const u32* __restrict__ starts, const u32* __restrict__ shead, int32_t* __restrict__ counts,
-                                                  uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
-                                                  ct_frame_out* __restrict__ out, int max_contours, long long max_points)
+// ---- the cycle bookkeeping between the two follower passes ----
+// Steps (1)-(5) of the list above, written once as per-head functions and run in two forms:
+//   k_ct_jump      one block of 1024 threads per frame, barriers between the steps, the tables in LDS when the frame's heads fit
+//                  (`lds_heads`), otherwise in global memory: ONE launch - what a module's mask or a batch of them needs;
+//   k_ctm_*        the same steps as launches over the whole chip, for a single image with very many heads (a speckled mask: one
+//                  block would take milliseconds over 600 k heads).  The host cannot know the rounds a frame needs, so every
+//                  round that could be needed is launched and a launch whose predecessor changed nothing returns at once.
+// Tables in global memory are read and written with relaxed agent-scope accesses (program order, barriers and kernel boundaries
+// do the rest).
+template <bool L> __device__ __forceinline__ unsigned long long ctj_ld(const unsigned long long* t, u32 k)
 {
-    __shared__ unsigned long long tab[CTJ_LDS];
-    const int f = blockIdx.x;
-    const u32 H = aux[f].nheads;
-    unsigned long long* nd = node + (size_t)f * hcap;
-    // A cycle that holds a terminal is through after ceil(log2(its heads)) rounds; a cycle without one (a hole border whose start was not
-    // looked for: k_ct_seeds with `nobg`) never is - so the rounds are bounded by the head count, not only by "nothing changed".
+    if (L) return t[k];
+    return __hip_atomic_load(t + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool L> __device__ __forceinline__ void ctj_st(unsigned long long* t, u32 k, unsigned long long v)
+{
+    if (L) t[k] = v;
+    else __hip_atomic_store(t + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32 ctj_gld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ctj_gst(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct ctj_frame {
+    u32 H;
+    unsigned long long* nd;      // in: (next head, points) of k_ct_seg<false>; out: (leader | CT_TERM, distance to it)
+    unsigned long long* tab;     // (next, smallest) pairs of step (1)
+    const u32* key;
+    u32* ext;                    // in: k_ct_seg<false>'s look to the left; then step (2)'s answers; then the ranks of step (3)
+    u32* hr;                     // out: rank of the border a leader starts | CT_UNSEL | CT_NONE (not a leader)
+    const u32* hp;
+    const u32* hb;
+    const uint8_t* c8;
+};
+
+// (1) leaders.  tab[k] = (J, m): m = the head with the smallest key among the heads from k up to, not including, J along the border.
+// A pair read in one 64-bit access is always a true statement of that kind (older or newer), so the rounds work in place and need no
+// order among the heads.  A round in which no m changed anywhere proves every m is its cycle's minimum: m(k) <= m(J(k)) for every k,
+// the chain k, J(k), J(J(k)), ... closes on itself, its windows tile the whole cycle, so m is constant on it and equal to the minimum.
+template <bool L> __device__ __forceinline__ void ctj_lead_init(const ctj_frame& F, u32 k) { ctj_st<L>(F.tab, k, (F.nd[k] & 0xffffffff00000000ull) | k); }
+template <bool L> __device__ __forceinline__ bool ctj_lead_step(const ctj_frame& F, u32 k)
+{
+    const unsigned long long v = ctj_ld<L>(F.tab, k);
+    const u32 J = (u32)(v >> 32), m = (u32)v;
+    if (J == k) return false;
+    const unsigned long long v2 = ctj_ld<L>(F.tab, J);
+    const u32 m2 = (u32)v2;
+    const bool better = F.key[m2] < F.key[m];
+    ctj_st<L>(F.tab, k, (v2 & 0xffffffff00000000ull) | (better ? m2 : m));
+    return better;
+}
+template <bool L> __device__ __forceinline__ bool ctj_leads(const ctj_frame& F, u32 k) { return (u32)ctj_ld<L>(F.tab, k) == k; }
+
+// (2) RETR_EXTERNAL: ext[leader of an outer border] = CT_FRAME (external) | CT_INSIDE | the leader whose answer is also this one's
+template <bool L> __device__ __forceinline__ void ctj_ext_init(const ctj_frame& F, u32 k)
+{
+    if (!ctj_leads<L>(F, k) || (F.key[k] & 1u)) return;
+    const u32 e = F.ext[k];                              // k_ct_seg<false>: the head owning the E crack met on the way left
+    if (e == CT_FRAME) return;
+    const u32 c2 = (u32)ctj_ld<L>(F.tab, e);
+    ctj_gst(F.ext + k, (F.key[c2] & 1u) ? CT_INSIDE : c2);
+}
+template <bool L> __device__ __forceinline__ bool ctj_ext_step(const ctj_frame& F, u32 k)
+{
+    if (!ctj_leads<L>(F, k) || (F.key[k] & 1u)) return false;
+    const u32 e = ctj_gld(F.ext + k);
+    if (e >= CT_INSIDE) return false;
+    ctj_gst(F.ext + k, ctj_gld(F.ext + e));
+    return true;
+}
+// does head k lead a border the mode returns
+template <bool L> __device__ __forceinline__ u32 ctj_selected(const ctj_frame& F, u32 k, int mode)
+{
+    if (!ctj_leads<L>(F, k)) return 0u;
+    return mode == 1 ? 1u : ((!(F.key[k] & 1u) && ctj_gld(F.ext + k) == CT_FRAME) ? 1u : 0u);
+}
+// (3) with hr[k] = 2 * (returned borders before head k in head order) + (k leads one): head order = scan order of the words; inside a
+// word the heads are listed by type, so there the keys decide
+__device__ __forceinline__ void ctj_rank(const ctj_frame& F, u32 k, const ccl_geom& G, u32* __restrict__ starts, u32* __restrict__ shead, int max_contours)
+{
+    if (!(ctj_gld(F.hr + k) & 1u)) return;
+    const u32 pix = F.hp[k] & 0x1fffffffu;
+    const int y = (int)(pix / (u32)G.w), x = (int)(pix - (u32)y * (u32)G.w);
+    const int wi = y * G.ww + (x >> 6);
+    const u32 b = F.hb[wi], e = b + F.c8[wi];
+    u32 r = ctj_gld(F.hr + b) >> 1;
+    const u32 mine = F.key[k];
+    for (u32 q = b; q < e; q++) r += (q != k && (ctj_gld(F.hr + q) & 1u) && F.key[q] < mine) ? 1u : 0u;
+    ctj_gst(F.ext + k, r);
+    if (r < (u32)max_contours) {
+        starts[r] = pix | ((mine & 1u) << 31);
+        shead[r] = k;
+    }
+}
+template <bool L> __device__ __forceinline__ void ctj_mark(const ctj_frame& F, u32 k)
+{
+    const u32 v = ctj_gld(F.hr + k);
+    ctj_gst(F.hr + k, (v & 1u) ? ctj_gld(F.ext + k) : (ctj_leads<L>(F, k) ? CT_UNSEL : CT_NONE));
+}
+// (4) distances.  t[k] = (J, D): D points lie between this head and head J along the border, until J is the cycle's leader.
+template <bool L> __device__ __forceinline__ void ctj_dist_init(const ctj_frame& F, unsigned long long* t, u32 k)
+{
+    const unsigned long long v = F.nd[k];
+    const u32 J = (u32)(v >> 32);
+    ctj_st<L>(t, k, ((unsigned long long)(J | (ctj_gld(F.hr + J) != CT_NONE ? CT_TERM : 0u)) << 32) | (u32)v);
+}
+template <bool L> __device__ __forceinline__ bool ctj_dist_step(unsigned long long* t, u32 k)
+{
+    const unsigned long long v = ctj_ld<L>(t, k);
+    const u32 J = (u32)(v >> 32);
+    if (J & CT_TERM) return false;
+    const unsigned long long v2 = ctj_ld<L>(t, J);
+    ctj_st<L>(t, k, (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2));
+    return true;
+}
+
+template <bool L>
+__device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* keyl, const unsigned long long* __restrict__ node, size_t hcap,
+                                         u32* __restrict__ starts, u32* __restrict__ shead, int32_t* __restrict__ counts,
+                                         uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
+                                         ct_frame_out* __restrict__ out, int max_contours, long long max_points, int mode)
+{
+    __shared__ u32 s_wsum[16];
+    __shared__ u32 s_carry;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 H = F.H;
     const int max_rounds = min(CT_JUMP_ROUNDS, 34 - __clz((int)(H | 1u)));
-    if (H <= CTJ_LDS) {
-        for (u32 k = threadIdx.x; k < H; k += 1024) tab[k] = nd[k];
+    if (L) {
+        for (u32 k = tid; k < H; k += 1024) keyl[k] = F.key[k];
+        F.key = keyl;
+    }
+    for (u32 k = tid; k < H; k += 1024) ctj_lead_init<L>(F, k);
+    __syncthreads();
+    for (int round = 0; round < max_rounds; round++) {
+        int changed = 0;
+        for (u32 k = tid; k < H; k += 1024) changed |= ctj_lead_step<L>(F, k) ? 1 : 0;
+        if (!__syncthreads_or(changed)) break;
+    }
+    if (mode == 0) {
+        for (u32 k = tid; k < H; k += 1024) ctj_ext_init<L>(F, k);
         __syncthreads();
-        for (int round = 0; round < max_rounds; round++) {
+        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
             int changed = 0;
-            for (u32 k = threadIdx.x; k < H; k += 1024) {
-                const unsigned long long v = tab[k];
-                const u32 J = (u32)(v >> 32);
-                if (J & CT_TERM) continue;
-                const unsigned long long v2 = tab[J];
-                tab[k] = (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2);
-                changed = 1;
-            }
-            if (!__syncthreads_or(changed)) break;
-        }
-        for (u32 k = threadIdx.x; k < H; k += 1024) nd[k] = tab[k];
-    } else {
-        for (int round = 0; round < max_rounds; round++) {
-            int changed = 0;
-            for (u32 k = threadIdx.x; k < H; k += 1024) {
-                const unsigned long long v = __hip_atomic_load(nd + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const u32 J = (u32)(v >> 32);
-                if (J & CT_TERM) continue;
-                const unsigned long long v2 = __hip_atomic_load(nd + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(nd + k, (v2 & 0xffffffff00000000ull) | (u32)((u32)v + (u32)v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                changed = 1;
-            }
+            for (u32 k = tid; k < H; k += 1024) changed |= ctj_ext_step<L>(F, k) ? 1 : 0;
             if (!__syncthreads_or(changed)) break;
         }
     }
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < H; base += 1024) {
+        const u32 k = base + tid;
+        const u32 sel = k < H ? ctj_selected<L>(F, k, mode) : 0u;
+        u32 inc = sel;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int q = 0; q < wv; q++) woff += s_wsum[q];
+        if (k < H) ctj_gst(F.hr + k, ((s_carry + woff + inc - sel) << 1) | sel);
+        __syncthreads();
+        if (tid == 1023) s_carry += woff + inc;
+        __syncthreads();
+    }
+    const u32 nsel = s_carry;
+    for (u32 k = tid; k < H; k += 1024) ctj_rank(F, k, G, starts + (size_t)f * max_contours, shead + (size_t)f * max_contours, max_contours);
+    __syncthreads();
+    for (u32 k = tid; k < H; k += 1024) ctj_mark<L>(F, k);
+    __threadfence_block();
+    __syncthreads();
+    unsigned long long* t = L ? F.tab : F.nd;          // (in global memory the distances replace the (next, points) pairs in place)
+    for (u32 k = tid; k < H; k += 1024) ctj_dist_init<L>(F, t, k);
+    __syncthreads();
+    for (int round = 0; round < max_rounds; round++) {
+        int changed = 0;
+        for (u32 k = tid; k < H; k += 1024) changed |= ctj_dist_step<L>(t, k) ? 1 : 0;
+        if (!__syncthreads_or(changed)) break;
+    }
+    if (L)
+        for (u32 k = tid; k < H; k += 1024) F.nd[k] = t[k];
     __threadfence_block();
     __syncthreads();               // the block's own stores to node[] are visible to all its threads from here on
-    ct_offsets_body<1024>(G, aux, starts, shead, node, hcap, counts, is_hole_out, offsets, points, out, max_contours, max_points);
+    ct_offsets_body<1024>(G, (int)nsel, starts, shead, node, hcap, counts, is_hole_out, offsets, points, out, max_contours, max_points);
+}
+
+struct ctj_args {
+    ccl_geom G;
+    ct_aux* aux;
+    unsigned long long *node, *node2;
+    const u32* hkey;
+    u32 *hext, *hrank;
+    const u32* hbase;
+    const uint8_t* cnt8;
+    const u32* head_pix;
+    size_t hcap;
+    u32 *starts, *shead;
+    int32_t* counts;
+    uint8_t* is_hole;
+    int32_t *offsets, *points;
+    ct_frame_out* out;
+    int max_contours;
+    long long max_points;
+    int mode;
+    u32 lds_heads;
+    u32* nheads_out;             // nullable: the frame's head count, for the caller's next call (vpk_find_contours `many_heads`)
+    u32 *flags, *csum;           // k_ctm_* only: per frame CTM_NFLAGS round flags; partial sums of the two scans
+    int hops;
+};
+__device__ __forceinline__ ctj_frame ctj_make_frame(const ctj_args& A, int f, unsigned long long* tab)
+{
+    ctj_frame F;
+    const int nwords = A.G.h * A.G.ww;
+    F.H = A.aux[f].nheads;
+    F.nd = A.node + (size_t)f * A.hcap;
+    F.tab = tab;
+    F.key = A.hkey + (size_t)f * A.hcap;
+    F.ext = A.hext + (size_t)f * A.hcap;
+    F.hr = A.hrank + (size_t)f * A.hcap;
+    F.hp = A.head_pix + (size_t)f * A.hcap;
+    F.hb = A.hbase + (size_t)f * nwords;
+    F.c8 = A.cnt8 + (size_t)f * nwords;
+    return F;
+}
+
+extern __shared__ unsigned long long ctj_dyn[];
+__global__ __launch_bounds__(1024) void k_ct_jump(ctj_args A)
+{
+    const int f = blockIdx.x;
+    const u32 H = A.aux[f].nheads;
+    if (A.nheads_out && threadIdx.x == 0) A.nheads_out[f] = H;
+    if (H <= A.lds_heads)
+        ctj_body<true>(A.G, ctj_make_frame(A, f, ctj_dyn), reinterpret_cast<u32*>(ctj_dyn + A.lds_heads), A.node, A.hcap, A.starts, A.shead, A.counts,
+                       A.is_hole, A.offsets, A.points, A.out, A.max_contours, A.max_points, A.mode);
+    else
+        ctj_body<false>(A.G, ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap), nullptr, A.node, A.hcap, A.starts, A.shead, A.counts, A.is_hole,
+                        A.offsets, A.points, A.out, A.max_contours, A.max_points, A.mode);
+}
+
+// ---- the same steps as launches over the chip (grid (blocks, n) x 256) ----
+// flags[f][i]: launch i of a round sequence changed something.  Slot 0 of each sequence is set by the launch before it.
+#define CTM_SEQ 32
+#define CTM_NFLAGS (3 * CTM_SEQ)
+enum { CTM_LEAD_INIT, CTM_LEAD, CTM_EXT_INIT, CTM_EXT, CTM_RANK, CTM_MARK, CTM_DIST };
+
+template <int PH>
+__global__ __launch_bounds__(256) void k_ctm(ctj_args A, int slot)
+{
+    const int f = blockIdx.y;
+    u32* fl = A.flags + (size_t)f * CTM_NFLAGS;
+    constexpr bool is_round = PH == CTM_LEAD || PH == CTM_EXT || PH == CTM_DIST;
+    if (is_round && !ctj_gld(fl + slot - 1)) return;       // the launch before this one changed nothing: the sequence is through
+    const ctj_frame F = ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap);
+    if (PH == CTM_LEAD_INIT && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < CTM_NFLAGS; i += 256) ctj_gst(fl + i, (i % CTM_SEQ) == 0 ? 1u : 0u);   // every sequence runs its first round
+        if (A.nheads_out && threadIdx.x == 0) A.nheads_out[f] = F.H;
+    }
+    int changed = 0;
+    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < F.H; k += gridDim.x * 256) {
+        if (PH == CTM_LEAD_INIT) ctj_lead_init<false>(F, k);
+        if (PH == CTM_LEAD)
+            for (int h = 0; h < A.hops; h++) changed |= ctj_lead_step<false>(F, k) ? 1 : 0;
+        if (PH == CTM_EXT_INIT) ctj_ext_init<false>(F, k);
+        if (PH == CTM_EXT)
+            for (int h = 0; h < A.hops; h++) changed |= ctj_ext_step<false>(F, k) ? 1 : 0;
+        if (PH == CTM_RANK) ctj_rank(F, k, A.G, A.starts + (size_t)f * A.max_contours, A.shead + (size_t)f * A.max_contours, A.max_contours);
+        if (PH == CTM_MARK) ctj_mark<false>(F, k);
+        if (PH == CTM_DIST)
+            for (int h = 0; h < A.hops; h++) changed |= ctj_dist_step<false>(F.nd, k) ? 1 : 0;
+    }
+    if (is_round && changed) ctj_gst(fl + slot, 1u);
+}
+// (the distances' start is a launch of its own, after the marks: it needs the mark of every head's successor)
+__global__ __launch_bounds__(256) void k_ctm_dist_init(ctj_args A)
+{
+    const int f = blockIdx.y;
+    const ctj_frame F = ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap);
+    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < F.H; k += gridDim.x * 256) ctj_dist_init<false>(F, F.nd, k);
+}
+
+// the two scans (returned borders before each head; points before each contour), two launches each: sums of chunks of 1024 items,
+// then every chunk adds up the sums before it and scans itself.  WHAT 0: heads -> hr[k]; 1: contours -> offsets, counts, is_hole
+template <int WHAT>
+__device__ __forceinline__ u32 ctm_item(const ctj_args& A, const ctj_frame& F, int f, u32 i, u32 n_items)
+{
+    if (i >= n_items) return 0u;
+    if (WHAT == 0) return ctj_selected<false>(F, i, A.mode);
+    const u32 sh = A.shead[(size_t)f * A.max_contours + i];
+    return (u32)ctj_ld<false>(F.nd, sh);                  // the leader's distance around its cycle = the contour's length
+}
+template <int WHAT>
+__global__ __launch_bounds__(1024) void k_ctm_sums(ctj_args A)
+{
+    __shared__ u32 s_w[16];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const ctj_frame F = ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap);
+    const u32 n_items = WHAT == 0 ? F.H : min(A.aux[f].nsel, (u32)A.max_contours);
+    const u32 nchunks = (n_items + 1023u) / 1024u;
+    u32* cs = A.csum + (size_t)f * (A.hcap / 1024 + 2);
+    for (u32 c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        u32 v = ctm_item<WHAT>(A, F, f, c * 1024u + tid, n_items);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0) s_w[wv] = v;
+        __syncthreads();
+        if (tid == 0) { u32 t = 0; for (int q = 0; q < 16; q++) t += s_w[q]; cs[c] = t; }
+        __syncthreads();
+    }
+}
+template <int WHAT>
+__global__ __launch_bounds__(1024) void k_ctm_scan(ctj_args A)
+{
+    __shared__ u32 s_w[16], s_t[16];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const ctj_frame F = ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap);
+    const u32 nsel = WHAT == 0 ? 0u : A.aux[f].nsel;
+    const u32 n_items = WHAT == 0 ? F.H : min(nsel, (u32)A.max_contours);
+    const u32 nchunks = (n_items + 1023u) / 1024u;
+    const u32* cs = A.csum + (size_t)f * (A.hcap / 1024 + 2);
+    if (nchunks == 0 && blockIdx.x == 0 && tid == 0) {
+        if (WHAT == 0) A.aux[f].nsel = 0u;
+        else { A.out[f].n_contours = (int32_t)nsel; A.out[f].n_points = 0; }
+    }
+    for (u32 c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        u32 pre = 0;
+        for (u32 q = tid; q < c; q += 1024) pre += cs[q];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+        if (lane == 0) s_t[wv] = pre;
+        const u32 i = c * 1024u + tid;
+        const u32 v = ctm_item<WHAT>(A, F, f, i, n_items);
+        u32 inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        u32 carry = 0, woff = 0;
+        for (int q = 0; q < 16; q++) carry += s_t[q];
+        for (int q = 0; q < wv; q++) woff += s_w[q];
+        const u32 excl = carry + woff + inc - v;
+        if (i < n_items) {
+            if (WHAT == 0) ctj_gst(F.hr + i, (excl << 1) | v);
+            else {
+                const size_t o = (size_t)f * A.max_contours + i;
+                A.counts[o] = (int32_t)v;
+                A.is_hole[o] = (uint8_t)(A.starts[o] >> 31);
+                A.offsets[o] = (int32_t)excl;
+            }
+        }
+        if (c == nchunks - 1 && tid == 1023) {
+            if (WHAT == 0) A.aux[f].nsel = excl + v;
+            else { A.out[f].n_contours = (int32_t)nsel; A.out[f].n_points = (int32_t)(excl + v); }
+        }
+        __syncthreads();
+    }
 }
 #undef dx8
 #undef dy8
@@ -663,286 +842,99 @@ int vpk_contour_features(vp_ctx* ctx, const int32_t* d_info, const int32_t* d_co
 
 size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
 {
-    const size_t nids = vp_ccl_nids(w, h);
     const size_t words = (size_t)n * h * vp_ww(w);
     const size_t hcap = ct_hcap(w, h) * n;
-    return 2 * vp_align(nids * 4 * n) + 3 * vp_align(nids / 8 * n) + 3 * vp_align(words * 8) + vp_align(words * 32) + 2 * vp_align(words * 4) +
-           2 * vp_align(hcap * 4) + vp_align(hcap * 8) + 2 * vp_align((size_t)n * max_contours * 4) + vp_align(sizeof(ct_aux) * n) + 2 * vp_align(words / 64 + 4 * n) + vp_align((size_t)n * 4) + 8192;
+    return vp_align(words * 32) + vp_align(words * 4) + vp_align(words) + 4 * vp_align(hcap * 4) + 2 * vp_align(hcap * 8) +
+           2 * vp_align((size_t)n * max_contours * 4) + vp_align(sizeof(ct_aux) * n) + vp_align(words / 64 + 4 * n) +
+           vp_align((size_t)n * CTM_NFLAGS * 4) + vp_align((ct_hcap(w, h) / 1024 + 2) * 4 * n) + 8192;
 }
 
-// Root bitmap of the foreground from a labelling that already exists: a component's first pixel in raster order lies in the top row of
-// its box and is the first pixel of that row that carries its label; the segment starting there is the component's smallest segment id
-// (pixel numbering) - the bit the foreground union-find would have left.  One wave per label; frames whose statistics table was too
-// small for their labels are marked in `only` and go through the union-find as before.  grid (ceil((max_labels - 1) / 4), n) x 256.
-__global__ __launch_bounds__(256) void k_ct_roots_from_labels(ccl_geom G, const int32_t* __restrict__ labels, const int32_t* __restrict__ stats,
-                                                              const int32_t* __restrict__ nlabels, int max_labels, u32* __restrict__ flags,
-                                                              u32* __restrict__ only)
-{
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int nl = nlabels[f];
-    if (blockIdx.x == 0 && threadIdx.x == 0) only[f] = nl > max_labels ? 1u : 0u;
-    if (nl > max_labels) return;
-    const int L = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
-    if (L >= nl) return;
-    const int32_t* st = stats + ((size_t)f * max_labels + L) * 5;
-    const int x0 = st[0], y = st[1], x1 = st[0] + st[2];
-    const int32_t* row = labels + ((size_t)f * G.h + y) * G.w;
-    for (int xb = x0; xb < x1; xb += 64) {
-        const int x = xb + lane;
-        const unsigned long long m = __ballot(x < x1 && row[x] == L);
-        if (m) {
-            if (lane == 0) {
-                const u32 id = seg_id(G, y, xb + __ffsll((long long)m) - 1);
-                atomicOr(flags + (size_t)f * G.nw32 + (id >> 5), 1u << (id & 31));
-            }
-            return;
-        }
-    }
-}
-
-// RETR_EXTERNAL with the components' boxes at hand (the chain has just labelled this mask): a component inside a hole of another one
-// has that one's pixels on all four sides, so its box lies STRICTLY inside the other's.  A frame without such a pair of boxes has only
-// external components: its background - the long half of a contour pass - is not needed at all.  bg_only[f] = 1: resolve it (a pair
-// exists, or the statistics table did not hold all labels, or there are too many labels to compare in passing).  grid n x 256.
-#define CT_NEEDS_BG_MAX 512
-__global__ __launch_bounds__(256) void k_ct_needs_bg(const int32_t* __restrict__ stats, const int32_t* __restrict__ nlabels, int max_labels,
-                                                     u32* __restrict__ bg_only)
-{
-    const int f = blockIdx.x;
-    const int nl = nlabels[f];
-    if (nl > max_labels || nl > CT_NEEDS_BG_MAX) { if (threadIdx.x == 0) bg_only[f] = 1u; return; }
-    const int32_t* st = stats + (size_t)f * max_labels * 5;
-    int found = 0;
-    for (int a = 1 + (int)threadIdx.x; a < nl && !found; a += 256) {
-        const int ax0 = st[a * 5], ay0 = st[a * 5 + 1], ax1 = ax0 + st[a * 5 + 2] - 1, ay1 = ay0 + st[a * 5 + 3] - 1;
-        for (int b = 1; b < nl; b++) {
-            const int bx0 = st[b * 5], by0 = st[b * 5 + 1], bx1 = bx0 + st[b * 5 + 2] - 1, by1 = by0 + st[b * 5 + 3] - 1;
-            if (bx0 < ax0 && by0 < ay0 && bx1 > ax1 && by1 > ay1) { found = 1; break; }
-        }
-    }
-    const int any = __syncthreads_or(found);
-    if (threadIdx.x == 0) bg_only[f] = any ? 1u : 0u;
-}
-
-// A contour pass in three steps, so that a caller with other work for the context's stream (the chain: its own labelling and the
-// label write, 260 us per 128 frames) can put it between the second and the third:
-//   ct_pass_setup        geometry, scratch carved from the workspace
-//   ct_pass_background   the background half - 4-connected union-find of the inverted mask, which regions reach the frame - queued
-//                        on the context's SIDE stream behind everything queued so far on its own stream
-//   ct_pass_finish       the foreground half, the join, seeds, starts, follower passes on the context's stream
-// vpk_find_contours runs the three back to back.
-static bool ct_known_usable(const vp_known_labels* known, const ccl_geom& Gf)
-{
-    size_t cap_unused;
-    static const bool known_off = getenv("VP_CT_KNOWN") && atoi(getenv("VP_CT_KNOWN")) == 0;
-    return known && !known_off && known->labels && known->stats && known->nlabels && known->max_labels >= 2 && known->max_labels <= 4096 &&
-           ccl_local_lds(Gf, cap_unused) <= 64 * 1024;
-}
-
-struct ct_pass {
-    ccl_geom Gf, Gb;
-    int w, h, n, nwords;
-    size_t hcap, nparts, mstride;
-    u32 *fg_parent, *bg_parent, *fg_flags, *bg_flags, *outside, *hbase, *head_pix, *hrank, *starts, *shead, *partsum, *partsum2;
-    uint8_t* cnt8;             // heads per word
-    u64 *maps3, *hmaps;
-    unsigned long long* node;
-    ct_aux* aux;
-    u32* bg_only;              // nullable, per frame: 1 = the background is resolved, 0 = not needed (k_ct_needs_bg)
-    hipError_t bg_join;        // result of recording the side stream's end event
-    bool bg_queued;
-    int rc_bg;                 // what queueing the background half returned (vpk_contours_begin / _finish)
-};
-
-static int ct_pass_setup(vp_ctx* ctx, int w, int h, int n, int max_contours, ct_pass* P)
-{
-    if ((size_t)w * h >= (1u << 29)) return vp_fail(ctx, VP_ERR_INVALID, "contours: image too large");
-    ccl_geom& Gf = P->Gf;
-    ccl_geom& Gb = P->Gb;
-    ccl_make_geom(Gf, w, h, VP_CCL_PIXEL, 0, 0);
-    ccl_make_geom(Gb, w, h, VP_CCL_PIXEL, 1, 1);
-    // One image (a module's findContours call) leaves most of the chip idle with 32-row strips (34 blocks at 1080p), and a block's
-    // time grows faster than its strip: shorter strips while the blocks still fit the CUs (1080p, one image: 0.184 -> 0.161 ms per
-    // call with 8 rows).  The strip height only moves work between the strip pass and the boundary pass; parent[] and the root bitmap
-    // come out the same.
-    if (!getenv("VP_CL_ROWS"))
-        for (int r = 8; r < Gf.rows; r *= 2)
-            if (((u32)r * (u32)Gf.wb) % 32u == 0 && (size_t)n * ((h + r - 1) / r) <= (size_t)2 * ctx->num_cu) { Gf.rows = Gb.rows = r; break; }
-    P->w = w; P->h = h; P->n = n;
-    const size_t nids = Gf.nids;
-    P->nwords = h * Gf.ww;
-    const size_t words = (size_t)n * P->nwords;
-    P->hcap = ct_hcap(w, h);
-    P->fg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
-    P->bg_parent = (u32*)vp_ws_take(ctx, nids * 4 * n);
-    P->fg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
-    P->bg_flags = (u32*)vp_ws_take(ctx, nids / 8 * n);
-    P->outside = (u32*)vp_ws_take(ctx, nids / 8 * n);
-    P->maps3 = (u64*)vp_ws_take(ctx, 3 * vp_align(words * 8));   // startmap, holemap, selmap: cleared together
-    P->hmaps = (u64*)vp_ws_take(ctx, words * 32);
-    P->hbase = (u32*)vp_ws_take(ctx, words * 4);
-    u32* sbase = (u32*)vp_ws_take(ctx, words * 4);   // (the first quarter holds the per-word head counts; the rest is unused since k_ct_starts ranks the starts itself)
-    P->cnt8 = reinterpret_cast<uint8_t*>(sbase);
-    P->head_pix = (u32*)vp_ws_take(ctx, P->hcap * n * 4);
-    P->hrank = (u32*)vp_ws_take(ctx, P->hcap * n * 4);
-    P->node = (unsigned long long*)vp_ws_take(ctx, P->hcap * n * 8);
-    P->starts = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
-    P->shead = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
-    P->aux = (ct_aux*)vp_ws_take(ctx, sizeof(ct_aux) * n);
-    P->nparts = (size_t)(P->nwords + 255) / 256;
-    P->partsum = (u32*)vp_ws_take(ctx, P->nparts * n * 4);
-    P->partsum2 = (u32*)vp_ws_take(ctx, P->nparts * n * 4);
-    if (!P->partsum || !P->partsum2 || !P->fg_parent || !P->bg_parent || !P->fg_flags || !P->bg_flags || !P->outside || !P->maps3 || !P->hmaps || !P->hbase ||
-        !sbase || !P->head_pix || !P->hrank || !P->node || !P->starts || !P->shead || !P->aux)
-        return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
-    P->mstride = vp_align(words * 8) / 8;
-    P->bg_only = nullptr;
-    P->bg_queued = false;
-    P->bg_join = hipSuccess;
-    return VP_OK;
-}
-
-// Background regions (4-connected union-find, then which of them reach the frame) on the context's side stream.  Always leaves the
-// side stream's end recorded in ev_fb_join (also after an error), for ct_pass_finish to wait on.
-static int ct_pass_background(vp_ctx* ctx, const u64* d_bits, ct_pass* P)
-{
-    hipStream_t s = ctx->stream;
-    hipStream_t side = ctx->fb_stream;
-    VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s));
-    VP_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fb_fork, 0));
-    ctx->stream = side;
-    int rc = ccl_roots(ctx, d_bits, P->Gb, P->n, P->bg_parent, P->bg_flags, P->bg_only, P->outside);   // (clears `outside` on the way)
-    ctx->stream = s;
-    if (rc == VP_OK)
-        hipLaunchKernelGGL(k_ct_outside, dim3((unsigned)((2 * P->Gb.ww + 2 * P->h + 255) / 256), (unsigned)P->n), dim3(256), 0, side, d_bits, P->Gb, P->bg_parent,
-                           P->outside, P->bg_only);
-    P->bg_join = hipEventRecord(ctx->ev_fb_join, side);
-    P->bg_queued = true;
-    return rc;
-}
+// LDS of the per-frame block of k_ct_jump: 12 B per head (the pair table and the keys); frames with more heads work in global memory
+#define CTJ_LDS_HEADS 8192
 
 // d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
 // stored in discovery order (raster order of the start pixel); cv2 returns them reversed - the caller reverses.
-// `rc_bg`: what ct_pass_background returned (the side stream is joined whatever happened).
-static int ct_pass_finish(vp_ctx* ctx, const u64* d_bits, ct_pass* P, int rc_bg, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
-                          int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
+// Five launches on the context's stream.  `many_heads` (one image whose last pass counted very many heads - the caller's guess, the
+// results do not depend on it): the bookkeeping between the follower passes as launches over the chip instead of one block.
+// d_nheads_out (nullable, [n]): the frames' head counts.
+int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
+                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, bool many_heads,
+                      uint32_t* d_nheads_out)
 {
-    const ccl_geom& Gf = P->Gf;
-    const ccl_geom& Gb = P->Gb;
-    const int n = P->n, w = P->w, nwords = P->nwords;
-    const size_t hcap = P->hcap, nparts = P->nparts, mstride = P->mstride;
-    u32 *fg_parent = P->fg_parent, *bg_parent = P->bg_parent, *fg_flags = P->fg_flags, *bg_flags = P->bg_flags, *outside = P->outside, *hbase = P->hbase,
-        *head_pix = P->head_pix, *hrank = P->hrank, *starts = P->starts, *shead = P->shead, *partsum = P->partsum, *partsum2 = P->partsum2;
-    u64 *maps3 = P->maps3, *hmaps = P->hmaps;
-    unsigned long long* node = P->node;
-    ct_aux* aux = P->aux;
-    u64* startmap = maps3;
-    u64* holemap = maps3 + mstride;
-    u64* selmap = maps3 + 2 * mstride;
+    if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
+    if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
+    if ((size_t)w * h >= (1u << 29)) return vp_fail(ctx, VP_ERR_INVALID, "contours: image too large");
+    ctj_args A;
+    ccl_make_geom(A.G, w, h, VP_CCL_PIXEL, 0, 0);
+    const ccl_geom& G = A.G;
+    const int nwords = h * G.ww;
+    const size_t words = (size_t)n * nwords;
+    const size_t hcap = ct_hcap(w, h);
+    u64* hmaps = (u64*)vp_ws_take(ctx, words * 32);
+    u32* hbase = (u32*)vp_ws_take(ctx, words * 4);
+    uint8_t* cnt8 = (uint8_t*)vp_ws_take(ctx, words);
+    u32* head_pix = (u32*)vp_ws_take(ctx, hcap * n * 4);
+    A.hrank = (u32*)vp_ws_take(ctx, hcap * n * 4);
+    u32* hkey = (u32*)vp_ws_take(ctx, hcap * n * 4);
+    A.hext = (u32*)vp_ws_take(ctx, hcap * n * 4);
+    A.node = (unsigned long long*)vp_ws_take(ctx, hcap * n * 8);
+    A.node2 = (unsigned long long*)vp_ws_take(ctx, hcap * n * 8);
+    A.starts = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
+    A.shead = (u32*)vp_ws_take(ctx, (size_t)n * max_contours * 4);
+    A.aux = (ct_aux*)vp_ws_take(ctx, sizeof(ct_aux) * n);
+    const size_t nparts = (size_t)(nwords + 255) / 256;
+    u32* partsum = (u32*)vp_ws_take(ctx, nparts * n * 4);
+    A.flags = (u32*)vp_ws_take(ctx, (size_t)n * CTM_NFLAGS * 4);
+    A.csum = (u32*)vp_ws_take(ctx, (hcap / 1024 + 2) * 4 * n);
+    if (!hmaps || !hbase || !cnt8 || !head_pix || !A.hrank || !hkey || !A.hext || !A.node || !A.node2 || !A.starts || !A.shead || !A.aux || !partsum ||
+        !A.flags || !A.csum)
+        return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
+    static bool lds_set = false;
+    const size_t jump_lds = (size_t)CTJ_LDS_HEADS * 12;
+    if (!lds_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ct_jump), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jump_lds));
+        lds_set = true;
+    }
+    A.hkey = hkey; A.hbase = hbase; A.cnt8 = cnt8; A.head_pix = head_pix; A.hcap = hcap;
+    A.counts = d_counts; A.is_hole = d_is_hole; A.offsets = d_offsets; A.points = d_points;
+    A.out = reinterpret_cast<ct_frame_out*>(d_info);
+    A.max_contours = max_contours; A.max_points = max_points; A.mode = mode; A.lds_heads = CTJ_LDS_HEADS; A.nheads_out = d_nheads_out;
+    A.hops = 3;
     hipStream_t s = ctx->stream;
-    ct_frame_out* info = reinterpret_cast<ct_frame_out*>(d_info);
     vp_prof_scope ps(ctx, VPK_OTHER);
     const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
     // heads per frame are not known on the host: a fixed number of blocks per frame walks the head list (a real mask has a few
     // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
     const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
-    int rc = rc_bg;
-    {
-        // the foreground's root bitmap: from the caller's labelling of the same mask when there is one (frames it could not hold keep
-        // the union-find through its per-frame switch), otherwise the union-find for every frame
-        const bool use_known = ct_known_usable(known, Gf);
-        if (rc == VP_OK && use_known) {
-            // (no early return in here: the side stream is joined below whatever happens, and the caller reuses the scratch after an error)
-            u32* only = (u32*)vp_ws_take(ctx, (size_t)n * 4);
-            if (!only) rc = vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
-            if (rc == VP_OK) {
-                const hipError_t em = hipMemsetAsync(fg_flags, 0, (size_t)Gf.nw32 * 4 * n, s);
-                if (em != hipSuccess) rc = vp_fail(ctx, VP_ERR_HIP, "hipMemsetAsync (root bitmap)", em);
-            }
-            if (rc == VP_OK) {
-                hipLaunchKernelGGL(k_ct_roots_from_labels, dim3((unsigned)((known->max_labels - 1 + 3) / 4), (unsigned)n), dim3(256), 0, s, Gf, known->labels,
-                                   known->stats, known->nlabels, known->max_labels, fg_flags, only);
-                rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags, only);
-            }
-        } else if (rc == VP_OK) {
-            rc = ccl_roots(ctx, d_bits, Gf, n, fg_parent, fg_flags);
+    hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
+    hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &A.aux->nheads, 2, w, G.ww, head_pix, hcap, cnt8);
+    hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method,
+                       d_offsets, d_points, max_contours, max_points);
+    if (!many_heads) {
+        hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), jump_lds, s, A);
+    } else {
+        // a launch of `hops` steps multiplies the shortest window (distance jumped) by hops + 1 at least: rounds that always suffice
+        int rounds = 2;
+        for (size_t reach = 1; reach < hcap; reach *= (size_t)(A.hops + 1)) rounds++;
+        if (rounds >= CTM_SEQ) return vp_fail(ctx, VP_ERR_INVALID, "contours: image too large");
+        const dim3 mg((unsigned)std::max(32, std::min(1024, 8192 / n)), (unsigned)n), sg((unsigned)std::max(8, std::min(256, 2048 / n)), (unsigned)n);
+        hipLaunchKernelGGL((k_ctm<CTM_LEAD_INIT>), mg, dim3(256), 0, s, A, 0);
+        for (int i = 1; i <= rounds; i++) hipLaunchKernelGGL((k_ctm<CTM_LEAD>), mg, dim3(256), 0, s, A, i);
+        if (mode == 0) {
+            hipLaunchKernelGGL((k_ctm<CTM_EXT_INIT>), mg, dim3(256), 0, s, A, 0);
+            for (int i = 1; i <= rounds; i++) hipLaunchKernelGGL((k_ctm<CTM_EXT>), mg, dim3(256), 0, s, A, CTM_SEQ + i);
         }
+        hipLaunchKernelGGL((k_ctm_sums<0>), sg, dim3(1024), 0, s, A);
+        hipLaunchKernelGGL((k_ctm_scan<0>), sg, dim3(1024), 0, s, A);
+        hipLaunchKernelGGL((k_ctm<CTM_RANK>), mg, dim3(256), 0, s, A, 0);
+        hipLaunchKernelGGL((k_ctm<CTM_MARK>), mg, dim3(256), 0, s, A, 0);
+        hipLaunchKernelGGL(k_ctm_dist_init, mg, dim3(256), 0, s, A);
+        for (int i = 1; i <= rounds; i++) hipLaunchKernelGGL((k_ctm<CTM_DIST>), mg, dim3(256), 0, s, A, 2 * CTM_SEQ + i);
+        hipLaunchKernelGGL((k_ctm_sums<1>), sg, dim3(1024), 0, s, A);
+        hipLaunchKernelGGL((k_ctm_scan<1>), sg, dim3(1024), 0, s, A);
     }
-    if (rc == VP_OK) {
-        hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, Gf, hmaps, partsum, maps3, mstride, partsum2, P->cnt8);
-        hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &aux->nheads, 2, w, Gf.ww, head_pix, hrank, hcap, P->cnt8);
-    }
-    // join whatever was queued on the side stream, also after an error
-    const hipError_t j1 = P->bg_queued ? P->bg_join : hipSuccess;
-    const hipError_t j2 = (P->bg_queued && j1 == hipSuccess) ? hipStreamWaitEvent(s, ctx->ev_fb_join, 0) : j1;
-    P->bg_queued = false;
-    if (rc != VP_OK) return rc;
-    if (j1 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", j1);
-    if (j2 != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipStreamWaitEvent", j2);
-    hipLaunchKernelGGL(k_ct_seeds, dim3((unsigned)((Gf.nw32 + 255) / 256), (unsigned)n), dim3(256), 0, s, d_bits, Gf, Gb, fg_flags, bg_flags, bg_parent,
-                       outside, mode, startmap, holemap, selmap, partsum2, (int)nparts, P->bg_only);
-    hipLaunchKernelGGL(k_ct_starts, wgrid, dim3(256), 0, s, d_bits, Gf, startmap, holemap, selmap, partsum2, &aux->nsel, hmaps, hbase, hrank, hcap, starts,
-                       shead, max_contours);
-    hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
-                       max_contours, max_points);
-    hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), 0, s, Gf, aux, node, hcap, starts, shead, d_counts, d_is_hole, d_offsets, d_points, info,
-                       max_contours, max_points);
-    hipLaunchKernelGGL((k_ct_seg<true>), hgrid, dim3(256), 0, s, d_bits, Gf, hmaps, hbase, head_pix, hrank, hcap, aux, node, method, d_offsets, d_points,
-                       max_contours, max_points);
+    hipLaunchKernelGGL((k_ct_seg<true>), hgrid, dim3(256), 0, s, d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method,
+                       d_offsets, d_points, max_contours, max_points);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
-}
-
-// The same in two calls, for a caller that has other work for the context's stream in between (vp_api.hip chain_core: the background
-// half is queued as soon as the mask exists and runs beside the chain's own labelling and label write).  `*pass` is owned by the pair:
-// vpk_contours_finish frees it (also on failure); a caller that cannot reach finish calls it with d_counts == NULL to join and free.
-int vpk_contours_begin(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int max_contours, void** pass)
-{
-    ct_pass* P = new (std::nothrow) ct_pass();
-    if (!P) return vp_fail(ctx, VP_ERR_NOMEM, "contour pass");
-    int rc = ct_pass_setup(ctx, w, h, n, max_contours, P);
-    if (rc != VP_OK) { delete P; *pass = nullptr; return rc; }
-    P->rc_bg = ct_pass_background(ctx, d_bits, P);
-    *pass = P;
-    return VP_OK;          // (a failure of the background half is reported by finish, after the join)
-}
-
-int vpk_contours_finish(vp_ctx* ctx, void* pass, const u64* d_bits, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole, int32_t* d_offsets,
-                        int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
-{
-    ct_pass* P = static_cast<ct_pass*>(pass);
-    if (!P) return vp_fail(ctx, VP_ERR_INVALID, "contour pass");
-    int rc;
-    if (!d_counts) {       // abandoned: only the join
-        rc = (P->bg_queued && P->bg_join == hipSuccess && hipStreamWaitEvent(ctx->stream, ctx->ev_fb_join, 0) != hipSuccess) ? VP_ERR_HIP : VP_OK;
-    } else if ((mode != 0 && mode != 1) || (method != 1 && method != 2)) {
-        (void)(P->bg_queued && P->bg_join == hipSuccess && hipStreamWaitEvent(ctx->stream, ctx->ev_fb_join, 0));
-        rc = vp_fail(ctx, VP_ERR_INVALID, "contour mode / approximation");
-    } else {
-        rc = ct_pass_finish(ctx, d_bits, P, P->rc_bg, mode, method, d_counts, d_is_hole, d_offsets, d_points, max_contours, max_points, d_info, known);
-    }
-    delete P;
-    return rc;
-}
-
-int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
-                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known)
-{
-    if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
-    if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
-    ct_pass P;
-    const int rc_setup = ct_pass_setup(ctx, w, h, n, max_contours, &P);
-    if (rc_setup != VP_OK) return rc_setup;
-    // Two independent halves up to the seeds: background regions on the context's side stream, foreground components and the head
-    // bitmaps on its own stream.  Each half is a chain of short, latency-bound launches, so side by side they take the time of one
-    // (one 1080p frame: 0.19 -> 0.15 ms per call).
-    static const bool skip_off = getenv("VP_CT_SKIP_BG") && atoi(getenv("VP_CT_SKIP_BG")) == 0;
-    if (mode == 0 && !skip_off && ct_known_usable(known, P.Gf)) {
-        // RETR_EXTERNAL of a mask whose components' boxes are known: frames without nested boxes skip the background half
-        P.bg_only = (u32*)vp_ws_take(ctx, (size_t)n * 4);
-        if (!P.bg_only) return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
-        hipLaunchKernelGGL(k_ct_needs_bg, dim3((unsigned)n), dim3(256), 0, ctx->stream, known->stats, known->nlabels, known->max_labels, P.bg_only);
-    }
-    const int rc_bg = ct_pass_background(ctx, d_bits, &P);
-    return ct_pass_finish(ctx, d_bits, &P, rc_bg, mode, method, d_counts, d_is_hole, d_offsets, d_points, max_contours, max_points, d_info, known);
 }

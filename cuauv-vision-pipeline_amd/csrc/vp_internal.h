@@ -37,6 +37,7 @@ struct vp_ctx {
     size_t ws_off;
     uint8_t* hstage;  // grow-only pinned host staging for small results (contour lists)
     size_t hstage_cap;
+    uint32_t ct_heads_hint;   // border segments the last single-image contour pass counted (vp_find_contours_*: which form of the bookkeeping to launch)
     int num_cu;
     int chain_streams;            // sub-batches of a chain run on this many internal streams (>= 1)
     hipStream_t aux[4];
@@ -190,18 +191,11 @@ void vp_ccl_ws_carve(vp_ctx* ctx, int w, int h, int n, int max_labels, vp_ccl_ws
 size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours);
 int vpk_contour_features(vp_ctx* ctx, const int32_t* d_info, const int32_t* d_counts, const int32_t* d_offsets, const int32_t* d_points, int n,
                          int max_contours, long long max_points, double* d_features);
-// A labelling of the very mask the contours are asked for, when the caller has one (the chain's): label image, statistics rows and
-// label counts of the same frames, all on the device.  The contour pass then takes every component's first pixel from them instead of
-// running its own foreground union-find.
-struct vp_known_labels { const int32_t* labels; const int32_t* stats; const int32_t* nlabels; int max_labels; };
+// contours of n bit images (no labelling involved: vp_contours.inl).  many_heads: the caller expects a frame with very many border
+// segments (its last pass said so through d_nheads_out) - a choice between two forms of the same steps, not of the result
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
-                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info,
-                      const struct vp_known_labels* known = nullptr);
-// the same in two calls: begin queues the background half on the context's side stream, finish does the rest on its own stream (and
-// frees *pass; d_counts == NULL: join and free only)
-int vpk_contours_begin(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int max_contours, void** pass);
-int vpk_contours_finish(vp_ctx* ctx, void* pass, const u64* d_bits, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole, int32_t* d_offsets,
-                        int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, const vp_known_labels* known);
+                      int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, bool many_heads = false,
+                      uint32_t* d_nheads_out = nullptr);
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
             int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels);
 

@@ -9,6 +9,14 @@ import frames as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["one_block", "launches"])
+def bookkeeping_form(request, monkeypatch):
+    """The single-image entries run the cycle bookkeeping between the two follower passes either in one block (the form a module's mask
+    takes) or as launches over the chip (the form chosen after a speckled mask); which one is a guess from the context's last call and
+    must not show in the results: every test of this file runs with each form forced (VP_CT_MANY)."""
+    monkeypatch.setenv("VP_CT_MANY", "0" if request.param == "one_block" else "1")
+
+
 def _same(a, b):
     return len(a) == len(b) and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a, b))
 
