@@ -41,8 +41,9 @@ struct ct_frame_out {      // per frame, device
 // Between s and s' the follower sweeps over background neighbours.  Every crack (edge between a foreground pixel and a
 // 4-adjacent background pixel) is swept by exactly one state of exactly one border, and that state can be written down from
 // the crack alone: s = first foreground neighbour clockwise from the crack's direction.  So the states that sweep a W or E
-// crack (and, to cut long flat edges, an N or S crack at x % 8 == 0) are enumerable with bit operations - the "heads" - and
-// they cut every border into short segments that are followed independently, one thread each.  A pixel without neighbours is a
+// crack in a row y % 4 == 0 or an N or S crack in a column x % 8 == 0 (and every W or E crack that a border could start at) are
+// enumerable with bit operations - the "heads" - and they cut every border into short segments that are followed independently, one
+// thread each.  A pixel without neighbours is a
 // border of its own: one head (listed with the W heads), one point.
 //   k_ct_headmaps   4 head bitmaps per word (a state that sweeps several eligible cracks belongs to the first one swept)
 //   k_ct_prefix     popcount prefix -> dense head index + head list (pixel, type)
@@ -114,10 +115,14 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
         const u64 el = CT_EL_NS;
         u64 hw = 0, he = 0, hn = 0, hs = 0;
         if (c) {
-            hw = c & ~n[4] & (n[3] | n[2] | (~el & (n[1] | n[0])));
-            he = c & ~n[0] & (n[7] | n[6] | (~el & (n[5] | n[4])));
-            hn = c & ~n[2] & el & (n[1] | n[0]);
-            hs = c & ~n[6] & el & (n[5] | n[4]);
+            // eligible cracks: N / S in columns x % 8 == 0; W / E in rows y % 4 == 0 and wherever the crack could be the smallest of
+            // its border (W: nothing above the pixel; E: the background pixel has foreground above it) - see ct_head_type
+            const u64 rowel = (y & 3) == 0 ? ~0ull : 0ull;
+            const u64 elw = rowel | ~(n[1] | n[2] | n[3]), ele = rowel | n[1];
+            hw = c & ~n[4] & elw & (n[3] | n[2] | (~el & (n[1] | n[0] | (~ele & (n[7] | n[6] | n[5])))));
+            he = c & ~n[0] & ele & (n[7] | n[6] | (~el & (n[5] | n[4] | (~elw & (n[3] | n[2] | n[1])))));
+            hn = c & ~n[2] & el & (n[1] | n[0] | (~ele & (n[7] | n[6])));
+            hs = c & ~n[6] & el & (n[5] | n[4] | (~elw & (n[3] | n[2])));
             hw |= c & ~(n[0] | n[1] | n[2] | n[3] | n[4] | n[5] | n[6] | n[7]);      // a pixel on its own: one state, one head
         }
         cnt = (u32)(__popcll(hw) + __popcll(he) + __popcll(hn) + __popcll(hs));
@@ -249,15 +254,21 @@ __device__ __forceinline__ int ct_first_cw(u32 R, int d)
     const u32 rr = ((R | (R << 8)) >> d) & 0xfeu;   // bit i = direction d + i, i = 1..7
     return (d + (31 - __clz((int)rr))) & 7;
 }
-// state (s, sweep length t = number of background neighbours swept before s') at column x: type of the head that owns it
-// (0 W, 1 E, 2 N, 3 S) or -1
-__device__ __forceinline__ int ct_head_type(int s, int t, int x)
+// state (s, sweep length t = number of background neighbours swept before s') of pixel (y, x) with neighbour ring R: type of the
+// head that owns it (0 W, 1 E, 2 N, 3 S) = the first ELIGIBLE crack it sweeps, or -1 (the state is not a head).  Eligible: N / S
+// cracks in columns x % 8 == 0; W / E cracks in rows y % 4 == 0 - these cut every border into segments of a few pixels - and every
+// W / E crack that could be the smallest of its border: a W crack of a pixel with nothing above it (a component's first pixel is such
+// a one), an E crack whose background pixel has foreground above it (a hole's first pixel is such a one) - so that every border has
+// a head at its start state.  (Every vertical crack used to be a head: 2.3 x the heads on a module's mask, and the bookkeeping
+// between the two follower passes is bound by exactly that number.)
+__device__ __forceinline__ int ct_head_type(int s, int t, int x, int y, u32 R)
 {
     const int iw = (3 - s) & 7, ie = (7 - s) & 7, in = (1 - s) & 7, is = (5 - s) & 7;
-    const bool ns = (x & 7) == 0;
+    const bool ns = (x & 7) == 0, rowel = (y & 3) == 0;
+    const bool elw = rowel || !(R & 0xeu), ele = rowel || (R & 2u);
     int best = 8, type = -1;
-    if (iw < t) { best = iw; type = 0; }
-    if (ie < t && ie < best) { best = ie; type = 1; }
+    if (elw && iw < t) { best = iw; type = 0; }
+    if (ele && ie < t && ie < best) { best = ie; type = 1; }
     if (ns && in < t && in < best) { best = in; type = 2; }
     if (ns && is < t && is < best) { best = is; type = 3; }
     return type;
@@ -268,8 +279,8 @@ __device__ __forceinline__ int ct_head_type(int s, int t, int x)
 __device__ __forceinline__ u32 ct_key_w(const ccl_geom& G, int y, int x) { return ((u32)y * (u32)(G.w + 1) + (u32)x) << 1; }
 __device__ __forceinline__ u32 ct_key_e(const ccl_geom& G, int y, int x) { return (((u32)y * (u32)(G.w + 1) + (u32)x + 1u) << 1) | 1u; }
 
-// RETR_EXTERNAL: what lies left of a possible first pixel (y, x) in its row: CT_FRAME, or the head that owns the E crack of the first
-// foreground pixel met
+// RETR_EXTERNAL: what lies left of a possible first pixel (y, x) in its row: CT_FRAME, or a head of the border that owns the E crack
+// of the first foreground pixel met (the first head at or after the state that sweeps that crack)
 __device__ __forceinline__ u32 ct_left_of(const ccl_geom& G, const u64* __restrict__ fb, const u64* __restrict__ hm, const u32* __restrict__ hb,
                                           int y, int x)
 {
@@ -278,17 +289,26 @@ __device__ __forceinline__ u32 ct_left_of(const ccl_geom& G, const u64* __restri
     u64 m = row[j] & ((1ull << (x & 63)) - 1ull);
     while (!m && j > 0) m = row[--j];
     if (!m) return CT_FRAME;
-    const int xq = 64 * j + 63 - __clzll((long long)m);
+    x = 64 * j + 63 - __clzll((long long)m);
     ct_tile T;
-    ct_tile_load(G, fb, y - 3, xq - 3, T);
-    const u32 R = ct_ring(T, y, xq);
-    int type = 0;                                       // a pixel on its own: its one head is listed with the W heads
-    if (R) {
-        const int s = ct_first_cw(R, 0);
+    ct_tile_load(G, fb, y - 3, x - 3, T);
+    u32 R = ct_ring(T, y, x);
+    if (!R) return ct_head_index(hm, hb, y * G.ww + (x >> 6), x & 63, 0);      // a pixel on its own: its one head is listed with the W heads
+    int s = ct_first_cw(R, 0);
+    for (long long guard = 8ll * G.w * G.h + 16; guard > 0; guard--) {
         const int t = __ffs((int)((R | (R << 8)) >> (s + 1))) - 1;
-        type = ct_head_type(s, t, xq);                  // >= 0: the sweep crosses the E crack
+        const int ht = ct_head_type(s, t, x, y, R);
+        if (ht >= 0) return ct_head_index(hm, hb, y * G.ww + (x >> 6), x & 63, ht);
+        const int s2 = (s + 1 + t) & 7;
+        x += dx8(s2); y += dy8(s2);
+        s = (s2 + 4) & 7;
+        if (!ct_tile_covers(T, y, x)) {
+            const int dy = dy8(s2), dx = dx8(s2);
+            ct_tile_load(G, fb, y - (dy > 0 ? 1 : (dy < 0 ? 6 : 3)), x - (dx > 0 ? 1 : (dx < 0 ? 6 : 3)), T);
+        }
+        R = ct_ring(T, y, x);
     }
-    return ct_head_index(hm, hb, y * G.ww + (xq >> 6), xq & 63, type);
+    return CT_FRAME;       // (not reached: every border has a head)
 }
 
 // one thread per head: follow the border from the head's state to the next head.
@@ -310,7 +330,14 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
     const u32* hr = hrank + (size_t)f * hcap;
     unsigned long long* nd = node + (size_t)f * hcap;
     const u32 H = aux[f].nheads;
-    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < H; k += gridDim.x * 256) {
+    // !WRITE: two threads per head, in different blocks: one follows the segment, one works out the key and the look to the left (a
+    // chain of dependent loads as long as a short walk: behind the walk in the same thread it was a third of this kernel)
+    const u32 Hp = (H + 255u) & ~255u;
+    const u32 items = WRITE ? H : 2u * Hp;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < items; i += gridDim.x * 256) {
+        const bool keys = !WRITE && i >= Hp;
+        const u32 k = keys ? i - Hp : i;
+        if (k >= H) continue;
         int32_t* out = nullptr;
         if (WRITE) {
             const unsigned long long v = nd[k];
@@ -323,6 +350,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             const long long base = offsets[(size_t)f * max_contours + r];
             if (base + (long long)total > max_points) continue;
             const u32 off = (k == T) ? 0u : total - (u32)v;
+            if (off >= total) continue;                 // (tables that do not add up must not turn into a write outside the contour)
             out = points + 2 * ((size_t)f * max_points + base + off);
         }
         const u32 hp = head_pix[(size_t)f * hcap + k];
@@ -333,20 +361,22 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
         u32 R = ct_ring(T, y, x);
         if (!R) {                                        // a pixel on its own: a border of one point, its own successor
             if (WRITE) { out[0] = x; out[1] = y; }
-            else {
-                nd[k] = ((unsigned long long)k << 32) | 1u;
+            else if (keys) {
                 hkey[(size_t)f * hcap + k] = ct_key_w(G, y, x);
                 if (mode == 0) hext[(size_t)f * hcap + k] = ct_left_of(G, fb, hm, hb, y, x);
+            } else {
+                nd[k] = ((unsigned long long)k << 32) | 1u;
             }
             continue;
         }
         int s = ct_first_cw(R, type == 0 ? 4 : (type == 1 ? 0 : (type == 2 ? 2 : 6)));
-        if (!WRITE) {
+        if (keys) {
             const int t0 = __ffs((int)((R | (R << 8)) >> (s + 1))) - 1;
             const bool sw = ((3 - s) & 7) < t0, se = ((7 - s) & 7) < t0;        // the state sweeps the pixel's W / E crack
             hkey[(size_t)f * hcap + k] = sw ? ct_key_w(G, y, x) : (se ? ct_key_e(G, y, x) : CT_NONE);
             // a component's first pixel has nothing above it: only such a W crack can turn out to be the smallest of its cycle
             if (mode == 0) hext[(size_t)f * hcap + k] = (sw && !(R & 0xeu)) ? ct_left_of(G, fb, hm, hb, y, x) : CT_INSIDE;
+            continue;
         }
         u32 cnt = 0, succ = k;
         bool first = true;
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             const u32 q = (R | (R << 8)) >> (s + 1);
             const int t = __ffs((int)q) - 1;
             if (!first) {
-                const int ht = ct_head_type(s, t, x);
+                const int ht = ct_head_type(s, t, x, y, R);
                 if (ht >= 0) { succ = ct_head_index(hm, hb, y * G.ww + (x >> 6), x & 63, ht); break; }
             }
             first = false;
@@ -377,13 +407,12 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
     }
 }
 
-// per frame: contour lengths from the terminals, exclusive scan -> offsets, total -> out[f].n_points; single-pixel contours are
-// written here.  All NT threads of the block take part.
-template <int NT>
-__device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, int nsel, const u32* __restrict__ starts,
-                                                const u32* __restrict__ shead, const unsigned long long* __restrict__ node, size_t hcap,
-                                                int32_t* __restrict__ counts, uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets,
-                                                int32_t* __restrict__ points, ct_frame_out* __restrict__ out, int max_contours, long long max_points)
+// per frame: contour lengths from the leaders, exclusive scan -> offsets, total -> out[f].n_points.  `dist`: per head of the frame,
+// low 32 bits = a leader's distance around its border = the length of its contour.  All NT threads of the block take part.
+template <int NT, typename DT>
+__device__ __forceinline__ void ct_offsets_body(int nsel, const u32* __restrict__ starts, const u32* __restrict__ shead,
+                                                const DT* dist, int32_t* __restrict__ counts, uint8_t* __restrict__ is_hole_out,
+                                                int32_t* __restrict__ offsets, ct_frame_out* __restrict__ out, int max_contours)
 {
     __shared__ u32 wsum[NT / 64];
     __shared__ u32 carry;
@@ -393,13 +422,11 @@ __device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, int nsel, con
     __syncthreads();
     for (int base = 0; base < K; base += NT) {
         const int i = base + tid;
-        u32 v = 0, st = 0, sh = 0;
+        u32 v = 0;
         if (i < K) {
-            st = starts[(size_t)f * max_contours + i];
-            sh = shead[(size_t)f * max_contours + i];
-            v = (sh == CT_NONE) ? 1u : (u32)node[(size_t)f * hcap + sh];
+            v = (u32)dist[shead[(size_t)f * max_contours + i]];
             counts[(size_t)f * max_contours + i] = (int32_t)v;
-            is_hole_out[(size_t)f * max_contours + i] = (uint8_t)(st >> 31);
+            is_hole_out[(size_t)f * max_contours + i] = (uint8_t)(starts[(size_t)f * max_contours + i] >> 31);
         }
         u32 inc = v;
 #pragma unroll
@@ -408,16 +435,7 @@ __device__ __forceinline__ void ct_offsets_body(const ccl_geom& G, int nsel, con
         __syncthreads();
         u32 woff = 0;
         for (int k = 0; k < wv; k++) woff += wsum[k];
-        if (i < K) {
-            const u32 off = carry + woff + inc - v;
-            offsets[(size_t)f * max_contours + i] = (int32_t)off;
-            if (sh == CT_NONE && (long long)off + 1 <= max_points) {
-                const int pix = (int)(st & 0x7fffffffu);
-                const int y = pix / G.w;
-                int32_t* p = points + 2 * ((size_t)f * max_points + off);
-                p[0] = pix - y * G.w; p[1] = y;
-            }
-        }
+        if (i < K) offsets[(size_t)f * max_contours + i] = (int32_t)(carry + woff + inc - v);
         __syncthreads();
         if (tid == NT - 1) carry += woff + inc;
         __syncthreads();
@@ -446,6 +464,8 @@ template <bool L> __device__ __forceinline__ void ctj_st(unsigned long long* t, 
 }
 __device__ __forceinline__ u32 ctj_gld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctj_gst(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool L> __device__ __forceinline__ u32 ctj_hld(const u32* p) { return L ? *p : ctj_gld(p); }
+template <bool L> __device__ __forceinline__ void ctj_hst(u32* p, u32 v) { if (L) *p = v; else ctj_gst(p, v); }
 
 struct ctj_frame {
     u32 H;
@@ -453,7 +473,8 @@ struct ctj_frame {
     unsigned long long* tab;     // (next, smallest) pairs of step (1)
     const u32* key;
     u32* ext;                    // in: k_ct_seg<false>'s look to the left; then step (2)'s answers; then the ranks of step (3)
-    u32* hr;                     // out: rank of the border a leader starts | CT_UNSEL | CT_NONE (not a leader)
+    u32* hr;                     // step (3)'s counts, then: rank of the border a leader starts | CT_UNSEL | CT_NONE (not a leader)
+    u32* hrg;                    // the same in global memory for k_ct_seg<true> (which asks for leaders only) when hr is in LDS
     const u32* hp;
     const u32* hb;
     const uint8_t* c8;
@@ -502,16 +523,17 @@ template <bool L> __device__ __forceinline__ u32 ctj_selected(const ctj_frame& F
 }
 // (3) with hr[k] = 2 * (returned borders before head k in head order) + (k leads one): head order = scan order of the words; inside a
 // word the heads are listed by type, so there the keys decide
+template <bool L>
 __device__ __forceinline__ void ctj_rank(const ctj_frame& F, u32 k, const ccl_geom& G, u32* __restrict__ starts, u32* __restrict__ shead, int max_contours)
 {
-    if (!(ctj_gld(F.hr + k) & 1u)) return;
+    if (!(ctj_hld<L>(F.hr + k) & 1u)) return;
     const u32 pix = F.hp[k] & 0x1fffffffu;
     const int y = (int)(pix / (u32)G.w), x = (int)(pix - (u32)y * (u32)G.w);
     const int wi = y * G.ww + (x >> 6);
     const u32 b = F.hb[wi], e = b + F.c8[wi];
-    u32 r = ctj_gld(F.hr + b) >> 1;
+    u32 r = ctj_hld<L>(F.hr + b) >> 1;
     const u32 mine = F.key[k];
-    for (u32 q = b; q < e; q++) r += (q != k && (ctj_gld(F.hr + q) & 1u) && F.key[q] < mine) ? 1u : 0u;
+    for (u32 q = b; q < e; q++) r += (q != k && (ctj_hld<L>(F.hr + q) & 1u) && F.key[q] < mine) ? 1u : 0u;
     ctj_gst(F.ext + k, r);
     if (r < (u32)max_contours) {
         starts[r] = pix | ((mine & 1u) << 31);
@@ -520,15 +542,18 @@ __device__ __forceinline__ void ctj_rank(const ctj_frame& F, u32 k, const ccl_ge
 }
 template <bool L> __device__ __forceinline__ void ctj_mark(const ctj_frame& F, u32 k)
 {
-    const u32 v = ctj_gld(F.hr + k);
-    ctj_gst(F.hr + k, (v & 1u) ? ctj_gld(F.ext + k) : (ctj_leads<L>(F, k) ? CT_UNSEL : CT_NONE));
+    const u32 v = ctj_hld<L>(F.hr + k);
+    const bool leads = ctj_leads<L>(F, k);
+    const u32 mark = (v & 1u) ? ctj_gld(F.ext + k) : (leads ? CT_UNSEL : CT_NONE);
+    ctj_hst<L>(F.hr + k, mark);
+    if (L && leads) F.hrg[k] = mark;
 }
 // (4) distances.  t[k] = (J, D): D points lie between this head and head J along the border, until J is the cycle's leader.
 template <bool L> __device__ __forceinline__ void ctj_dist_init(const ctj_frame& F, unsigned long long* t, u32 k)
 {
     const unsigned long long v = F.nd[k];
     const u32 J = (u32)(v >> 32);
-    ctj_st<L>(t, k, ((unsigned long long)(J | (ctj_gld(F.hr + J) != CT_NONE ? CT_TERM : 0u)) << 32) | (u32)v);
+    ctj_st<L>(t, k, ((unsigned long long)(J | (ctj_hld<L>(F.hr + J) != CT_NONE ? CT_TERM : 0u)) << 32) | (u32)v);
 }
 template <bool L> __device__ __forceinline__ bool ctj_dist_step(unsigned long long* t, u32 k)
 {
@@ -541,7 +566,7 @@ template <bool L> __device__ __forceinline__ bool ctj_dist_step(unsigned long lo
 }
 
 template <bool L>
-__device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* keyl, const unsigned long long* __restrict__ node, size_t hcap,
+__device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* keyl, u32* hrl, const unsigned long long* __restrict__ node, size_t hcap,
                                          u32* __restrict__ starts, u32* __restrict__ shead, int32_t* __restrict__ counts,
                                          uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
                                          ct_frame_out* __restrict__ out, int max_contours, long long max_points, int mode)
@@ -554,12 +579,15 @@ __device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* ke
     if (L) {
         for (u32 k = tid; k < H; k += 1024) keyl[k] = F.key[k];
         F.key = keyl;
+        F.hr = hrl;
     }
     for (u32 k = tid; k < H; k += 1024) ctj_lead_init<L>(F, k);
     __syncthreads();
+    // (two steps between barriers: the statements stay true in any order, and a barrier costs about what a step does)
     for (int round = 0; round < max_rounds; round++) {
         int changed = 0;
-        for (u32 k = tid; k < H; k += 1024) changed |= ctj_lead_step<L>(F, k) ? 1 : 0;
+        for (int hop = 0; hop < 2; hop++)
+            for (u32 k = tid; k < H; k += 1024) changed |= ctj_lead_step<L>(F, k) ? 1 : 0;
         if (!__syncthreads_or(changed)) break;
     }
     if (mode == 0) {
@@ -583,13 +611,13 @@ __device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* ke
         __syncthreads();
         u32 woff = 0;
         for (int q = 0; q < wv; q++) woff += s_wsum[q];
-        if (k < H) ctj_gst(F.hr + k, ((s_carry + woff + inc - sel) << 1) | sel);
+        if (k < H) ctj_hst<L>(F.hr + k, ((s_carry + woff + inc - sel) << 1) | sel);
         __syncthreads();
         if (tid == 1023) s_carry += woff + inc;
         __syncthreads();
     }
     const u32 nsel = s_carry;
-    for (u32 k = tid; k < H; k += 1024) ctj_rank(F, k, G, starts + (size_t)f * max_contours, shead + (size_t)f * max_contours, max_contours);
+    for (u32 k = tid; k < H; k += 1024) ctj_rank<L>(F, k, G, starts + (size_t)f * max_contours, shead + (size_t)f * max_contours, max_contours);
     __syncthreads();
     for (u32 k = tid; k < H; k += 1024) ctj_mark<L>(F, k);
     __threadfence_block();
@@ -599,14 +627,15 @@ __device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* ke
     __syncthreads();
     for (int round = 0; round < max_rounds; round++) {
         int changed = 0;
-        for (u32 k = tid; k < H; k += 1024) changed |= ctj_dist_step<L>(t, k) ? 1 : 0;
+        for (int hop = 0; hop < 2; hop++)
+            for (u32 k = tid; k < H; k += 1024) changed |= ctj_dist_step<L>(t, k) ? 1 : 0;
         if (!__syncthreads_or(changed)) break;
     }
     if (L)
         for (u32 k = tid; k < H; k += 1024) F.nd[k] = t[k];
     __threadfence_block();
     __syncthreads();               // the block's own stores to node[] are visible to all its threads from here on
-    ct_offsets_body<1024>(G, (int)nsel, starts, shead, node, hcap, counts, is_hole_out, offsets, points, out, max_contours, max_points);
+    ct_offsets_body<1024>((int)nsel, starts, shead, F.nd, counts, is_hole_out, offsets, out, max_contours);
 }
 
 struct ctj_args {
@@ -642,23 +671,266 @@ __device__ __forceinline__ ctj_frame ctj_make_frame(const ctj_args& A, int f, un
     F.key = A.hkey + (size_t)f * A.hcap;
     F.ext = A.hext + (size_t)f * A.hcap;
     F.hr = A.hrank + (size_t)f * A.hcap;
+    F.hrg = F.hr;
     F.hp = A.head_pix + (size_t)f * A.hcap;
     F.hb = A.hbase + (size_t)f * nwords;
     F.c8 = A.cnt8 + (size_t)f * nwords;
     return F;
 }
 
-extern __shared__ unsigned long long ctj_dyn[];
+
+// The one-block form with every table in LDS (frames of up to CTJ_LDS_HEADS heads: any mask a module makes).  Written out on its own,
+// because what it waits for is not bandwidth: on a nearly idle chip (one image per call) an LDS round trip takes 0.3-0.4 us and a
+// barrier with a vote about as long, so the form is built to need few of them:
+//   * step (1)'s pairs carry the smallest KEY, not the head that has it (a jump then reads one pair, not a pair and two keys); a
+//     head leads iff the smallest key of its border is its own, and the few places that need a leader's index find it among the
+//     heads of the key's word;
+//   * only its owner writes a head's pair, so the owner keeps it in registers: a jump is one 8-byte read at a random place and one
+//     write; each thread takes its (up to 8) heads through a jump together, four jumps between barriers;
+//   * the (next, points) pairs stay in registers from the first load to step (4), and in between only the few leaders touch global
+//     memory.
+// (Steps (1) and (4) as ONE sequence on 16-byte entries (J, D, m, dm, leader) was built and measured: a 16-byte jump costs twice an
+// 8-byte one, 12.8 us against 8.1 + 5.6 - not worth entries whose halves another wave might see apart.)
+// 16 B of LDS per head: tab (8): the pairs of step (1), then of step (4); a1 (4): keys, then (after the ranks are out) the marks;
+// a2 (4): the look to the left / step (2)'s answers, then step (3)'s counts.
+#define CTJ_LDS_HEADS 8192
+#define CTJ_ITEMS (CTJ_LDS_HEADS / 1024)
+#ifndef CTJ_HOPS
+#define CTJ_HOPS 4
+#endif
+__device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, unsigned long long* tab, u32* a1, u32* a2)
+{
+    __shared__ u32 s_wsum[16];
+    __shared__ u32 s_carry;
+    const ccl_geom& G = A.G;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int mode = A.mode;
+    const unsigned long long HI = 0xffffffff00000000ull;
+    unsigned long long* nd = A.node + (size_t)f * A.hcap;
+    const u32* gkey = A.hkey + (size_t)f * A.hcap;
+    const u32* gext = A.hext + (size_t)f * A.hcap;
+    u32* ghr = A.hrank + (size_t)f * A.hcap;
+    const int nwords = G.h * G.ww;
+    const u32* hb = A.hbase + (size_t)f * nwords;
+    const uint8_t* c8 = A.cnt8 + (size_t)f * nwords;
+    u32* starts = A.starts + (size_t)f * A.max_contours;
+    u32* shead = A.shead + (size_t)f * A.max_contours;
+    const int max_rounds = min(CT_JUMP_ROUNDS, 34 - __clz((int)(H | 1u)));
+#ifdef VP_CT_PROBE
+    long long pt[12]; int pn = 0, pr1 = 0, pr2 = 0, pr3 = 0;
+#define CT_STAMP() do { __syncthreads(); pt[pn++] = wall_clock64(); } while (0)
+#else
+#define CT_STAMP() do { } while (0)
+#endif
+    CT_STAMP();
+    unsigned long long ndv[CTJ_ITEMS], v[CTJ_ITEMS];
+    u32 own[CTJ_ITEMS];
+#pragma unroll
+    for (int i = 0; i < CTJ_ITEMS; i++) {
+        const u32 k = tid + 1024u * i;
+        ndv[i] = 0; own[i] = CT_NONE;
+        if (k < H) {
+            ndv[i] = nd[k];
+            own[i] = gkey[k];
+            if (mode == 0) a2[k] = gext[k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CTJ_ITEMS; i++) {
+        const u32 k = tid + 1024u * i;
+        v[i] = (unsigned long long)k << 32;
+        if (k < H) { v[i] = (ndv[i] & HI) | own[i]; tab[k] = v[i]; a1[k] = own[i]; }
+    }
+    __syncthreads();
+    CT_STAMP();
+    // (1) leaders: a round in which no smallest key changed anywhere proves every one is its border's (see ctj_lead_step)
+    for (int round = 0; round < max_rounds; round++) {
+        int changed = 0;
+        for (int hop = 0; hop < CTJ_HOPS; hop++) {
+            unsigned long long v2[CTJ_ITEMS];
+#pragma unroll
+            for (int i = 0; i < CTJ_ITEMS; i++) { const u32 k = tid + 1024u * i; const u32 J = (u32)(v[i] >> 32); v2[i] = (k < H && J != k) ? tab[J] : v[i]; }
+#pragma unroll
+            for (int i = 0; i < CTJ_ITEMS; i++) {
+                const u32 k = tid + 1024u * i;
+                if (k < H && (u32)(v[i] >> 32) != k) {
+                    const bool better = (u32)v2[i] < (u32)v[i];
+                    v[i] = (v2[i] & HI) | (better ? (u32)v2[i] : (u32)v[i]);
+                    tab[k] = v[i];
+                    changed |= better ? 1 : 0;
+                }
+            }
+        }
+#ifdef VP_CT_PROBE
+        pr1++;
+#endif
+        if (!__syncthreads_or(changed)) break;
+    }
+    CT_STAMP();
+    // (2) RETR_EXTERNAL: a2[leader of an outer border] = CT_FRAME (external) | CT_INSIDE | the leader whose answer is also this one's
+    if (mode == 0) {
+#pragma unroll
+        for (int i = 0; i < CTJ_ITEMS; i++) {
+            const u32 k = tid + 1024u * i;
+            if (k >= H || (u32)v[i] != own[i] || (own[i] & 1u)) continue;
+            const u32 e = a2[k];
+            if (e == CT_FRAME) continue;
+            const u32 km = (u32)tab[e];                  // the smallest key of the border that owns the crack met on the way left
+            u32 c2 = CT_INSIDE;
+            if (!(km & 1u)) {                            // an outer border: its leader is one of the heads of that key's word
+                const u32 pos = km >> 1;
+                const int y = (int)(pos / (u32)(G.w + 1));
+                const int wi = y * G.ww + ((int)(pos - (u32)y * (u32)(G.w + 1)) >> 6);
+                const u32 b = hb[wi], e2 = b + c8[wi];
+                for (u32 q = b; q < e2; q++) c2 = a1[q] == km ? q : c2;
+            }
+            a2[k] = c2;
+        }
+        __syncthreads();
+        for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
+            int changed = 0;
+#pragma unroll
+            for (int i = 0; i < CTJ_ITEMS; i++) {
+                const u32 k = tid + 1024u * i;
+                if (k >= H || (u32)v[i] != own[i] || (own[i] & 1u)) continue;
+                const u32 e = a2[k];
+                if (e >= CT_INSIDE) continue;
+                a2[k] = a2[e];
+                changed = 1;
+            }
+#ifdef VP_CT_PROBE
+            pr2++;
+#endif
+            if (!__syncthreads_or(changed)) break;
+        }
+    }
+    CT_STAMP();
+    // (3) a2[k] = 2 * (returned borders before head k in head order) + (k leads one): every thread takes a run of consecutive heads
+    const u32 per = (H + 1023u) / 1024u;
+    u32 selbits = 0;
+    for (u32 i = 0; i < per; i++) {
+        const u32 k = tid * per + i;
+        if (k >= H) break;
+        const u32 mine = a1[k];
+        if ((u32)tab[k] == mine && (mode == 1 || (!(mine & 1u) && a2[k] == CT_FRAME))) selbits |= 1u << i;
+    }
+    {
+        const u32 cnt = (u32)__popc(selbits);
+        u32 inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        u32 woff = 0, tot = 0;
+        for (int q = 0; q < 16; q++) { woff += q < wv ? s_wsum[q] : 0u; tot += s_wsum[q]; }
+        const u32 before = woff + inc - cnt;
+        for (u32 i = 0; i < per; i++) {
+            const u32 k = tid * per + i;
+            if (k >= H) break;
+            a2[k] = ((before + (u32)__popc(selbits & ((1u << i) - 1u))) << 1) | ((selbits >> i) & 1u);
+        }
+        if (tid == 0) s_carry = tot;
+        __syncthreads();
+    }
+    const u32 nsel = s_carry;
+    CT_STAMP();
+    // head order = scan order of the words; inside a word the heads are listed by type, so there the keys decide.  (a key says where
+    // its crack is: no look at the head list)
+    u32 rk[CTJ_ITEMS];
+#pragma unroll
+    for (int i = 0; i < CTJ_ITEMS; i++) {
+        const u32 k = tid + 1024u * i;
+        rk[i] = CT_NONE;
+        if (k >= H || (u32)v[i] != own[i]) continue;
+        rk[i] = CT_UNSEL;
+        if (!(a2[k] & 1u)) continue;
+        const u32 mine = own[i];
+        const u32 pos = mine >> 1;
+        const int y = (int)(pos / (u32)(G.w + 1));
+        const int x = (int)(pos - (u32)y * (u32)(G.w + 1)) - (int)(mine & 1u);
+        const int wi = y * G.ww + (x >> 6);
+        const u32 b = hb[wi], e = b + c8[wi];
+        u32 r = a2[b] >> 1;
+        for (u32 q = b; q < e; q++) r += (q != k && (a2[q] & 1u) && a1[q] < mine) ? 1u : 0u;
+        rk[i] = r;
+        if (r < (u32)A.max_contours) {
+            starts[r] = (u32)(y * G.w + x) | ((mine & 1u) << 31);
+            shead[r] = k;
+        }
+    }
+    __syncthreads();
+    CT_STAMP();
+    // marks (k_ct_seg<true> asks for the marks of leaders only)
+#pragma unroll
+    for (int i = 0; i < CTJ_ITEMS; i++) {
+        const u32 k = tid + 1024u * i;
+        if (k >= H) continue;
+        a1[k] = rk[i];
+        if (rk[i] != CT_NONE) ghr[k] = rk[i];
+    }
+    __syncthreads();
+    CT_STAMP();
+    // (4) distances
+#pragma unroll
+    for (int i = 0; i < CTJ_ITEMS; i++) {
+        const u32 k = tid + 1024u * i;
+        v[i] = (unsigned long long)CT_TERM << 32;
+        if (k < H) {
+            const u32 J = (u32)(ndv[i] >> 32);
+            v[i] = ((unsigned long long)(J | (a1[J] != CT_NONE ? CT_TERM : 0u)) << 32) | (u32)ndv[i];
+            tab[k] = v[i];
+        }
+    }
+    __syncthreads();
+    for (int round = 0; round < max_rounds; round++) {
+        int waiting = 0;                                  // some head of this thread has not reached its leader yet
+        for (int hop = 0; hop < CTJ_HOPS; hop++) {
+            unsigned long long v2[CTJ_ITEMS];
+#pragma unroll
+            for (int i = 0; i < CTJ_ITEMS; i++) { const u32 J = (u32)(v[i] >> 32); v2[i] = (J & CT_TERM) ? 0ull : tab[J]; }
+            waiting = 0;
+#pragma unroll
+            for (int i = 0; i < CTJ_ITEMS; i++) {
+                const u32 k = tid + 1024u * i;
+                if (!((u32)(v[i] >> 32) & CT_TERM)) {
+                    v[i] = (v2[i] & HI) | (u32)((u32)v[i] + (u32)v2[i]);
+                    tab[k] = v[i];
+                    waiting |= ((u32)(v[i] >> 32) & CT_TERM) ? 0 : 1;
+                }
+            }
+        }
+#ifdef VP_CT_PROBE
+        pr3++;
+#endif
+        if (!__syncthreads_or(waiting)) break;
+    }
+    CT_STAMP();
+#pragma unroll
+    for (int i = 0; i < CTJ_ITEMS; i++) {
+        const u32 k = tid + 1024u * i;
+        if (k < H) nd[k] = v[i];
+    }
+    ct_offsets_body<1024>((int)nsel, A.starts, A.shead, tab, A.counts, A.is_hole, A.offsets, A.out, A.max_contours);
+#ifdef VP_CT_PROBE
+    CT_STAMP();
+    if (tid == 0 && f == 0) {
+        printf("jump H=%u nsel=%u rounds %d %d %d | x10ns:", H, nsel, pr1, pr2, pr3);
+        for (int i = 1; i < pn; i++) printf(" %lld", pt[i] - pt[i - 1]);
+        printf(" | total %lld\n", pt[pn - 1] - pt[0]);
+    }
+#endif
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned long long ctj_dyn[];
 __global__ __launch_bounds__(1024) void k_ct_jump(ctj_args A)
 {
     const int f = blockIdx.x;
     const u32 H = A.aux[f].nheads;
     if (A.nheads_out && threadIdx.x == 0) A.nheads_out[f] = H;
-    if (H <= A.lds_heads)
-        ctj_body<true>(A.G, ctj_make_frame(A, f, ctj_dyn), reinterpret_cast<u32*>(ctj_dyn + A.lds_heads), A.node, A.hcap, A.starts, A.shead, A.counts,
-                       A.is_hole, A.offsets, A.points, A.out, A.max_contours, A.max_points, A.mode);
+    if (H <= (u32)CTJ_LDS_HEADS)
+        ctj_body_lds(A, f, H, ctj_dyn, reinterpret_cast<u32*>(ctj_dyn + CTJ_LDS_HEADS), reinterpret_cast<u32*>(ctj_dyn + CTJ_LDS_HEADS) + CTJ_LDS_HEADS);
     else
-        ctj_body<false>(A.G, ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap), nullptr, A.node, A.hcap, A.starts, A.shead, A.counts, A.is_hole,
+        ctj_body<false>(A.G, ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap), nullptr, nullptr, A.node, A.hcap, A.starts, A.shead, A.counts, A.is_hole,
                         A.offsets, A.points, A.out, A.max_contours, A.max_points, A.mode);
 }
 
@@ -688,7 +960,7 @@ __global__ __launch_bounds__(256) void k_ctm(ctj_args A, int slot)
         if (PH == CTM_EXT_INIT) ctj_ext_init<false>(F, k);
         if (PH == CTM_EXT)
             for (int h = 0; h < A.hops; h++) changed |= ctj_ext_step<false>(F, k) ? 1 : 0;
-        if (PH == CTM_RANK) ctj_rank(F, k, A.G, A.starts + (size_t)f * A.max_contours, A.shead + (size_t)f * A.max_contours, A.max_contours);
+        if (PH == CTM_RANK) ctj_rank<false>(F, k, A.G, A.starts + (size_t)f * A.max_contours, A.shead + (size_t)f * A.max_contours, A.max_contours);
         if (PH == CTM_MARK) ctj_mark<false>(F, k);
         if (PH == CTM_DIST)
             for (int h = 0; h < A.hops; h++) changed |= ctj_dist_step<false>(F.nd, k) ? 1 : 0;
@@ -849,8 +1121,6 @@ size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
            vp_align((size_t)n * CTM_NFLAGS * 4) + vp_align((ct_hcap(w, h) / 1024 + 2) * 4 * n) + 8192;
 }
 
-// LDS of the per-frame block of k_ct_jump: 12 B per head (the pair table and the keys); frames with more heads work in global memory
-#define CTJ_LDS_HEADS 8192
 
 // d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
 // stored in discovery order (raster order of the start pixel); cv2 returns them reversed - the caller reverses.
@@ -890,7 +1160,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
         !A.flags || !A.csum)
         return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
     static bool lds_set = false;
-    const size_t jump_lds = (size_t)CTJ_LDS_HEADS * 12;
+    const size_t jump_lds = (size_t)CTJ_LDS_HEADS * 16;
     if (!lds_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ct_jump), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jump_lds));
         lds_set = true;
