@@ -1242,18 +1242,29 @@ static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_devic
     const char* many_s = getenv("VP_CT_MANY");
     const int many_env = many_s ? atoi(many_s) : -1;
     const bool many = many_env >= 0 ? many_env != 0 : ctx->ct_heads_hint > 16384u;
-    VP_TRY(vpk_find_contours(ctx, bits_use, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info, many,
-                             reinterpret_cast<uint32_t*>(d_info + 2)));
-    // the header and the first points come back under one synchronisation; longer point lists take a second copy
+    // The header and the first points come back without a copy: the kernels that make them write them into the pinned staging
+    // buffer as well, and the call only synchronises (longer point lists take a copy afterwards).  VP_CT_MIRROR=0: a copy, as before.
     const size_t spec_pts = points ? (size_t)std::min<long long>(mp, 8192) : 0;
     const size_t hdr_pad = vp_align(hdr_bytes);
     uint8_t* hs = (uint8_t*)vp_hstage(ctx, hdr_pad + spec_pts * 8);
     if (!hs) return vp_fail(ctx, VP_ERR_NOMEM, "pinned staging");
-    if (spec_pts && reinterpret_cast<uint8_t*>(d_points) == d_hdr + hdr_pad) {
-        VP_TRY(d2h(ctx, hs, d_hdr, hdr_pad + spec_pts * 8));           // header and points lie back to back in the workspace: one copy
-    } else {
-        VP_TRY(d2h(ctx, hs, d_hdr, hdr_bytes));
-        if (spec_pts) VP_TRY(d2h(ctx, hs + hdr_pad, d_points, spec_pts * 8));
+    static const bool mirror_off = getenv("VP_CT_MIRROR") && atoi(getenv("VP_CT_MIRROR")) == 0;
+    vp_contour_mirror hm;
+    hm.info = reinterpret_cast<int32_t*>(hs);
+    hm.counts = reinterpret_cast<int32_t*>(hs + 16);
+    hm.offsets = hm.counts + mc;
+    hm.is_hole = reinterpret_cast<uint8_t*>(hm.offsets + mc);
+    hm.points = spec_pts ? reinterpret_cast<int32_t*>(hs + hdr_pad) : nullptr;
+    hm.points_cap = (long long)spec_pts;
+    VP_TRY(vpk_find_contours(ctx, bits_use, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info, many,
+                             reinterpret_cast<uint32_t*>(d_info + 2), mirror_off ? nullptr : &hm));
+    if (mirror_off) {
+        if (spec_pts && reinterpret_cast<uint8_t*>(d_points) == d_hdr + hdr_pad) {
+            VP_TRY(d2h(ctx, hs, d_hdr, hdr_pad + spec_pts * 8));           // header and points lie back to back in the workspace: one copy
+        } else {
+            VP_TRY(d2h(ctx, hs, d_hdr, hdr_bytes));
+            if (spec_pts) VP_TRY(d2h(ctx, hs + hdr_pad, d_points, spec_pts * 8));
+        }
     }
     VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t* info = reinterpret_cast<const int32_t*>(hs);

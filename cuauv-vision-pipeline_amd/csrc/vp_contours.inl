@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
                                                 const u32* __restrict__ head_pix, const u32* __restrict__ hrank, size_t hcap,
                                                 const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, u32* __restrict__ hkey,
                                                 u32* __restrict__ hext, int mode, int method, const int32_t* __restrict__ offsets,
-                                                int32_t* __restrict__ points, int max_contours, long long max_points)
+                                                int32_t* __restrict__ points, int max_contours, long long max_points, int32_t* __restrict__ h_points,
+                                                long long h_cap)
 {
     const int f = blockIdx.y;
     const int nwords = G.h * G.ww;
@@ -339,6 +340,8 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
         const u32 k = keys ? i - Hp : i;
         if (k >= H) continue;
         int32_t* out = nullptr;
+        int32_t* hout = nullptr;                         // (WRITE, single image) the same points in the caller's pinned buffer
+        long long hroom = 0;
         if (WRITE) {
             const unsigned long long v = nd[k];
             const u32 J = (u32)(v >> 32);
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             const u32 off = (k == T) ? 0u : total - (u32)v;
             if (off >= total) continue;                 // (tables that do not add up must not turn into a write outside the contour)
             out = points + 2 * ((size_t)f * max_points + base + off);
+            if (h_points) { hout = h_points + 2 * (base + (long long)off); hroom = h_cap - (base + (long long)off); }
         }
         const u32 hp = head_pix[(size_t)f * hcap + k];
         const int pix = (int)(hp & 0x1fffffffu), type = (int)(hp >> 29);
@@ -360,8 +364,10 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
         ct_tile_load(G, fb, y - 3, x - 3, T);
         u32 R = ct_ring(T, y, x);
         if (!R) {                                        // a pixel on its own: a border of one point, its own successor
-            if (WRITE) { out[0] = x; out[1] = y; }
-            else if (keys) {
+            if (WRITE) {
+                out[0] = x; out[1] = y;
+                if (hroom > 0) { hout[0] = x; hout[1] = y; }
+            } else if (keys) {
                 hkey[(size_t)f * hcap + k] = ct_key_w(G, y, x);
                 if (mode == 0) hext[(size_t)f * hcap + k] = ct_left_of(G, fb, hm, hb, y, x);
             } else {
@@ -392,7 +398,10 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             first = false;
             const int s2 = (s + 1 + t) & 7;
             if (s2 != (s ^ 4) || method == 1) {
-                if (WRITE) { out[2 * cnt] = x; out[2 * cnt + 1] = y; }
+                if (WRITE) {
+                    out[2 * cnt] = x; out[2 * cnt + 1] = y;
+                    if ((long long)cnt < hroom) { hout[2 * cnt] = x; hout[2 * cnt + 1] = y; }
+                }
                 cnt++;
             }
             x += dx8(s2); y += dy8(s2);
@@ -407,12 +416,23 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
     }
 }
 
+// A single-image call hands its results to the host: the kernels that produce them write them a second time, straight into the
+// caller's pinned buffer (posted writes over the link), instead of a copy launched behind them.  All NULL: no mirror.
+struct ct_mirror {
+    int32_t* info;       // {n_contours, n_points, heads}
+    int32_t* counts;
+    int32_t* offsets;
+    uint8_t* hole;
+    int32_t* points;     // the first `cap` points
+    long long cap;
+};
+
 // per frame: contour lengths from the leaders, exclusive scan -> offsets, total -> out[f].n_points.  `dist`: per head of the frame,
 // low 32 bits = a leader's distance around its border = the length of its contour.  All NT threads of the block take part.
 template <int NT, typename DT>
 __device__ __forceinline__ void ct_offsets_body(int nsel, const u32* __restrict__ starts, const u32* __restrict__ shead,
                                                 const DT* dist, int32_t* __restrict__ counts, uint8_t* __restrict__ is_hole_out,
-                                                int32_t* __restrict__ offsets, ct_frame_out* __restrict__ out, int max_contours)
+                                                int32_t* __restrict__ offsets, ct_frame_out* __restrict__ out, int max_contours, const ct_mirror& M)
 {
     __shared__ u32 wsum[NT / 64];
     __shared__ u32 carry;
@@ -425,8 +445,10 @@ __device__ __forceinline__ void ct_offsets_body(int nsel, const u32* __restrict_
         u32 v = 0;
         if (i < K) {
             v = (u32)dist[shead[(size_t)f * max_contours + i]];
+            const uint8_t hole = (uint8_t)(starts[(size_t)f * max_contours + i] >> 31);
             counts[(size_t)f * max_contours + i] = (int32_t)v;
-            is_hole_out[(size_t)f * max_contours + i] = (uint8_t)(starts[(size_t)f * max_contours + i] >> 31);
+            is_hole_out[(size_t)f * max_contours + i] = hole;
+            if (M.counts) { M.counts[i] = (int32_t)v; M.hole[i] = hole; }
         }
         u32 inc = v;
 #pragma unroll
@@ -435,12 +457,18 @@ __device__ __forceinline__ void ct_offsets_body(int nsel, const u32* __restrict_
         __syncthreads();
         u32 woff = 0;
         for (int k = 0; k < wv; k++) woff += wsum[k];
-        if (i < K) offsets[(size_t)f * max_contours + i] = (int32_t)(carry + woff + inc - v);
+        if (i < K) {
+            offsets[(size_t)f * max_contours + i] = (int32_t)(carry + woff + inc - v);
+            if (M.offsets) M.offsets[i] = (int32_t)(carry + woff + inc - v);
+        }
         __syncthreads();
         if (tid == NT - 1) carry += woff + inc;
         __syncthreads();
     }
-    if (tid == 0) { out[f].n_contours = nsel; out[f].n_points = (int32_t)carry; }
+    if (tid == 0) {
+        out[f].n_contours = nsel; out[f].n_points = (int32_t)carry;
+        if (M.info) { M.info[0] = nsel; M.info[1] = (int32_t)carry; }
+    }
 }
 
 // ---- the cycle bookkeeping between the two follower passes ----
@@ -569,7 +597,7 @@ template <bool L>
 __device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* keyl, u32* hrl, const unsigned long long* __restrict__ node, size_t hcap,
                                          u32* __restrict__ starts, u32* __restrict__ shead, int32_t* __restrict__ counts,
                                          uint8_t* __restrict__ is_hole_out, int32_t* __restrict__ offsets, int32_t* __restrict__ points,
-                                         ct_frame_out* __restrict__ out, int max_contours, long long max_points, int mode)
+                                         ct_frame_out* __restrict__ out, int max_contours, long long max_points, int mode, const ct_mirror& M)
 {
     __shared__ u32 s_wsum[16];
     __shared__ u32 s_carry;
@@ -635,7 +663,7 @@ __device__ __forceinline__ void ctj_body(const ccl_geom& G, ctj_frame F, u32* ke
         for (u32 k = tid; k < H; k += 1024) F.nd[k] = t[k];
     __threadfence_block();
     __syncthreads();               // the block's own stores to node[] are visible to all its threads from here on
-    ct_offsets_body<1024>((int)nsel, starts, shead, F.nd, counts, is_hole_out, offsets, out, max_contours);
+    ct_offsets_body<1024>((int)nsel, starts, shead, F.nd, counts, is_hole_out, offsets, out, max_contours, M);
 }
 
 struct ctj_args {
@@ -658,6 +686,7 @@ struct ctj_args {
     int mode;
     u32 lds_heads;
     u32* nheads_out;             // nullable: the frame's head count, for the caller's next call (vpk_find_contours `many_heads`)
+    ct_mirror mirror;            // single image: the results written a second time, into the caller's pinned buffer
     u32 *flags, *csum;           // k_ctm_* only: per frame CTM_NFLAGS round flags; partial sums of the two scans
     int hops;
 };
@@ -910,7 +939,7 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
         const u32 k = tid + 1024u * i;
         if (k < H) nd[k] = v[i];
     }
-    ct_offsets_body<1024>((int)nsel, A.starts, A.shead, tab, A.counts, A.is_hole, A.offsets, A.out, A.max_contours);
+    ct_offsets_body<1024>((int)nsel, A.starts, A.shead, tab, A.counts, A.is_hole, A.offsets, A.out, A.max_contours, A.mirror);
 #ifdef VP_CT_PROBE
     CT_STAMP();
     if (tid == 0 && f == 0) {
@@ -927,11 +956,12 @@ __global__ __launch_bounds__(1024) void k_ct_jump(ctj_args A)
     const int f = blockIdx.x;
     const u32 H = A.aux[f].nheads;
     if (A.nheads_out && threadIdx.x == 0) A.nheads_out[f] = H;
+    if (A.mirror.info && threadIdx.x == 0) A.mirror.info[2] = (int32_t)H;
     if (H <= (u32)CTJ_LDS_HEADS)
         ctj_body_lds(A, f, H, ctj_dyn, reinterpret_cast<u32*>(ctj_dyn + CTJ_LDS_HEADS), reinterpret_cast<u32*>(ctj_dyn + CTJ_LDS_HEADS) + CTJ_LDS_HEADS);
     else
         ctj_body<false>(A.G, ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap), nullptr, nullptr, A.node, A.hcap, A.starts, A.shead, A.counts, A.is_hole,
-                        A.offsets, A.points, A.out, A.max_contours, A.max_points, A.mode);
+                        A.offsets, A.points, A.out, A.max_contours, A.max_points, A.mode, A.mirror);
 }
 
 // ---- the same steps as launches over the chip (grid (blocks, n) x 256) ----
@@ -951,6 +981,7 @@ __global__ __launch_bounds__(256) void k_ctm(ctj_args A, int slot)
     if (PH == CTM_LEAD_INIT && blockIdx.x == 0) {
         for (int i = threadIdx.x; i < CTM_NFLAGS; i += 256) ctj_gst(fl + i, (i % CTM_SEQ) == 0 ? 1u : 0u);   // every sequence runs its first round
         if (A.nheads_out && threadIdx.x == 0) A.nheads_out[f] = F.H;
+        if (A.mirror.info && threadIdx.x == 0) A.mirror.info[2] = (int32_t)F.H;
     }
     int changed = 0;
     for (u32 k = blockIdx.x * 256 + threadIdx.x; k < F.H; k += gridDim.x * 256) {
@@ -1016,7 +1047,10 @@ __global__ __launch_bounds__(1024) void k_ctm_scan(ctj_args A)
     const u32* cs = A.csum + (size_t)f * (A.hcap / 1024 + 2);
     if (nchunks == 0 && blockIdx.x == 0 && tid == 0) {
         if (WHAT == 0) A.aux[f].nsel = 0u;
-        else { A.out[f].n_contours = (int32_t)nsel; A.out[f].n_points = 0; }
+        else {
+            A.out[f].n_contours = (int32_t)nsel; A.out[f].n_points = 0;
+            if (A.mirror.info) { A.mirror.info[0] = (int32_t)nsel; A.mirror.info[1] = 0; }
+        }
     }
     for (u32 c = blockIdx.x; c < nchunks; c += gridDim.x) {
         u32 pre = 0;
@@ -1042,11 +1076,15 @@ __global__ __launch_bounds__(1024) void k_ctm_scan(ctj_args A)
                 A.counts[o] = (int32_t)v;
                 A.is_hole[o] = (uint8_t)(A.starts[o] >> 31);
                 A.offsets[o] = (int32_t)excl;
+                if (A.mirror.counts) { A.mirror.counts[i] = (int32_t)v; A.mirror.hole[i] = (uint8_t)(A.starts[o] >> 31); A.mirror.offsets[i] = (int32_t)excl; }
             }
         }
         if (c == nchunks - 1 && tid == 1023) {
             if (WHAT == 0) A.aux[f].nsel = excl + v;
-            else { A.out[f].n_contours = (int32_t)nsel; A.out[f].n_points = (int32_t)(excl + v); }
+            else {
+                A.out[f].n_contours = (int32_t)nsel; A.out[f].n_points = (int32_t)(excl + v);
+                if (A.mirror.info) { A.mirror.info[0] = (int32_t)nsel; A.mirror.info[1] = (int32_t)(excl + v); }
+            }
         }
         __syncthreads();
     }
@@ -1129,7 +1167,7 @@ size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
 // d_nheads_out (nullable, [n]): the frames' head counts.
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, bool many_heads,
-                      uint32_t* d_nheads_out)
+                      uint32_t* d_nheads_out, const vp_contour_mirror* host)
 {
     if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
     if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
@@ -1170,6 +1208,8 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     A.out = reinterpret_cast<ct_frame_out*>(d_info);
     A.max_contours = max_contours; A.max_points = max_points; A.mode = mode; A.lds_heads = CTJ_LDS_HEADS; A.nheads_out = d_nheads_out;
     A.hops = 3;
+    A.mirror = ct_mirror{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (host && n == 1) A.mirror = ct_mirror{host->info, host->counts, host->offsets, host->is_hole, host->points, host->points_cap};
     hipStream_t s = ctx->stream;
     vp_prof_scope ps(ctx, VPK_OTHER);
     const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
@@ -1179,7 +1219,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
     hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &A.aux->nheads, 2, w, G.ww, head_pix, hcap, cnt8);
     hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method,
-                       d_offsets, d_points, max_contours, max_points);
+                       d_offsets, d_points, max_contours, max_points, (int32_t*)nullptr, 0ll);
     if (!many_heads) {
         hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), jump_lds, s, A);
     } else {
@@ -1204,7 +1244,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
         hipLaunchKernelGGL((k_ctm_scan<1>), sg, dim3(1024), 0, s, A);
     }
     hipLaunchKernelGGL((k_ct_seg<true>), hgrid, dim3(256), 0, s, d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method,
-                       d_offsets, d_points, max_contours, max_points);
+                       d_offsets, d_points, max_contours, max_points, A.mirror.points, A.mirror.cap);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
