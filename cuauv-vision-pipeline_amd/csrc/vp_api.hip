@@ -128,6 +128,10 @@ int vp_destroy(vp_ctx* ctx)
     vp_post_teardown(ctx);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->c3_acc) hipFree(ctx->c3_acc);
+    for (int i = 0; i < 4; i++) {
+        if (ctx->ring_buf[i]) hipHostFree(ctx->ring_buf[i]);
+        if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
+    }
     if (ctx->hstage) hipHostFree(ctx->hstage);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     hipEventDestroy(ctx->ev0);
@@ -1107,6 +1111,32 @@ int vp_inrange_u8_bits_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride,
 
 // The polylines of vp_draw_polylines_u8 drawn into a packed device image (bins.py draws its rectangles into an overlay that only ever
 // leaves the device when it is posted).  Points and counts are host arrays; the same pixels as the host rasteriser.
+// ring of pinned chunks for small host -> device hand-overs (see vp_ctx): the chunk is the caller's until ring_done, and is handed
+// out again only after everything queued on the context's stream up to ring_done has run
+static uint8_t* ring_take(vp_ctx* ctx, size_t bytes, int* slot)
+{
+    const int s = ctx->ring_next;
+    ctx->ring_next = (s + 1) & 3;
+    if (ctx->ring_busy[s]) { (void)hipEventSynchronize(ctx->ring_ev[s]); ctx->ring_busy[s] = 0; }
+    if (bytes > ctx->ring_cap[s]) {
+        if (ctx->ring_buf[s]) { (void)hipHostFree(ctx->ring_buf[s]); ctx->ring_buf[s] = nullptr; ctx->ring_cap[s] = 0; }
+        const size_t cap = (bytes + (1u << 16) - 1) >> 16 << 16;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ctx->ring_buf[s] = (uint8_t*)p;
+        ctx->ring_cap[s] = cap;
+    }
+    if (!ctx->ring_ev[s] && hipEventCreateWithFlags(&ctx->ring_ev[s], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *slot = s;
+    return ctx->ring_buf[s];
+}
+static void ring_done(vp_ctx* ctx, int slot)
+{
+    if (slot < 0) return;
+    if (hipEventRecord(ctx->ring_ev[slot], ctx->stream) == hipSuccess) ctx->ring_busy[slot] = 1;
+    else { (void)hipGetLastError(); (void)hipStreamSynchronize(ctx->stream); }
+}
+
 int vp_draw_polylines_dev(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* pts, const int32_t* counts, int npolys, int closed,
                           const uint8_t* color, int thickness)
 {
@@ -1114,43 +1144,35 @@ int vp_draw_polylines_dev(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, con
     if (!d_img || !pts || !counts || !color || w <= 0 || h <= 0 || cn < 1 || cn > 4 || npolys < 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_draw_polylines_dev arguments");
     if (thickness < 1) thickness = 1;
     if (thickness > 255) return vp_fail(ctx, VP_ERR_UNSUPPORTED, "vp_draw_polylines_dev: thickness");
-    // brush centres: every Bresenham step of every segment whose stamp can reach the image (consecutive repeats dropped)
-    std::vector<int32_t> cen;
-    auto line = [&](int x0, int y0, int x1, int y1) {
-        const int dx = abs(x1 - x0), dy = -abs(y1 - y0);
-        const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
-        long long err = (long long)dx + dy;
-        for (;;) {
-            if (x0 + thickness > 0 && x0 - thickness < w && y0 + thickness > 0 && y0 - thickness < h) {
-                const size_t n = cen.size();
-                if (n < 2 || cen[n - 2] != x0 || cen[n - 1] != y0) { cen.push_back(x0); cen.push_back(y0); }
-            }
-            if (x0 == x1 && y0 == y1) break;
-            const long long e2 = 2 * err;
-            if (e2 >= dy) { err += dy; x0 += sx; }
-            if (e2 <= dx) { err += dx; y0 += sy; }
-        }
-    };
+    // the vertices and, per vertex, the vertex it is joined to go over in one pinned chunk; the device walks the lines (k_draw_segments)
+    long long total = 0;
+    for (int k = 0; k < npolys; k++) {
+        if (counts[k] < 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_draw_polylines_dev: counts");
+        total += counts[k];
+    }
+    if (total == 0) return VP_OK;
+    if (total > (1ll << 28)) return vp_fail(ctx, VP_ERR_INVALID, "vp_draw_polylines_dev: too many points");
+    const size_t N = (size_t)total;
+    int slot = -1;
+    uint8_t* hp = ring_take(ctx, N * 12, &slot);
+    if (!hp) return vp_fail(ctx, VP_ERR_NOMEM, "pinned staging");
+    memcpy(hp, pts, N * 8);
+    int32_t* nxt = reinterpret_cast<int32_t*>(hp + N * 8);
     size_t o = 0;
     for (int k = 0; k < npolys; k++) {
-        const int npts = counts[k];
-        if (npts < 0) return vp_fail(ctx, VP_ERR_INVALID, "vp_draw_polylines_dev: counts");
-        const int32_t* p = pts + 2 * o;
-        o += (size_t)npts;
-        if (npts == 0) continue;
-        if (npts == 1) { line(p[0], p[1], p[0], p[1]); continue; }
-        const int last = closed ? npts : npts - 1;
-        for (int i = 0; i < last; i++) {
-            const int j = i + 1 < npts ? i + 1 : 0;
-            line(p[2 * i], p[2 * i + 1], p[2 * j], p[2 * j + 1]);
-        }
+        const size_t npts = (size_t)counts[k];
+        for (size_t i = 0; i + 1 < npts; i++) nxt[o + i] = (int32_t)(o + i + 1);
+        if (npts) nxt[o + npts - 1] = (npts == 1 || closed) ? (int32_t)o : -1;
+        o += npts;
     }
-    const int ncen = (int)(cen.size() / 2);
-    if (ncen == 0) return VP_OK;
-    VP_TRY(vp_ws_reserve(ctx, vp_align(cen.size() * 4) + 4096));
-    TAKE(d_cen, int32_t*, cen.size() * 4);
-    VP_TRY(h2d(ctx, d_cen, cen.data(), cen.size() * 4));     // pageable source: staged by the runtime before the call returns
-    return vpk_draw_stamps(ctx, d_img, w, h, cn, d_cen, ncen, thickness, color);
+    int rc = vp_ws_reserve(ctx, vp_align(N * 12) + 4096);
+    uint8_t* d_buf = rc == VP_OK ? (uint8_t*)vp_ws_take(ctx, N * 12) : nullptr;
+    if (rc == VP_OK && !d_buf) rc = vp_fail(ctx, VP_ERR_NOMEM, "workspace exhausted: overlay vertices");
+    if (rc == VP_OK) rc = h2d(ctx, d_buf, hp, N * 12);
+    if (rc == VP_OK)
+        rc = vpk_draw_segments(ctx, d_img, w, h, cn, reinterpret_cast<const int32_t*>(d_buf), reinterpret_cast<const int32_t*>(d_buf + N * 8), (int)N, thickness, color);
+    ring_done(ctx, slot);
+    return rc;
 }
 
 // cv2.addWeighted on two device images of n bytes each (modules/bins.py:20: the mask overlay); d_dst may be one of the sources

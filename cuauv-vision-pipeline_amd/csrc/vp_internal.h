@@ -37,6 +37,13 @@ struct vp_ctx {
     size_t ws_off;
     uint8_t* hstage;  // grow-only pinned host staging for small results (contour lists)
     size_t hstage_cap;
+    // small host -> device hand-overs that must not wait (overlay vertices): a ring of pinned chunks, each free again once the work
+    // queued behind its copy has run
+    uint8_t* ring_buf[4];
+    size_t ring_cap[4];
+    hipEvent_t ring_ev[4];
+    int ring_busy[4];
+    int ring_next;
     uint32_t ct_heads_hint;   // border segments the last single-image contour pass counted (vp_find_contours_*: which form of the bookkeeping to launch)
     int num_cu;
     int chain_streams;            // sub-batches of a chain run on this many internal streams (>= 1)
@@ -155,7 +162,8 @@ int vpk_morph_generic(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int 
 // span form (see vp_morph.hip): d_spans = nspans triples (dy, x0, x1); d_tab = 7 planes of w*h*cn bytes; max_len = longest span
 int vpk_morph_spans(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int h, int cn, const int16_t* d_spans, int nspans, int max_len,
                     uint8_t* d_tab, uint8_t* d_dst);
-int vpk_draw_stamps(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* d_centres, int ncentres, int thickness, const uint8_t* color);
+int vpk_draw_segments(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* d_pts, const int32_t* d_nxt, int npts, int thickness,
+                      const uint8_t* color);
 int vpk_add_weighted_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double alpha, double beta, double gamma, uint8_t* dst);
 int vpk_absdiff_sub_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* dst);  // a - b saturating
 

@@ -622,34 +622,54 @@ __global__ __launch_bounds__(256) void k_add_weighted_u8(const uint8_t* __restri
     }
 }
 
-// Overlay drawing into a device image: the host has walked the Bresenham steps of the polylines (the statement sequence of the host
-// rasteriser, vp_draw_polylines_u8 / vision/utils/draw.py _line) and hands over the brush centres; one thread per (centre, brush pixel)
-// writes the colour.  Stamps overlap freely: everything is written in one colour.
-__global__ __launch_bounds__(256) void k_draw_stamps(uint8_t* __restrict__ img, int w, int h, int cn, const int2* __restrict__ centre, int ncentres,
-                                                    int thickness, uchar4 color)
+// Overlay drawing into a device image (vp_draw_polylines_dev): one wave per segment.  The host rasteriser's Bresenham loop (vp_draw_polylines_u8 /
+// vision/utils/draw.py _line: err = dx + dy;
+// e2 = 2 err; x steps when e2 >= dy, y steps when e2 <= dx) always advances the longer axis, and after i steps the shorter one stands
+// at floor((2 i m + M) / (2 M)) (m, M = the shorter and the longer extent; dx >= |dy| counts as x-major) - checked against the loop
+// for every segment of a 141 x 141 neighbourhood and 3000 random long ones - so the steps of a segment are independent: lane = step.
+// nxt[g] = index of the point that point g is joined to (itself: a single point; -1: the open end of a polyline).
+__global__ __launch_bounds__(256) void k_draw_segments(uint8_t* __restrict__ img, int w, int h, int cn, const int2* __restrict__ pts,
+                                                       const int32_t* __restrict__ nxt, int npts, int thickness, uchar4 color)
 {
-    const int t2 = thickness * thickness;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)ncentres * t2) return;
-    const int ci = (int)(i / t2), bi = (int)(i - (long long)ci * t2);
-    const int2 c = centre[ci];
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= npts) return;
+    const int j = nxt[g];
+    if (j < 0) return;
+    const int2 a = pts[g], b = pts[j];
+    const long long dx = llabs((long long)b.x - a.x), ady = llabs((long long)b.y - a.y);
+    const int sx = a.x < b.x ? 1 : -1, sy = a.y < b.y ? 1 : -1;
+    const long long n = dx > ady ? dx : ady;
     const int r0 = (thickness - 1) / 2;
-    const int px = c.x - r0 + bi % thickness, py = c.y - r0 + bi / thickness;
-    if (px < 0 || px >= w || py < 0 || py >= h) return;
-    uint8_t* q = img + ((size_t)py * w + px) * cn;
-    q[0] = color.x;
-    if (cn > 1) q[1] = color.y;
-    if (cn > 2) q[2] = color.z;
-    if (cn > 3) q[3] = color.w;
+    for (long long i = lane; i <= n; i += 64) {
+        long long x = a.x, y = a.y;
+        if (n > 0) {
+            if (dx >= ady) { x += sx * i; y += sy * ((2 * i * ady + dx) / (2 * dx)); }
+            else { y += sy * i; x += sx * ((2 * i * dx + ady) / (2 * ady)); }
+        }
+        if (x + thickness <= 0 || x - thickness >= w || y + thickness <= 0 || y - thickness >= h) continue;
+        for (int by = 0; by < thickness; by++) {
+            const long long py = y - r0 + by;
+            if (py < 0 || py >= h) continue;
+            for (int bx = 0; bx < thickness; bx++) {
+                const long long px = x - r0 + bx;
+                if (px < 0 || px >= w) continue;
+                uint8_t* q = img + ((size_t)py * w + (size_t)px) * cn;
+                q[0] = color.x;
+                if (cn > 1) q[1] = color.y;
+                if (cn > 2) q[2] = color.z;
+                if (cn > 3) q[3] = color.w;
+            }
+        }
+    }
 }
 
-int vpk_draw_stamps(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* d_centres, int ncentres, int thickness, const uint8_t* color)
+int vpk_draw_segments(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* d_pts, const int32_t* d_nxt, int npts, int thickness,
+                      const uint8_t* color)
 {
-    if (ncentres <= 0) return VP_OK;
+    if (npts <= 0) return VP_OK;
     const uchar4 c = make_uchar4(color[0], cn > 1 ? color[1] : 0, cn > 2 ? color[2] : 0, cn > 3 ? color[3] : 0);
-    const long long total = (long long)ncentres * thickness * thickness;
-    hipLaunchKernelGGL(k_draw_stamps, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_img, w, h, cn, reinterpret_cast<const int2*>(d_centres),
-                       ncentres, thickness, c);
+    hipLaunchKernelGGL(k_draw_segments, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, ctx->stream, d_img, w, h, cn, reinterpret_cast<const int2*>(d_pts), d_nxt,
+                       npts, thickness, c);
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
