@@ -61,3 +61,41 @@ def test_draw_contours_entry():
     D.draw_contours(img, cs, thickness=10)
     _python(ref, cs, True, np.asarray((0, 0, 255), np.uint8), 10)
     assert np.array_equal(img, ref) and img.any()
+
+
+def test_bresenham_steps_have_a_closed_form():
+    """The device overlay kernel (csrc/vp_morph.hip k_draw_segments) takes the steps of a segment in parallel: after i steps of the host
+    rasteriser's loop (utils/draw.py _line / vp_draw_polylines_u8) the longer axis has advanced i and the shorter one stands at
+    floor((2 i m + M) / (2 M)), dx >= |dy| counting as x-major.  Checked here against the loop itself."""
+    def loop(x0, y0, x1, y1):
+        dx, dy = abs(x1 - x0), -abs(y1 - y0)
+        sx, sy = (1 if x0 < x1 else -1), (1 if y0 < y1 else -1)
+        err, out = dx + dy, []
+        while True:
+            out.append((x0, y0))
+            if x0 == x1 and y0 == y1:
+                return out
+            e2 = 2 * err
+            if e2 >= dy:
+                err += dy
+                x0 += sx
+            if e2 <= dx:
+                err += dx
+                y0 += sy
+
+    def closed(x0, y0, x1, y1):
+        dx, ady = abs(x1 - x0), abs(y1 - y0)
+        sx, sy = (1 if x0 < x1 else -1), (1 if y0 < y1 else -1)
+        n = max(dx, ady)
+        if n == 0:
+            return [(x0, y0)]
+        if dx >= ady:
+            return [(x0 + sx * i, y0 + sy * ((2 * i * ady + dx) // (2 * dx))) for i in range(n + 1)]
+        return [(x0 + sx * ((2 * i * dx + ady) // (2 * ady)), y0 + sy * i) for i in range(n + 1)]
+
+    for x1 in range(-40, 41):
+        for y1 in range(-40, 41):
+            assert loop(3, -2, x1, y1) == closed(3, -2, x1, y1), (x1, y1)
+    rng = np.random.default_rng(5)
+    for a in rng.integers(-4000, 4000, (400, 4)).tolist():
+        assert loop(*a) == closed(*a), a
