@@ -1153,6 +1153,17 @@ int vp_draw_polylines_dev(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, con
     if (total == 0) return VP_OK;
     if (total > (1ll << 28)) return vp_fail(ctx, VP_ERR_INVALID, "vp_draw_polylines_dev: too many points");
     const size_t N = (size_t)total;
+    if (N <= 48) {                                       // a few vertices travel as kernel arguments (vpk_draw_small)
+        int32_t nx[48];
+        size_t o = 0;
+        for (int k = 0; k < npolys; k++) {
+            const size_t npts = (size_t)counts[k];
+            for (size_t i = 0; i + 1 < npts; i++) nx[o + i] = (int32_t)(o + i + 1);
+            if (npts) nx[o + npts - 1] = (npts == 1 || closed) ? (int32_t)o : -1;
+            o += npts;
+        }
+        return vpk_draw_small(ctx, d_img, w, h, cn, pts, nx, (int)N, thickness, color);
+    }
     int slot = -1;
     uint8_t* hp = ring_take(ctx, N * 12, &slot);
     if (!hp) return vp_fail(ctx, VP_ERR_NOMEM, "pinned staging");

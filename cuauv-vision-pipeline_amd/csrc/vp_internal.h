@@ -162,6 +162,7 @@ int vpk_morph_generic(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int 
 // span form (see vp_morph.hip): d_spans = nspans triples (dy, x0, x1); d_tab = 7 planes of w*h*cn bytes; max_len = longest span
 int vpk_morph_spans(vp_ctx* ctx, int dilate, const uint8_t* d_src, int w, int h, int cn, const int16_t* d_spans, int nspans, int max_len,
                     uint8_t* d_tab, uint8_t* d_dst);
+int vpk_draw_small(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* pts, const int32_t* nxt, int npts, int thickness, const uint8_t* color);
 int vpk_draw_segments(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* d_pts, const int32_t* d_nxt, int npts, int thickness,
                       const uint8_t* color);
 int vpk_add_weighted_u8(vp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double alpha, double beta, double gamma, uint8_t* dst);

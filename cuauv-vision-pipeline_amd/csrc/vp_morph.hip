@@ -622,20 +622,13 @@ __global__ __launch_bounds__(256) void k_add_weighted_u8(const uint8_t* __restri
     }
 }
 
-// Overlay drawing into a device image (vp_draw_polylines_dev): one wave per segment.  The host rasteriser's Bresenham loop (vp_draw_polylines_u8 /
-// vision/utils/draw.py _line: err = dx + dy;
-// e2 = 2 err; x steps when e2 >= dy, y steps when e2 <= dx) always advances the longer axis, and after i steps the shorter one stands
-// at floor((2 i m + M) / (2 M)) (m, M = the shorter and the longer extent; dx >= |dy| counts as x-major) - checked against the loop
-// for every segment of a 141 x 141 neighbourhood and 3000 random long ones - so the steps of a segment are independent: lane = step.
-// nxt[g] = index of the point that point g is joined to (itself: a single point; -1: the open end of a polyline).
-__global__ __launch_bounds__(256) void k_draw_segments(uint8_t* __restrict__ img, int w, int h, int cn, const int2* __restrict__ pts,
-                                                       const int32_t* __restrict__ nxt, int npts, int thickness, uchar4 color)
+// Overlay drawing into a device image (vp_draw_polylines_dev): one wave per segment.  The host rasteriser's Bresenham loop
+// (vp_draw_polylines_u8 / vision/utils/draw.py _line: err = dx + dy; e2 = 2 err; x steps when e2 >= dy, y steps when e2 <= dx) always
+// advances the longer axis, and after i steps the shorter one stands at floor((2 i m + M) / (2 M)) (m, M = the shorter and the longer
+// extent; dx >= |dy| counts as x-major) - tests/test_draw.py checks that against the loop - so the steps of a segment are independent:
+// lane = step.  nxt[g] = index of the point that point g is joined to (itself: a single point; -1: the open end of a polyline).
+__device__ __forceinline__ void draw_segment_steps(uint8_t* __restrict__ img, int w, int h, int cn, int2 a, int2 b, int thickness, uchar4 color, int lane)
 {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (g >= npts) return;
-    const int j = nxt[g];
-    if (j < 0) return;
-    const int2 a = pts[g], b = pts[j];
     const long long dx = llabs((long long)b.x - a.x), ady = llabs((long long)b.y - a.y);
     const int sx = a.x < b.x ? 1 : -1, sy = a.y < b.y ? 1 : -1;
     const long long n = dx > ady ? dx : ady;
@@ -661,6 +654,38 @@ __global__ __launch_bounds__(256) void k_draw_segments(uint8_t* __restrict__ img
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void k_draw_segments(uint8_t* __restrict__ img, int w, int h, int cn, const int2* __restrict__ pts,
+                                                       const int32_t* __restrict__ nxt, int npts, int thickness, uchar4 color)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= npts) return;
+    const int j = nxt[g];
+    if (j < 0) return;
+    draw_segment_steps(img, w, h, cn, pts[g], pts[j], thickness, color, lane);
+}
+
+// a few vertices (a box of bins.py: four) travel as kernel arguments: no copy, no staging
+#define VP_DRAW_SMALL 48
+struct draw_small { int2 pts[VP_DRAW_SMALL]; int16_t nxt[VP_DRAW_SMALL]; };
+__global__ __launch_bounds__(256) void k_draw_small(uint8_t* __restrict__ img, int w, int h, int cn, draw_small D, int npts, int thickness, uchar4 color)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= npts) return;
+    const int j = D.nxt[g];
+    if (j < 0) return;
+    draw_segment_steps(img, w, h, cn, D.pts[g], D.pts[j], thickness, color, threadIdx.x & 63);
+}
+int vpk_draw_small(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* pts, const int32_t* nxt, int npts, int thickness, const uint8_t* color)
+{
+    if (npts <= 0) return VP_OK;
+    if (npts > VP_DRAW_SMALL) return vp_fail(ctx, VP_ERR_INVALID, "vpk_draw_small: too many points");
+    draw_small D;
+    for (int i = 0; i < npts; i++) { D.pts[i] = make_int2(pts[2 * i], pts[2 * i + 1]); D.nxt[i] = (int16_t)nxt[i]; }
+    const uchar4 c = make_uchar4(color[0], cn > 1 ? color[1] : 0, cn > 2 ? color[2] : 0, cn > 3 ? color[3] : 0);
+    hipLaunchKernelGGL(k_draw_small, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, ctx->stream, d_img, w, h, cn, D, npts, thickness, c);
+    VP_HIP(ctx, hipGetLastError());
+    return VP_OK;
 }
 
 int vpk_draw_segments(vp_ctx* ctx, uint8_t* d_img, int w, int h, int cn, const int32_t* d_pts, const int32_t* d_nxt, int npts, int thickness,
