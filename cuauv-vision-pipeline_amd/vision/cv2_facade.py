@@ -192,8 +192,9 @@ def minAreaRect(points):
     """Minimum-area enclosing rectangle by rotating calipers over the convex hull: ((cx, cy), (w, h), angle in degrees).
     Angle convention of OpenCV >= 4.5.1: in (0, 90], width measured along the edge that defines the angle."""
     p = np.asarray(points).reshape(-1, 2)
-    if np.issubdtype(p.dtype, np.integer) and len(p) and np.abs(p).max(initial=0) < 2**31:
-        # contours: hull and calipers in libvp's host routine (the doubles of _min_area_rect_loop, statement by statement)
+    # contours: hull and calipers in libvp's host routine (the doubles of _min_area_rect_loop, statement by statement).  What
+    # find_contours returns is int32 already: no range check, no copy (numpy calls on a handful of points cost more than the calipers)
+    if len(p) and (p.dtype == np.int32 or (np.issubdtype(p.dtype, np.integer) and np.abs(p).max(initial=0) < 2**31)):
         p32 = p if (p.dtype == np.int32 and p.flags.c_contiguous) else np.ascontiguousarray(p, np.int32)
         out = (_vp.C.c_float * 5)()
         _vp.check(_vp.lib().vp_min_area_rect_i32(p32.ctypes.data, len(p32), out))
