@@ -202,6 +202,24 @@ def test_full_size_frame_properties(vp, oracle):
         assert all(tuple(p) in ia for p in b)
     noise = F.random_mask(rng, 1080, 1920, 0.5)
     _check(vp, oracle, noise, 1, 2)
+    # RETR_EXTERNAL on speckle (140 k components, chains of "same answer as the component to my left" across the frame)
+    _check(vp, oracle, F.random_mask(rng, 1080, 1920, 0.1), 0, 2)
+
+
+def test_4k_frame(vp, oracle):
+    """3840 x 2160 (BASELINE config 4's frame size): discs with holes and a frame-wide bar, both retrieval modes."""
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:2160, 0:3840]
+    m = np.zeros((2160, 3840), np.uint8)
+    for _ in range(40):
+        cx, cy, r = rng.uniform(0, 3840), rng.uniform(0, 2160), rng.uniform(10, 400)
+        m[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 255
+    for _ in range(20):
+        cx, cy, r = rng.uniform(0, 3840), rng.uniform(0, 2160), rng.uniform(5, 120)
+        m[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 0
+    m[1000:1004, :] = 255
+    for mode in (0, 1):
+        _check(vp, oracle, m, mode, 2)
 
 
 @pytest.mark.parametrize("source,mode", [("cleaned", 0), ("threshed", 1)])
