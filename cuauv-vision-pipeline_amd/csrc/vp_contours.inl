@@ -41,7 +41,7 @@ struct ct_frame_out {      // per frame, device
 // Between s and s' the follower sweeps over background neighbours.  Every crack (edge between a foreground pixel and a
 // 4-adjacent background pixel) is swept by exactly one state of exactly one border, and that state can be written down from
 // the crack alone: s = first foreground neighbour clockwise from the crack's direction.  So the states that sweep a W or E
-// crack in a row y % 4 == 0 or an N or S crack in a column x % 8 == 0 (and every W or E crack that a border could start at) are
+// crack in a row y % 2 == 0 or an N or S crack in a column x % 4 == 0 (and every W or E crack that a border could start at) are
 // enumerable with bit operations - the "heads" - and they cut every border into short segments that are followed independently, one
 // thread each.  A pixel without neighbours is a
 // border of its own: one head (listed with the W heads), one point.
@@ -63,8 +63,14 @@ struct ct_frame_out {      // per frame, device
 #define CT_UNSEL 0xfffffffeu
 #define CT_FRAME 0xffffffffu      // ext[]: nothing but background left of the first pixel / the border is external
 #define CT_INSIDE 0xfffffffeu     // ext[]: inside a hole
-#define CT_EL_NS 0x0101010101010101ull   // N / S cracks are heads only in columns x % 8 == 0
+#ifndef CT_COL_MASK
+#define CT_COL_MASK 3            // N / S cracks are heads only in columns x % 4 == 0
+#endif
+#define CT_EL_NS (CT_COL_MASK == 7 ? 0x0101010101010101ull : (CT_COL_MASK == 3 ? 0x1111111111111111ull : 0x5555555555555555ull))
 #define CT_JUMP_ROUNDS 40
+#ifndef CT_ROW_MASK
+#define CT_ROW_MASK 1            // W / E cracks are heads in rows y % 2 == 0 (and wherever a border could start)
+#endif
 
 struct ct_aux { u32 nheads; u32 nsel; };
 
@@ -115,9 +121,9 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
         const u64 el = CT_EL_NS;
         u64 hw = 0, he = 0, hn = 0, hs = 0;
         if (c) {
-            // eligible cracks: N / S in columns x % 8 == 0; W / E in rows y % 4 == 0 and wherever the crack could be the smallest of
+            // eligible cracks: N / S in columns x % 4 == 0; W / E in rows y % 2 == 0 and wherever the crack could be the smallest of
             // its border (W: nothing above the pixel; E: the background pixel has foreground above it) - see ct_head_type
-            const u64 rowel = (y & 3) == 0 ? ~0ull : 0ull;
+            const u64 rowel = (y & CT_ROW_MASK) == 0 ? ~0ull : 0ull;
             const u64 elw = rowel | ~(n[1] | n[2] | n[3]), ele = rowel | n[1];
             hw = c & ~n[4] & elw & (n[3] | n[2] | (~el & (n[1] | n[0] | (~ele & (n[7] | n[6] | n[5])))));
             he = c & ~n[0] & ele & (n[7] | n[6] | (~el & (n[5] | n[4] | (~elw & (n[3] | n[2] | n[1])))));
@@ -256,15 +262,16 @@ __device__ __forceinline__ int ct_first_cw(u32 R, int d)
 }
 // state (s, sweep length t = number of background neighbours swept before s') of pixel (y, x) with neighbour ring R: type of the
 // head that owns it (0 W, 1 E, 2 N, 3 S) = the first ELIGIBLE crack it sweeps, or -1 (the state is not a head).  Eligible: N / S
-// cracks in columns x % 8 == 0; W / E cracks in rows y % 4 == 0 - these cut every border into segments of a few pixels - and every
+// cracks in columns x % 4 == 0; W / E cracks in rows y % 2 == 0 - these cut every border into segments of a few pixels (measured:
+// 8 / 4, 8 / 2 and 4 / 2 for the two spacings: chain + contours of 128 frames 0.75 / 0.715 / 0.69 ms) - and every
 // W / E crack that could be the smallest of its border: a W crack of a pixel with nothing above it (a component's first pixel is such
 // a one), an E crack whose background pixel has foreground above it (a hole's first pixel is such a one) - so that every border has
-// a head at its start state.  (Every vertical crack used to be a head: 2.3 x the heads on a module's mask, and the bookkeeping
-// between the two follower passes is bound by exactly that number.)
+// a head at its start state.  (Every vertical crack as a head: more heads than the walks need - speckle pays for them in the
+// bookkeeping: 10 % noise 1.89 -> 1.59 ms with rows thinned; the one-block form does not care, it waits for latency.)
 __device__ __forceinline__ int ct_head_type(int s, int t, int x, int y, u32 R)
 {
     const int iw = (3 - s) & 7, ie = (7 - s) & 7, in = (1 - s) & 7, is = (5 - s) & 7;
-    const bool ns = (x & 7) == 0, rowel = (y & 3) == 0;
+    const bool ns = (x & CT_COL_MASK) == 0, rowel = (y & CT_ROW_MASK) == 0;
     const bool elw = rowel || !(R & 0xeu), ele = rowel || (R & 2u);
     int best = 8, type = -1;
     if (elw && iw < t) { best = iw; type = 0; }
