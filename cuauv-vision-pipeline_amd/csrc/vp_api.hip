@@ -1438,10 +1438,7 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
             if (d->ccl == 1) ccl_bits = bits_a;
         }
     }
-    if (d->ccl) {
-        VP_TRY(vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels, b->nlabels ? b->nlabels : d_nl));
-    }
-    if (cd) {
+    auto contours_of_batch = [&]() -> int {
         const u64* src = cd->source == 1 ? clean_bits : bits_t;
         const size_t fw = (size_t)h * vp_ww(w);
         const size_t mc = (size_t)cd->max_contours;
@@ -1455,7 +1452,32 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
                                      cd->max_points, cb->info + 2 * (size_t)f0));
         }
         if (cb->features) VP_TRY(vpk_contour_features(ctx, cb->info, cb->counts, cb->offsets, cb->points, n, cd->max_contours, cd->max_points, cb->features));
+        return VP_OK;
+    };
+    // The contour pass needs the mask only, not the labelling: when the chain does both it is queued on the context's side stream as
+    // soon as the mask exists and runs beside the labelling and its label write (latency-bound launches beside a bandwidth-bound one);
+    // the caller's stream joins it at the end.  One pass for the whole batch only (the scratch is carved once).  VP_CT_SIDE=0: in a row.
+    static const bool ct_side_off = getenv("VP_CT_SIDE") && atoi(getenv("VP_CT_SIDE")) == 0;
+    const bool ct_side = cd && d->ccl && !ct_side_off && ctx->chain_streams == 1 && ct_group_for(w, h, cd->max_contours) >= n;
+    int rc_ct = VP_OK;
+    bool joined = true;
+    hipStream_t s_main = ctx->stream;
+    if (ct_side) {
+        VP_HIP(ctx, hipEventRecord(ctx->ev_fb_fork, s_main));
+        VP_HIP(ctx, hipStreamWaitEvent(ctx->fb_stream, ctx->ev_fb_fork, 0));
+        ctx->stream = ctx->fb_stream;
+        rc_ct = contours_of_batch();
+        const hipError_t ej = hipEventRecord(ctx->ev_fb_join, ctx->fb_stream);
+        ctx->stream = s_main;
+        joined = false;
+        if (ej != hipSuccess) { (void)hipStreamSynchronize(ctx->fb_stream); joined = true; if (rc_ct == VP_OK) rc_ct = vp_fail(ctx, VP_ERR_HIP, "hipEventRecord", ej); }
     }
+    int rc_ccl = VP_OK;
+    if (d->ccl) rc_ccl = vpk_ccl(ctx, ccl_bits, w, h, n, d->numbering, ws, b->labels, b->stats, b->centroids, d->max_labels, b->nlabels ? b->nlabels : d_nl);
+    if (!joined && hipStreamWaitEvent(s_main, ctx->ev_fb_join, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(ctx->fb_stream); }
+    if (rc_ccl != VP_OK) return rc_ccl;
+    if (rc_ct != VP_OK) return rc_ct;
+    if (cd && !ct_side) VP_TRY(contours_of_batch());
     return VP_OK;
 }
 
