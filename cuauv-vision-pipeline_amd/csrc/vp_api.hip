@@ -128,6 +128,7 @@ int vp_destroy(vp_ctx* ctx)
     vp_post_teardown(ctx);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->c3_acc) hipFree(ctx->c3_acc);
+    if (ctx->ct_hint_host) hipHostFree(ctx->ct_hint_host);
     for (int i = 0; i < 4; i++) {
         if (ctx->ring_buf[i]) hipHostFree(ctx->ring_buf[i]);
         if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
@@ -1271,10 +1272,10 @@ static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_devic
         VP_TRY(vpk_pack_bits(ctx, d_src, d_stride, w, h, 1, d_bits, nullptr));
     }
     // one block does the bookkeeping between the two follower passes - unless the last pass of this context met a speckled mask
-    // (tens of thousands of border segments): then it is launched over the chip (VP_CT_MANY=0 / 1: never / always)
+    // (more border segments than the block's LDS tables hold: 8192): then it is launched over the chip (VP_CT_MANY=0 / 1: never / always)
     const char* many_s = getenv("VP_CT_MANY");
     const int many_env = many_s ? atoi(many_s) : -1;
-    const bool many = many_env >= 0 ? many_env != 0 : ctx->ct_heads_hint > 16384u;
+    const bool many = many_env >= 0 ? many_env != 0 : ctx->ct_heads_hint > 8192u;
     // The header and the first points come back without a copy: the kernels that make them write them into the pinned staging
     // buffer as well, and the call only synchronises (longer point lists take a copy afterwards).  VP_CT_MIRROR=0: a copy, as before.
     const size_t spec_pts = points ? (size_t)std::min<long long>(mp, 8192) : 0;
@@ -1346,6 +1347,13 @@ int vp_find_contours_dev(vp_ctx* ctx, const uint8_t* d_src, size_t src_stride, i
                          int64_t max_points, int32_t* counts, uint8_t* is_hole, int max_contours, int32_t* n_contours, int64_t* n_points)
 {
     return find_contours_impl(ctx, d_src, true, src_stride, w, h, mode, method, points, max_points, counts, is_hole, max_contours, n_contours, n_points);
+}
+
+unsigned int vp_contours_last_heads(vp_ctx* ctx)
+{
+    if (!ctx) return 0;
+    const uint32_t b = vp_ct_batch_hint(ctx);
+    return b > ctx->ct_heads_hint ? b : ctx->ct_heads_hint;
 }
 
 int vp_find_contours_bits_dev(vp_ctx* ctx, const unsigned long long* d_bits, int w, int h, int mode, int method, int32_t* points, int64_t max_points,
@@ -1444,12 +1452,16 @@ static int chain_core(vp_ctx* ctx, const vp_chain_desc* d, const vp_chain_buffer
         const size_t mc = (size_t)cd->max_contours;
         const size_t mark = ctx->ws_off;
         const int group = ct_group_for(w, h, cd->max_contours);
+        // speckled frames in the last batch (its prefix kernel left the head counts in pinned memory): the bookkeeping as launches over
+        // the chip instead of one block per frame (VP_CT_MANY=0 / 1: never / always)
+        const char* many_s = getenv("VP_CT_MANY");
+        const bool many = many_s ? atoi(many_s) != 0 : vp_ct_batch_hint(ctx) > 8192u;
         for (int f0 = 0; f0 < n; f0 += group) {
             const int g = std::min(group, n - f0);
             ctx->ws_off = mark;   // every group reuses the same scratch (stream order keeps them apart)
             VP_TRY(vpk_find_contours(ctx, src + (size_t)f0 * fw, w, h, g, cd->mode, cd->method, cb->counts + f0 * mc, cb->is_hole + f0 * mc,
                                      cb->offsets + f0 * mc, cb->points + 2 * (size_t)f0 * (size_t)cd->max_points, cd->max_contours,
-                                     cd->max_points, cb->info + 2 * (size_t)f0));
+                                     cd->max_points, cb->info + 2 * (size_t)f0, many));
         }
         if (cb->features) VP_TRY(vpk_contour_features(ctx, cb->info, cb->counts, cb->offsets, cb->points, n, cd->max_contours, cd->max_points, cb->features));
         return VP_OK;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
 // grid (ceil(nwords/256), n): block b adds up the block sums before it, then scans its 256 words.
 __global__ __launch_bounds__(256) void k_ct_prefix(const u64* __restrict__ maps, int nm, int nwords, const u32* __restrict__ partsum,
                                                    u32* __restrict__ base, u32* __restrict__ total_out, int tstride, int w, int ww,
-                                                   u32* __restrict__ head_pix, size_t hcap, const uint8_t* __restrict__ cnt8)
+                                                   u32* __restrict__ head_pix, size_t hcap, const uint8_t* __restrict__ cnt8, u32* __restrict__ hint_host)
 {
     __shared__ u32 wsum[4], wtot[4];
     const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void k_ct_prefix(const u64* __restrict__ maps,
             }
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) total_out[(size_t)f * tstride] = carry + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        total_out[(size_t)f * tstride] = carry + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (hint_host) hint_host[f & 63] = carry + wsum[0] + wsum[1] + wsum[2] + wsum[3];     // (pinned: the caller's guess for its next batch)
+    }
 }
 
 // dense index of head (word idx, bit b, type t)
@@ -1167,6 +1170,28 @@ size_t vp_contours_ws_bytes(int w, int h, int n, int max_contours)
 }
 
 
+// Head counts of the frames of the last batched pass (up to 64 of them), written by its prefix kernel into a pinned array of the
+// context's: read WITHOUT synchronising by the next call that has to choose a form of the bookkeeping (vp_ct_batch_hint) - possibly
+// a call late, possibly of another mask: a guess, which the results do not depend on.
+static u32* vp_ct_hint_slots(vp_ctx* ctx, int n)
+{
+    if (!ctx->ct_hint_host) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64 * sizeof(u32), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        memset(p, 0, 64 * sizeof(u32));
+        ctx->ct_hint_host = (uint32_t*)p;
+    }
+    ctx->ct_hint_n = n < 64 ? n : 64;
+    return ctx->ct_hint_host;
+}
+uint32_t vp_ct_batch_hint(vp_ctx* ctx)
+{
+    uint32_t m = 0;
+    if (ctx->ct_hint_host)
+        for (int i = 0; i < ctx->ct_hint_n; i++) { const uint32_t v = *(volatile uint32_t*)(ctx->ct_hint_host + i); m = v > m ? v : m; }
+    return m;
+}
+
 // d_counts / d_is_hole / d_offsets: [n][max_contours]; d_points: [n][max_points][2]; d_info: [n] {n_contours, n_points}.  Contours are
 // stored in discovery order (raster order of the start pixel); cv2 returns them reversed - the caller reverses.
 // Five launches on the context's stream.  `many_heads` (one image whose last pass counted very many heads - the caller's guess, the
@@ -1224,7 +1249,8 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
     const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
     hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
-    hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &A.aux->nheads, 2, w, G.ww, head_pix, hcap, cnt8);
+    hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &A.aux->nheads, 2, w, G.ww, head_pix, hcap, cnt8,
+                       (n > 1 || !host) ? vp_ct_hint_slots(ctx, n) : nullptr);
     hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method,
                        d_offsets, d_points, max_contours, max_points, (int32_t*)nullptr, 0ll);
     if (!many_heads) {

@@ -44,6 +44,8 @@ struct vp_ctx {
     hipEvent_t ring_ev[4];
     int ring_busy[4];
     int ring_next;
+    uint32_t* ct_hint_host;       // pinned: head counts of the last batched contour pass (vp_contours.inl vp_ct_hint_slots)
+    int ct_hint_n;
     uint32_t ct_heads_hint;   // border segments the last single-image contour pass counted (vp_find_contours_*: which form of the bookkeeping to launch)
     int num_cu;
     int chain_streams;            // sub-batches of a chain run on this many internal streams (>= 1)
@@ -204,6 +206,7 @@ int vpk_contour_features(vp_ctx* ctx, const int32_t* d_info, const int32_t* d_co
 // segments (its last pass said so through d_nheads_out) - a choice between two forms of the same steps, not of the result.
 // host (n == 1 only): pinned, device-visible buffers the producing kernels write the results into as well - info {n_contours,
 // n_points, heads}, counts / offsets / is_hole [max_contours], the first points_cap points - so that the caller only synchronises.
+uint32_t vp_ct_batch_hint(vp_ctx* ctx);      // largest head count the last batched pass reported (a guess; no synchronisation)
 struct vp_contour_mirror { int32_t* info; int32_t* counts; int32_t* offsets; uint8_t* is_hole; int32_t* points; long long points_cap; };
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, bool many_heads = false,

@@ -137,6 +137,7 @@ _SIGS = {
     "vp_post_fence": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_post_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vp_inrange_u8_bits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "vp_contours_last_heads": (C.c_uint, [C.c_void_p]),
     "vp_find_contours_bits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "vp_memcpy_d2d_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

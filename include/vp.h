@@ -214,6 +214,11 @@ int vp_add_weighted_u8_dev(vp_ctx* ctx, const uint8_t* a_dev, double alpha, cons
 int vp_find_contours_bits_dev(vp_ctx* ctx, const unsigned long long* bits_dev, int w, int h, int mode, int method, int32_t* points_host,
                               int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours, int32_t* n_contours,
                               int64_t* n_points);
+/* Diagnostic: the largest number of border segments ("heads") a frame of this context's last contour pass held, as far as it has been
+ * reported back (single-image calls: exact; batched passes: read from pinned memory without synchronising, so possibly one call
+ * late).  It is what the next pass chooses the form of its bookkeeping by (one block per frame / launches over the chip) - a choice
+ * the results do not depend on. */
+unsigned int vp_contours_last_heads(vp_ctx* ctx);
 int vp_find_contours_dev(vp_ctx* ctx, const uint8_t* src_dev, size_t src_stride, int w, int h, int mode, int method,
                          int32_t* points_host, int64_t max_points, int32_t* counts_host, uint8_t* is_hole_host, int max_contours,
                          int32_t* n_contours, int64_t* n_points);

@@ -544,3 +544,33 @@ def test_threshold_masks_carry_their_bit_plane_to_the_contour_pass(vp, oracle):
     assert th._bits is None
     th = color.range_threshold(color.bgr_to_lab(DeviceMat.from_host(ctx, frame))[1][1], 150, 255)
     assert th.reshaped((360, 640, 1))._bits is None
+
+
+def test_batch_with_speckled_frames_takes_either_form(vp, oracle, monkeypatch):
+    """vp_chain_run_contours on a batch that holds raw-noise frames (tens of thousands of border segments each): the first call does the
+    bookkeeping in one block per frame (tables in global memory for such frames), the prefix kernel leaves the head counts in pinned
+    memory, and the next call - unforced - launches the bookkeeping over the chip.  Same contours as the oracle either way."""
+    from vision import _vp
+    from vision.utils import chain
+    h, w = 200, 320
+    frames = np.stack([F.s3_noise(0, w, h), F.s1_buoy(1, w, h), F.s3_noise(2, w, h), F.s4_flat(255, w, h)])
+    exp = []
+    for f in range(len(frames)):
+        th = oracle.inrange(oracle.bgr2gray(frames[f]), 128, 255)
+        exp.append((th,) + tuple(oracle.find_contours(th, 1, 2, with_holes=True)))
+    cap = max(len(e[1]) for e in exp) + 8
+    pts = max(sum(len(c) for c in e[1]) for e in exp) + 64
+
+    def run():
+        out = chain.run_chain(frames, _vp.BGR2GRAY, (128, 0, 0), (255, 255, 255), (), ccl=1, want=("threshed", "stats"),
+                              contours=dict(source="threshed", mode=1, method=2, max_contours=cap, max_points=pts))
+        for f, (th, ec, eh) in enumerate(exp):
+            assert np.array_equal(out["threshed"][f], th)
+            got, gh = out["contours"][f]
+            assert _same(got, ec) and np.array_equal(gh, eh), f
+    run()                                            # the form the fixture forces
+    monkeypatch.delenv("VP_CT_MANY")
+    ctx = vp.default_context()
+    run()
+    run()                                            # by now the hint of the call before has arrived
+    assert vp.lib().vp_contours_last_heads(ctx.handle) > 8192
