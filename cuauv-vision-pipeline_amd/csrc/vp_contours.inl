@@ -41,7 +41,8 @@ struct ct_frame_out {      // per frame, device
 // Between s and s' the follower sweeps over background neighbours.  Every crack (edge between a foreground pixel and a
 // 4-adjacent background pixel) is swept by exactly one state of exactly one border, and that state can be written down from
 // the crack alone: s = first foreground neighbour clockwise from the crack's direction.  So the states that sweep a W or E
-// crack in a row y % 2 == 0 or an N or S crack in a column x % 4 == 0 (and every W or E crack that a border could start at) are
+// crack in every second (or fourth) row or an N or S crack in every fourth (or eighth) column - ct_cut - (and every W or E crack that
+// a border could start at) are
 // enumerable with bit operations - the "heads" - and they cut every border into short segments that are followed independently, one
 // thread each.  A pixel without neighbours is a
 // border of its own: one head (listed with the W heads), one point.
@@ -63,14 +64,16 @@ struct ct_frame_out {      // per frame, device
 #define CT_UNSEL 0xfffffffeu
 #define CT_FRAME 0xffffffffu      // ext[]: nothing but background left of the first pixel / the border is external
 #define CT_INSIDE 0xfffffffeu     // ext[]: inside a hole
-#ifndef CT_COL_MASK
-#define CT_COL_MASK 3            // N / S cracks are heads only in columns x % 4 == 0
-#endif
-#define CT_EL_NS (CT_COL_MASK == 7 ? 0x0101010101010101ull : (CT_COL_MASK == 3 ? 0x1111111111111111ull : 0x5555555555555555ull))
 #define CT_JUMP_ROUNDS 40
-#ifndef CT_ROW_MASK
-#define CT_ROW_MASK 1            // W / E cracks are heads in rows y % 2 == 0 (and wherever a border could start)
-#endif
+// Spacing of the cuts.  DENSE (a module's mask): W / E cracks are heads in rows y % 2 == 0, N / S cracks in columns x % 4 == 0 - short
+// walks, what the follower passes of a clean mask or a batch wait for (8 / 4, 8 / 2, 4 / 2 for columns / rows: chain + contours of 128
+// frames 0.75 / 0.715 / 0.69 ms).  SPARSE (a frame expected to be speckled - the caller's `many_heads`): rows y % 4, columns x % 8 -
+// fewer heads, what the bookkeeping of 600 k of them pays for (10 % noise, one image: 1.57 against 1.75 ms).
+template <bool SPARSE> struct ct_cut {
+    static constexpr int row_mask = SPARSE ? 3 : 1;
+    static constexpr int col_mask = SPARSE ? 7 : 3;
+    static constexpr u64 el_ns = SPARSE ? 0x0101010101010101ull : 0x1111111111111111ull;
+};
 
 struct ct_aux { u32 nheads; u32 nsel; };
 
@@ -106,6 +109,7 @@ __device__ __forceinline__ void ct_block_sum(u32 c, u32* __restrict__ partsum)
     if (threadIdx.x == 0) partsum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ws4[0] + ws4[1] + ws4[2] + ws4[3];
 }
 
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bits, ccl_geom G, u64* __restrict__ hmaps, u32* __restrict__ partsum,
                                                      uint8_t* __restrict__ cnt8)
 {
@@ -118,12 +122,12 @@ __global__ __launch_bounds__(256) void k_ct_headmaps(const u64* __restrict__ bit
         const int y = idx / G.ww, j = idx - y * G.ww;
         u64 c, n[8];
         ct_neighbours(G, fb, y, j, c, n);
-        const u64 el = CT_EL_NS;
+        const u64 el = ct_cut<SPARSE>::el_ns;
         u64 hw = 0, he = 0, hn = 0, hs = 0;
         if (c) {
-            // eligible cracks: N / S in columns x % 4 == 0; W / E in rows y % 2 == 0 and wherever the crack could be the smallest of
+            // eligible cracks: N / S in the cut columns; W / E in the cut rows (ct_cut) and wherever the crack could be the smallest of
             // its border (W: nothing above the pixel; E: the background pixel has foreground above it) - see ct_head_type
-            const u64 rowel = (y & CT_ROW_MASK) == 0 ? ~0ull : 0ull;
+            const u64 rowel = (y & ct_cut<SPARSE>::row_mask) == 0 ? ~0ull : 0ull;
             const u64 elw = rowel | ~(n[1] | n[2] | n[3]), ele = rowel | n[1];
             hw = c & ~n[4] & elw & (n[3] | n[2] | (~el & (n[1] | n[0] | (~ele & (n[7] | n[6] | n[5])))));
             he = c & ~n[0] & ele & (n[7] | n[6] | (~el & (n[5] | n[4] | (~elw & (n[3] | n[2] | n[1])))));
@@ -265,16 +269,16 @@ __device__ __forceinline__ int ct_first_cw(u32 R, int d)
 }
 // state (s, sweep length t = number of background neighbours swept before s') of pixel (y, x) with neighbour ring R: type of the
 // head that owns it (0 W, 1 E, 2 N, 3 S) = the first ELIGIBLE crack it sweeps, or -1 (the state is not a head).  Eligible: N / S
-// cracks in columns x % 4 == 0; W / E cracks in rows y % 2 == 0 - these cut every border into segments of a few pixels (measured:
-// 8 / 4, 8 / 2 and 4 / 2 for the two spacings: chain + contours of 128 frames 0.75 / 0.715 / 0.69 ms) - and every
+// cracks in the cut columns, W / E cracks in the cut rows (ct_cut) - these cut every border into segments of a few pixels - and every
 // W / E crack that could be the smallest of its border: a W crack of a pixel with nothing above it (a component's first pixel is such
 // a one), an E crack whose background pixel has foreground above it (a hole's first pixel is such a one) - so that every border has
 // a head at its start state.  (Every vertical crack as a head: more heads than the walks need - speckle pays for them in the
 // bookkeeping: 10 % noise 1.89 -> 1.59 ms with rows thinned; the one-block form does not care, it waits for latency.)
+template <bool SPARSE>
 __device__ __forceinline__ int ct_head_type(int s, int t, int x, int y, u32 R)
 {
     const int iw = (3 - s) & 7, ie = (7 - s) & 7, in = (1 - s) & 7, is = (5 - s) & 7;
-    const bool ns = (x & CT_COL_MASK) == 0, rowel = (y & CT_ROW_MASK) == 0;
+    const bool ns = (x & ct_cut<SPARSE>::col_mask) == 0, rowel = (y & ct_cut<SPARSE>::row_mask) == 0;
     const bool elw = rowel || !(R & 0xeu), ele = rowel || (R & 2u);
     int best = 8, type = -1;
     if (elw && iw < t) { best = iw; type = 0; }
@@ -291,6 +295,7 @@ __device__ __forceinline__ u32 ct_key_e(const ccl_geom& G, int y, int x) { retur
 
 // RETR_EXTERNAL: what lies left of a possible first pixel (y, x) in its row: CT_FRAME, or a head of the border that owns the E crack
 // of the first foreground pixel met (the first head at or after the state that sweeps that crack)
+template <bool SPARSE>
 __device__ __forceinline__ u32 ct_left_of(const ccl_geom& G, const u64* __restrict__ fb, const u64* __restrict__ hm, const u32* __restrict__ hb,
                                           int y, int x)
 {
@@ -307,7 +312,7 @@ __device__ __forceinline__ u32 ct_left_of(const ccl_geom& G, const u64* __restri
     int s = ct_first_cw(R, 0);
     for (long long guard = 8ll * G.w * G.h + 16; guard > 0; guard--) {
         const int t = __ffs((int)((R | (R << 8)) >> (s + 1))) - 1;
-        const int ht = ct_head_type(s, t, x, y, R);
+        const int ht = ct_head_type<SPARSE>(s, t, x, y, R);
         if (ht >= 0) return ct_head_index(hm, hb, y * G.ww + (x >> 6), x & 63, ht);
         const int s2 = (s + 1 + t) & 7;
         x += dx8(s2); y += dy8(s2);
@@ -324,7 +329,7 @@ __device__ __forceinline__ u32 ct_left_of(const ccl_geom& G, const u64* __restri
 // one thread per head: follow the border from the head's state to the next head.
 //   !WRITE: node[k] = next head << 32 | points emitted; key[k]; ext[k] (mode 0)
 //    WRITE: the points go to their final place (see ct_offsets_body)
-template <bool WRITE>
+template <bool WRITE, bool SPARSE>
 __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, ccl_geom G, const u64* __restrict__ hmaps, const u32* __restrict__ hbase,
                                                 const u32* __restrict__ head_pix, const u32* __restrict__ hrank, size_t hcap,
                                                 const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, u32* __restrict__ hkey,
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
                 if (hroom > 0) { hout[0] = x; hout[1] = y; }
             } else if (keys) {
                 hkey[(size_t)f * hcap + k] = ct_key_w(G, y, x);
-                if (mode == 0) hext[(size_t)f * hcap + k] = ct_left_of(G, fb, hm, hb, y, x);
+                if (mode == 0) hext[(size_t)f * hcap + k] = ct_left_of<SPARSE>(G, fb, hm, hb, y, x);
             } else {
                 nd[k] = ((unsigned long long)k << 32) | 1u;
             }
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             const bool sw = ((3 - s) & 7) < t0, se = ((7 - s) & 7) < t0;        // the state sweeps the pixel's W / E crack
             hkey[(size_t)f * hcap + k] = sw ? ct_key_w(G, y, x) : (se ? ct_key_e(G, y, x) : CT_NONE);
             // a component's first pixel has nothing above it: only such a W crack can turn out to be the smallest of its cycle
-            if (mode == 0) hext[(size_t)f * hcap + k] = (sw && !(R & 0xeu)) ? ct_left_of(G, fb, hm, hb, y, x) : CT_INSIDE;
+            if (mode == 0) hext[(size_t)f * hcap + k] = (sw && !(R & 0xeu)) ? ct_left_of<SPARSE>(G, fb, hm, hb, y, x) : CT_INSIDE;
             continue;
         }
         u32 cnt = 0, succ = k;
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
             const u32 q = (R | (R << 8)) >> (s + 1);
             const int t = __ffs((int)q) - 1;
             if (!first) {
-                const int ht = ct_head_type(s, t, x, y, R);
+                const int ht = ct_head_type<SPARSE>(s, t, x, y, R);
                 if (ht >= 0) { succ = ct_head_index(hm, hb, y * G.ww + (x >> 6), x & 63, ht); break; }
             }
             first = false;
@@ -1248,11 +1253,13 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     // heads per frame are not known on the host: a fixed number of blocks per frame walks the head list (a real mask has a few
     // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
     const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
-    hipLaunchKernelGGL(k_ct_headmaps, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
+    if (many_heads) hipLaunchKernelGGL(k_ct_headmaps<true>, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
+    else hipLaunchKernelGGL(k_ct_headmaps<false>, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
     hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &A.aux->nheads, 2, w, G.ww, head_pix, hcap, cnt8,
                        (n > 1 || !host) ? vp_ct_hint_slots(ctx, n) : nullptr);
-    hipLaunchKernelGGL((k_ct_seg<false>), hgrid, dim3(256), 0, s, d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method,
-                       d_offsets, d_points, max_contours, max_points, (int32_t*)nullptr, 0ll);
+#define CT_SEG_ARGS d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method, d_offsets, d_points, max_contours, max_points
+    if (many_heads) hipLaunchKernelGGL((k_ct_seg<false, true>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, (int32_t*)nullptr, 0ll);
+    else hipLaunchKernelGGL((k_ct_seg<false, false>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, (int32_t*)nullptr, 0ll);
     if (!many_heads) {
         hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), jump_lds, s, A);
     } else {
@@ -1276,8 +1283,9 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
         hipLaunchKernelGGL((k_ctm_sums<1>), sg, dim3(1024), 0, s, A);
         hipLaunchKernelGGL((k_ctm_scan<1>), sg, dim3(1024), 0, s, A);
     }
-    hipLaunchKernelGGL((k_ct_seg<true>), hgrid, dim3(256), 0, s, d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method,
-                       d_offsets, d_points, max_contours, max_points, A.mirror.points, A.mirror.cap);
+    if (many_heads) hipLaunchKernelGGL((k_ct_seg<true, true>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, A.mirror.points, A.mirror.cap);
+    else hipLaunchKernelGGL((k_ct_seg<true, false>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, A.mirror.points, A.mirror.cap);
+#undef CT_SEG_ARGS
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
 }
