@@ -742,6 +742,7 @@ __device__ __forceinline__ ctj_frame ctj_make_frame(const ctj_args& A, int f, un
 #ifndef CTJ_HOPS
 #define CTJ_HOPS 4
 #endif
+template <int ITEMS>
 __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, unsigned long long* tab, u32* a1, u32* a2)
 {
     __shared__ u32 s_wsum[16];
@@ -767,10 +768,10 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
 #define CT_STAMP() do { } while (0)
 #endif
     CT_STAMP();
-    unsigned long long ndv[CTJ_ITEMS], v[CTJ_ITEMS];
-    u32 own[CTJ_ITEMS];
+    unsigned long long ndv[ITEMS], v[ITEMS];
+    u32 own[ITEMS];
 #pragma unroll
-    for (int i = 0; i < CTJ_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const u32 k = tid + 1024u * i;
         ndv[i] = 0; own[i] = CT_NONE;
         if (k < H) {
@@ -780,7 +781,7 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
         }
     }
 #pragma unroll
-    for (int i = 0; i < CTJ_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const u32 k = tid + 1024u * i;
         v[i] = (unsigned long long)k << 32;
         if (k < H) { v[i] = (ndv[i] & HI) | own[i]; tab[k] = v[i]; a1[k] = own[i]; }
@@ -791,11 +792,11 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
     for (int round = 0; round < max_rounds; round++) {
         int changed = 0;
         for (int hop = 0; hop < CTJ_HOPS; hop++) {
-            unsigned long long v2[CTJ_ITEMS];
+            unsigned long long v2[ITEMS];
 #pragma unroll
-            for (int i = 0; i < CTJ_ITEMS; i++) { const u32 k = tid + 1024u * i; const u32 J = (u32)(v[i] >> 32); v2[i] = (k < H && J != k) ? tab[J] : v[i]; }
+            for (int i = 0; i < ITEMS; i++) { const u32 k = tid + 1024u * i; const u32 J = (u32)(v[i] >> 32); v2[i] = (k < H && J != k) ? tab[J] : v[i]; }
 #pragma unroll
-            for (int i = 0; i < CTJ_ITEMS; i++) {
+            for (int i = 0; i < ITEMS; i++) {
                 const u32 k = tid + 1024u * i;
                 if (k < H && (u32)(v[i] >> 32) != k) {
                     const bool better = (u32)v2[i] < (u32)v[i];
@@ -814,7 +815,7 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
     // (2) RETR_EXTERNAL: a2[leader of an outer border] = CT_FRAME (external) | CT_INSIDE | the leader whose answer is also this one's
     if (mode == 0) {
 #pragma unroll
-        for (int i = 0; i < CTJ_ITEMS; i++) {
+        for (int i = 0; i < ITEMS; i++) {
             const u32 k = tid + 1024u * i;
             if (k >= H || (u32)v[i] != own[i] || (own[i] & 1u)) continue;
             const u32 e = a2[k];
@@ -834,7 +835,7 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
         for (int round = 0; round < CT_JUMP_ROUNDS; round++) {
             int changed = 0;
 #pragma unroll
-            for (int i = 0; i < CTJ_ITEMS; i++) {
+            for (int i = 0; i < ITEMS; i++) {
                 const u32 k = tid + 1024u * i;
                 if (k >= H || (u32)v[i] != own[i] || (own[i] & 1u)) continue;
                 const u32 e = a2[k];
@@ -880,9 +881,9 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
     CT_STAMP();
     // head order = scan order of the words; inside a word the heads are listed by type, so there the keys decide.  (a key says where
     // its crack is: no look at the head list)
-    u32 rk[CTJ_ITEMS];
+    u32 rk[ITEMS];
 #pragma unroll
-    for (int i = 0; i < CTJ_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const u32 k = tid + 1024u * i;
         rk[i] = CT_NONE;
         if (k >= H || (u32)v[i] != own[i]) continue;
@@ -906,7 +907,7 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
     CT_STAMP();
     // marks (k_ct_seg<true> asks for the marks of leaders only)
 #pragma unroll
-    for (int i = 0; i < CTJ_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const u32 k = tid + 1024u * i;
         if (k >= H) continue;
         a1[k] = rk[i];
@@ -916,7 +917,7 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
     CT_STAMP();
     // (4) distances
 #pragma unroll
-    for (int i = 0; i < CTJ_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const u32 k = tid + 1024u * i;
         v[i] = (unsigned long long)CT_TERM << 32;
         if (k < H) {
@@ -929,12 +930,12 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
     for (int round = 0; round < max_rounds; round++) {
         int waiting = 0;                                  // some head of this thread has not reached its leader yet
         for (int hop = 0; hop < CTJ_HOPS; hop++) {
-            unsigned long long v2[CTJ_ITEMS];
+            unsigned long long v2[ITEMS];
 #pragma unroll
-            for (int i = 0; i < CTJ_ITEMS; i++) { const u32 J = (u32)(v[i] >> 32); v2[i] = (J & CT_TERM) ? 0ull : tab[J]; }
+            for (int i = 0; i < ITEMS; i++) { const u32 J = (u32)(v[i] >> 32); v2[i] = (J & CT_TERM) ? 0ull : tab[J]; }
             waiting = 0;
 #pragma unroll
-            for (int i = 0; i < CTJ_ITEMS; i++) {
+            for (int i = 0; i < ITEMS; i++) {
                 const u32 k = tid + 1024u * i;
                 if (!((u32)(v[i] >> 32) & CT_TERM)) {
                     v[i] = (v2[i] & HI) | (u32)((u32)v[i] + (u32)v2[i]);
@@ -950,7 +951,7 @@ __device__ __forceinline__ void ctj_body_lds(const ctj_args& A, int f, u32 H, un
     }
     CT_STAMP();
 #pragma unroll
-    for (int i = 0; i < CTJ_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const u32 k = tid + 1024u * i;
         if (k < H) nd[k] = v[i];
     }
@@ -973,7 +974,19 @@ __global__ __launch_bounds__(1024) void k_ct_jump(ctj_args A)
     if (A.nheads_out && threadIdx.x == 0) A.nheads_out[f] = H;
     if (A.mirror.info && threadIdx.x == 0) A.mirror.info[2] = (int32_t)H;
     if (H <= (u32)CTJ_LDS_HEADS)
-        ctj_body_lds(A, f, H, ctj_dyn, reinterpret_cast<u32*>(ctj_dyn + CTJ_LDS_HEADS), reinterpret_cast<u32*>(ctj_dyn + CTJ_LDS_HEADS) + CTJ_LDS_HEADS);
+    {
+        // (every thread takes ceil(H / 1024) heads through a jump together; the loops over them are unrolled, and what a small frame does
+        // not need would still be issued: an instantiation per count - a module's mask has 1,400-2,800 heads)
+        unsigned long long* tab = ctj_dyn;
+        u32* a1 = reinterpret_cast<u32*>(ctj_dyn + CTJ_LDS_HEADS);
+        u32* a2 = a1 + CTJ_LDS_HEADS;
+        if (H <= 1024u) ctj_body_lds<1>(A, f, H, tab, a1, a2);
+        else if (H <= 2048u) ctj_body_lds<2>(A, f, H, tab, a1, a2);
+        else if (H <= 3072u) ctj_body_lds<3>(A, f, H, tab, a1, a2);
+        else if (H <= 4096u) ctj_body_lds<4>(A, f, H, tab, a1, a2);
+        else if (H <= 6144u) ctj_body_lds<6>(A, f, H, tab, a1, a2);
+        else ctj_body_lds<CTJ_ITEMS>(A, f, H, tab, a1, a2);
+    }
     else
         ctj_body<false>(A.G, ctj_make_frame(A, f, A.node2 + (size_t)f * A.hcap), nullptr, nullptr, A.node, A.hcap, A.starts, A.shead, A.counts, A.is_hole,
                         A.offsets, A.points, A.out, A.max_contours, A.max_points, A.mode, A.mirror);
