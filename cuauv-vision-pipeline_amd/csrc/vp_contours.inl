@@ -1247,11 +1247,10 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     if (!hmaps || !hbase || !cnt8 || !head_pix || !A.hrank || !hkey || !A.hext || !A.node || !A.node2 || !A.starts || !A.shead || !A.aux || !partsum ||
         !A.flags || !A.csum)
         return vp_fail(ctx, VP_ERR_NOMEM, "contour workspace");
-    static bool lds_set = false;
     const size_t jump_lds = (size_t)CTJ_LDS_HEADS * 16;
-    if (!lds_set) {
+    if (!ctx->ct_lds_set) {                               // (per context = per device: the attribute belongs to the device's copy of the kernel)
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ct_jump), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jump_lds));
-        lds_set = true;
+        ctx->ct_lds_set = 1;
     }
     A.hkey = hkey; A.hbase = hbase; A.cnt8 = cnt8; A.head_pix = head_pix; A.hcap = hcap;
     A.counts = d_counts; A.is_hole = d_is_hole; A.offsets = d_offsets; A.points = d_points;
@@ -1265,7 +1264,11 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     const dim3 wgrid((unsigned)((nwords + 255) / 256), (unsigned)n);
     // heads per frame are not known on the host: a fixed number of blocks per frame walks the head list (a real mask has a few
     // thousand heads; empty blocks of a grid sized for the worst case would cost more than the work)
-    const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, (size_t)std::max(32, std::min(1024, 8192 / n))), (unsigned)n);
+    // (one image: the head count of the context's last single-image pass sizes the grid - two items per head, half as much again -
+    // instead of a thousand blocks of which thirty find work; the loops stride over the grid, so a wrong guess only costs time)
+    size_t hblocks = (size_t)std::max(32, std::min(1024, 8192 / n));
+    if (n == 1 && ctx->ct_heads_hint) hblocks = std::min<size_t>(hblocks, std::max<size_t>(32, ((size_t)ctx->ct_heads_hint * 3 + 255) / 256));
+    const dim3 hgrid((unsigned)std::min<size_t>((hcap + 255) / 256, hblocks), (unsigned)n);
     if (many_heads) hipLaunchKernelGGL(k_ct_headmaps<true>, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
     else hipLaunchKernelGGL(k_ct_headmaps<false>, wgrid, dim3(256), 0, s, d_bits, G, hmaps, partsum, cnt8);
     hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &A.aux->nheads, 2, w, G.ww, head_pix, hcap, cnt8,

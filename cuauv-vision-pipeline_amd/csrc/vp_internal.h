@@ -44,6 +44,7 @@ struct vp_ctx {
     hipEvent_t ring_ev[4];
     int ring_busy[4];
     int ring_next;
+    int ct_lds_set;               // k_ct_jump's LDS attribute has been set on this context's device
     uint32_t* ct_hint_host;       // pinned: head counts of the last batched contour pass (vp_contours.inl vp_ct_hint_slots)
     int ct_hint_n;
     uint32_t ct_heads_hint;   // border segments the last single-image contour pass counted (vp_find_contours_*: which form of the bookkeeping to launch)
