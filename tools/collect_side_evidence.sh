@@ -17,6 +17,9 @@ VP_DMA_POSTS=0 python3 tools/exp_posts.py 2> /dev/null | python3 -c "import sys;
 python3 tools/exp_postcost.py 2>&1 | grep -v "^\[\|amdgpu.ids" > $out/${tag}_postcost.txt
 python3 tools/exp_contours_single.py 200 2> /dev/null | tail -1 > $out/${tag}_contours_single.json
 python3 tools/exp_opkernels.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_opkernels.txt
+python3 tools/exp_bits_cache.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_bits_cache.txt
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $out/kt -o kt -- python3 $root/tools/exp_bits_cache.py > /dev/null 2>&1)
+python3 tools/kernel_medians.py $(find $out/kt -name '*kernel_trace.csv' | head -1) > $out/${tag}_contour_kernel_medians.txt 2>&1; rm -rf $out/kt
 python3 tools/exp_hostfed.py 1080p > $out/${tag}_hostfed.txt 2>&1
 python3 tools/exp_hostfed.py 4k >> $out/${tag}_hostfed.txt 2>&1
 for m in buoy bins gate; do python3 tools/exp_runtime.py 4 $m 2>&1 | tail -1; done > $out/${tag}_runtime.txt
