@@ -152,3 +152,54 @@ def test_statement_on_random_masks(oracle):
             assert _same(got, exp) and np.array_equal(gh, eh), (trial, mode, method, m.tolist())
             n += len(exp)
     assert n > 2000
+
+
+@pytest.mark.parametrize("row_mask,col_mask", [(1, 3), (3, 7)])
+def test_head_bitmaps_agree_with_the_follower(row_mask, col_mask):
+    """The GPU pass cuts borders at "heads": states that sweep an eligible crack (N / S in cut columns, W / E in cut rows and wherever
+    a border could start).  Two pieces of code must name the same heads: k_ct_headmaps, which writes them down per crack with bit
+    operations on whole words (a crack is a head iff, going clockwise from it towards its state's direction, no other eligible crack
+    comes first), and ct_head_type, which a walker asks per state (the first eligible crack the state sweeps).  Restated here for both
+    cut spacings (csrc/vp_contours.inl ct_cut) and compared on random masks."""
+    rng = np.random.default_rng(77)
+    for trial in range(120):
+        h, w = int(rng.integers(1, 12)), int(rng.integers(1, 20))
+        mask = rng.random((h, w)) < rng.choice([0.2, 0.5, 0.8])
+        m = np.pad(mask, 1)
+
+        def ring(y, x):
+            return [bool(m[y + 1 + DY[d], x + 1 + DX[d]]) for d in range(8)]
+        for y in range(h):
+            for x in range(w):
+                if not mask[y, x]:
+                    continue
+                n = ring(y, x)
+                if not any(n):
+                    continue
+                rowel, el = (y & row_mask) == 0, (x & col_mask) == 0
+                elw = rowel or not (n[1] or n[2] or n[3])
+                ele = rowel or n[1]
+                # k_ct_headmaps, bit for bit
+                hw = (not n[4]) and elw and (n[3] or n[2] or ((not el) and (n[1] or n[0] or ((not ele) and (n[7] or n[6] or n[5])))))
+                he = (not n[0]) and ele and (n[7] or n[6] or ((not el) and (n[5] or n[4] or ((not elw) and (n[3] or n[2] or n[1])))))
+                hn = (not n[2]) and el and (n[1] or n[0] or ((not ele) and (n[7] or n[6])))
+                hs = (not n[6]) and el and (n[5] or n[4] or ((not elw) and (n[3] or n[2])))
+                by_map = {c for c, on in ((4, hw), (0, he), (2, hn), (6, hs)) if on}
+                # ct_head_type over the states of this pixel that sweep a crack
+                by_state = set()
+                for c in (0, 2, 4, 6):
+                    if n[c]:
+                        continue
+                    s = next((c - i) % 8 for i in range(1, 8) if n[(c - i) % 8])      # the state that sweeps crack c
+                    t = 0
+                    while not n[(s + 1 + t) % 8]:
+                        t += 1
+                    first = None
+                    for i in range(t):                                              # first eligible crack of the sweep
+                        d = (s + 1 + i) % 8
+                        if (d == 4 and elw) or (d == 0 and ele) or (d in (2, 6) and el):
+                            first = d
+                            break
+                    if first is not None:
+                        by_state.add(first)
+                assert by_map == by_state, (trial, y, x, n, by_map, by_state)
