@@ -1290,19 +1290,32 @@ static int find_contours_impl(vp_ctx* ctx, const uint8_t* src, bool src_on_devic
     hm.is_hole = reinterpret_cast<uint8_t*>(hm.offsets + mc);
     hm.points = spec_pts ? reinterpret_cast<int32_t*>(hs + hdr_pad) : nullptr;
     hm.points_cap = (long long)spec_pts;
-    VP_TRY(vpk_find_contours(ctx, bits_use, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info, many,
-                             reinterpret_cast<uint32_t*>(d_info + 2), mirror_off ? nullptr : &hm));
-    if (mirror_off) {
-        if (spec_pts && reinterpret_cast<uint8_t*>(d_points) == d_hdr + hdr_pad) {
-            VP_TRY(d2h(ctx, hs, d_hdr, hdr_pad + spec_pts * 8));           // header and points lie back to back in the workspace: one copy
-        } else {
-            VP_TRY(d2h(ctx, hs, d_hdr, hdr_bytes));
-            if (spec_pts) VP_TRY(d2h(ctx, hs + hdr_pad, d_points, spec_pts * 8));
+    // One block only up to what its LDS tables hold: a mask that turns out to have more heads than that while none was expected says so
+    // in place of a result (0.1 ms), and the pass is repeated as launches - instead of one block working through 600 k heads in global
+    // memory (9 ms at 10 % noise).  Not when a form is forced.
+    bool many_now = many;
+    const size_t ws_mark = ctx->ws_off;
+    const int32_t* info = nullptr;
+    for (;;) {
+        const bool defer = !many_now && many_env < 0;
+        ctx->ws_off = ws_mark;
+        VP_TRY(vpk_find_contours(ctx, bits_use, w, h, 1, mode, method, d_counts, d_hole, d_offsets, d_points, mc, mp, d_info, many_now,
+                                 reinterpret_cast<uint32_t*>(d_info + 2), mirror_off ? nullptr : &hm, defer));
+        if (mirror_off) {
+            if (spec_pts && reinterpret_cast<uint8_t*>(d_points) == d_hdr + hdr_pad) {
+                VP_TRY(d2h(ctx, hs, d_hdr, hdr_pad + spec_pts * 8));           // header and points lie back to back in the workspace: one copy
+            } else {
+                VP_TRY(d2h(ctx, hs, d_hdr, hdr_bytes));
+                if (spec_pts) VP_TRY(d2h(ctx, hs + hdr_pad, d_points, spec_pts * 8));
+            }
         }
+        VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        info = reinterpret_cast<const int32_t*>(hs);
+        ctx->ct_heads_hint = (uint32_t)info[2];
+        if (info[0] != -1 || many_now) break;
+        many_now = true;
     }
-    VP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int32_t* info = reinterpret_cast<const int32_t*>(hs);
-    ctx->ct_heads_hint = (uint32_t)info[2];
+    if (info[0] < 0) return vp_fail(ctx, VP_ERR_HIP, "contours: no result");
     const int K = info[0];
     const int64_t P = info[1];
     *n_contours = K;

@@ -700,6 +700,7 @@ struct ctj_args {
     long long max_points;
     int mode;
     u32 lds_heads;
+    int defer_big;               // a frame with more heads than the LDS tables hold: report -1 contours instead of working in global memory
     u32* nheads_out;             // nullable: the frame's head count, for the caller's next call (vpk_find_contours `many_heads`)
     ct_mirror mirror;            // single image: the results written a second time, into the caller's pinned buffer
     u32 *flags, *csum;           // k_ctm_* only: per frame CTM_NFLAGS round flags; partial sums of the two scans
@@ -973,6 +974,13 @@ __global__ __launch_bounds__(1024) void k_ct_jump(ctj_args A)
     const u32 H = A.aux[f].nheads;
     if (A.nheads_out && threadIdx.x == 0) A.nheads_out[f] = H;
     if (A.mirror.info && threadIdx.x == 0) A.mirror.info[2] = (int32_t)H;
+    if (H > (u32)CTJ_LDS_HEADS && A.defer_big) {          // the caller repeats the pass in the launches form (k_ct_seg<true> finds no leader marks: writes nothing)
+        if (threadIdx.x == 0) {
+            A.out[f].n_contours = -1; A.out[f].n_points = 0;
+            if (A.mirror.info) { A.mirror.info[0] = -1; A.mirror.info[1] = 0; }
+        }
+        return;
+    }
     if (H <= (u32)CTJ_LDS_HEADS)
     {
         // (every thread takes ceil(H / 1024) heads through a jump together; the loops over them are unrolled, and what a small frame does
@@ -1217,7 +1225,7 @@ uint32_t vp_ct_batch_hint(vp_ctx* ctx)
 // d_nheads_out (nullable, [n]): the frames' head counts.
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, bool many_heads,
-                      uint32_t* d_nheads_out, const vp_contour_mirror* host)
+                      uint32_t* d_nheads_out, const vp_contour_mirror* host, bool defer_big)
 {
     if (mode != 0 && mode != 1) return vp_fail(ctx, VP_ERR_INVALID, "contour mode");
     if (method != 1 && method != 2) return vp_fail(ctx, VP_ERR_INVALID, "contour approximation");
@@ -1257,6 +1265,7 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     A.out = reinterpret_cast<ct_frame_out*>(d_info);
     A.max_contours = max_contours; A.max_points = max_points; A.mode = mode; A.lds_heads = CTJ_LDS_HEADS; A.nheads_out = d_nheads_out;
     A.hops = 3;
+    A.defer_big = (defer_big && n == 1 && !many_heads) ? 1 : 0;
     A.mirror = ct_mirror{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (host && n == 1) A.mirror = ct_mirror{host->info, host->counts, host->offsets, host->is_hole, host->points, host->points_cap};
     hipStream_t s = ctx->stream;

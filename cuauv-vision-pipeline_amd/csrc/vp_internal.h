@@ -207,11 +207,13 @@ int vpk_contour_features(vp_ctx* ctx, const int32_t* d_info, const int32_t* d_co
 // segments (its last pass said so through d_nheads_out) - a choice between two forms of the same steps, not of the result.
 // host (n == 1 only): pinned, device-visible buffers the producing kernels write the results into as well - info {n_contours,
 // n_points, heads}, counts / offsets / is_hole [max_contours], the first points_cap points - so that the caller only synchronises.
+// defer_big (n == 1, not many_heads): a frame with more heads than the one block's LDS tables hold reports n_contours = -1 and nothing
+// else; the caller repeats the pass with many_heads.
 uint32_t vp_ct_batch_hint(vp_ctx* ctx);      // largest head count the last batched pass reported (a guess; no synchronisation)
 struct vp_contour_mirror { int32_t* info; int32_t* counts; int32_t* offsets; uint8_t* is_hole; int32_t* points; long long points_cap; };
 int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int mode, int method, int32_t* d_counts, uint8_t* d_is_hole,
                       int32_t* d_offsets, int32_t* d_points, int max_contours, long long max_points, int32_t* d_info, bool many_heads = false,
-                      uint32_t* d_nheads_out = nullptr, const vp_contour_mirror* host = nullptr);
+                      uint32_t* d_nheads_out = nullptr, const vp_contour_mirror* host = nullptr, bool defer_big = false);
 int vpk_ccl(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int numbering, const vp_ccl_ws& ws, int32_t* d_labels,
             int32_t* d_stats, double* d_centroids, int max_labels, int32_t* d_nlabels);
 

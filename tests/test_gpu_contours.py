@@ -574,3 +574,21 @@ def test_batch_with_speckled_frames_takes_either_form(vp, oracle, monkeypatch):
     run()
     run()                                            # by now the hint of the call before has arrived
     assert vp.lib().vp_contours_last_heads(ctx.handle) > 8192
+
+
+def test_unexpected_speckle_is_repeated_as_launches(vp, oracle, monkeypatch):
+    """A single-image call whose mask turns out to hold more border segments than the one block's LDS tables (no such frame was
+    expected: the call before saw a clean mask) is answered by "too many" in place of a result and repeated in the launches form inside
+    the same call - same contours as the oracle; the call after it starts in the launches form, and a clean mask brings the block back."""
+    from vision.utils import feature
+    monkeypatch.delenv("VP_CT_MANY")
+    ctx = vp.default_context()
+    rng = np.random.default_rng(41)
+    clean = np.zeros((360, 640), np.uint8)
+    clean[100:200, 200:400] = 255
+    noise = F.random_mask(rng, 360, 640, 0.3)
+    for m in (clean, noise, noise, clean, clean, noise):
+        for mode in (0, 1):
+            _check(vp, oracle, m, mode, 2)
+        if m is noise:                              # (the diagnostic also remembers the last batched pass: nothing to assert for a clean mask)
+            assert vp.lib().vp_contours_last_heads(ctx.handle) > 8192

@@ -49,6 +49,19 @@ def measure(calls=200):
             call()
         dn = (time.perf_counter() - t0) / n
         out[name] = {"ms_per_call": round(1e3 * dt, 4), "ms_native_call": round(1e3 * dn, 4), "contours": len(cs), "points": npts, "calls": n}
+    # the first call on a speckled mask after calls on clean ones (the pass is chosen by the last call's head count: this one is
+    # answered "too many heads" by the one block and repeated as launches inside the call)
+    clean, speck = DeviceMat.from_host(ctx, np.ascontiguousarray(np.asarray(masks[1][1])), binary=True), DeviceMat.from_host(
+        ctx, np.ascontiguousarray(np.asarray(masks[3][1])), binary=True)
+    feature.outer_contours(speck)
+    first = []
+    for _ in range(5):
+        for _ in range(3):
+            feature.outer_contours(clean)
+        t0 = time.perf_counter()
+        feature.outer_contours(speck)
+        first.append(time.perf_counter() - t0)
+    out["s3_noise_10pct_first_after_clean"] = {"ms_per_call": round(1e3 * float(np.median(first)), 4), "calls": len(first)}
     return out
 
 
