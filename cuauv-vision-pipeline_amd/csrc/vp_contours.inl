@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
                                                 const ct_aux* __restrict__ aux, unsigned long long* __restrict__ node, u32* __restrict__ hkey,
                                                 u32* __restrict__ hext, int mode, int method, const int32_t* __restrict__ offsets,
                                                 int32_t* __restrict__ points, int max_contours, long long max_points, int32_t* __restrict__ h_points,
-                                                long long h_cap)
+                                                long long h_cap, u32 skip_above)
 {
     const int f = blockIdx.y;
     const int nwords = G.h * G.ww;
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void k_ct_seg(const u64* __restrict__ bits, cc
     const u32* hr = hrank + (size_t)f * hcap;
     unsigned long long* nd = node + (size_t)f * hcap;
     const u32 H = aux[f].nheads;
+    if (skip_above && H > skip_above) return;            // (the caller will repeat the pass in the other form: nothing of this one is kept)
     // !WRITE: two threads per head, in different blocks: one follows the segment, one works out the key and the look to the left (a
     // chain of dependent loads as long as a short walk: behind the walk in the same thread it was a third of this kernel)
     const u32 Hp = (H + 255u) & ~255u;
@@ -1283,8 +1284,9 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
     hipLaunchKernelGGL(k_ct_prefix, wgrid, dim3(256), 0, s, hmaps, 4, nwords, partsum, hbase, &A.aux->nheads, 2, w, G.ww, head_pix, hcap, cnt8,
                        (n > 1 || !host) ? vp_ct_hint_slots(ctx, n) : nullptr);
 #define CT_SEG_ARGS d_bits, G, hmaps, hbase, head_pix, A.hrank, hcap, A.aux, A.node, hkey, A.hext, mode, method, d_offsets, d_points, max_contours, max_points
-    if (many_heads) hipLaunchKernelGGL((k_ct_seg<false, true>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, (int32_t*)nullptr, 0ll);
-    else hipLaunchKernelGGL((k_ct_seg<false, false>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, (int32_t*)nullptr, 0ll);
+    const u32 skip_above = A.defer_big ? (u32)CTJ_LDS_HEADS : 0u;
+    if (many_heads) hipLaunchKernelGGL((k_ct_seg<false, true>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, (int32_t*)nullptr, 0ll, skip_above);
+    else hipLaunchKernelGGL((k_ct_seg<false, false>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, (int32_t*)nullptr, 0ll, skip_above);
     if (!many_heads) {
         hipLaunchKernelGGL(k_ct_jump, dim3((unsigned)n), dim3(1024), jump_lds, s, A);
     } else {
@@ -1308,8 +1310,8 @@ int vpk_find_contours(vp_ctx* ctx, const u64* d_bits, int w, int h, int n, int m
         hipLaunchKernelGGL((k_ctm_sums<1>), sg, dim3(1024), 0, s, A);
         hipLaunchKernelGGL((k_ctm_scan<1>), sg, dim3(1024), 0, s, A);
     }
-    if (many_heads) hipLaunchKernelGGL((k_ct_seg<true, true>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, A.mirror.points, A.mirror.cap);
-    else hipLaunchKernelGGL((k_ct_seg<true, false>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, A.mirror.points, A.mirror.cap);
+    if (many_heads) hipLaunchKernelGGL((k_ct_seg<true, true>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, A.mirror.points, A.mirror.cap, skip_above);
+    else hipLaunchKernelGGL((k_ct_seg<true, false>), hgrid, dim3(256), 0, s, CT_SEG_ARGS, A.mirror.points, A.mirror.cap, skip_above);
 #undef CT_SEG_ARGS
     VP_HIP(ctx, hipGetLastError());
     return VP_OK;
