@@ -198,7 +198,7 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
         h, w = mat.shape
     # capacities that served the last call of this size: a mask with more contours than the first guess (speckle: modules/red_buoy.py:38
     # runs on the un-cleaned mask) would otherwise be traced twice at every call, once to learn the sizes and once to keep the result
-    max_c, max_p = _capacity.get((h, w), (256, 1 << 14))
+    max_c, max_p, ttl = _capacity.get((h, w), (256, 1 << 14, 0))
     while True:
         pts = np.empty((max_p, 2), np.int32)
         counts = np.empty(max_c, np.int32)
@@ -221,7 +221,9 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
         max_p = max(max_p, 2 * npts.value)
     k = nc.value
     if k > 256 or npts.value > (1 << 14):
-        _capacity[(h, w)] = (max(256, k + k // 2), max(1 << 14, npts.value + npts.value // 2))     # follows the masks up and down
+        _capacity[(h, w)] = (max(256, k + k // 2), max(1 << 14, npts.value + npts.value // 2), 32)     # follows the masks up and down ...
+    elif ttl > 1:
+        _capacity[(h, w)] = (max_c, max_p, ttl - 1)    # ... down only after 32 small results in a row: speckle that comes and goes is not traced twice each time
     else:
         _capacity.pop((h, w), None)
     flat = pts[:npts.value].copy()                     # one block for all contours; the arrays handed out are views of it
@@ -239,7 +241,7 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
     return (out, holes[:k].copy()) if with_holes else out
 
 
-_capacity = {}            # (h, w) -> (contours, points) the result arrays of find_contours start with
+_capacity = {}            # (h, w) -> (contours, points, calls left before shrinking) the result arrays of find_contours start with
 
 
 class ContourList(tuple):
