@@ -299,7 +299,9 @@ def pinned_empty(ctx, shape, dtype):
 
 
 def ptr(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    """Address of a numpy array for a `void*` argument, as an int (`.ctypes.data_as(c_void_p)` costs 3 us a time, this 1; eight of them per
+    module call).  The caller keeps the array alive across the call - every call site passes a named local."""
+    return a.ctypes.data if a is not None else None
 
 
 def get_tables():
