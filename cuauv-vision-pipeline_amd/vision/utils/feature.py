@@ -200,9 +200,14 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
     # runs on the un-cleaned mask) would otherwise be traced twice at every call, once to learn the sizes and once to keep the result
     max_c, max_p, ttl = _capacity.get((h, w), (256, 1 << 14, 0))
     while True:
-        pts = np.empty((max_p, 2), np.int32)
-        counts = np.empty(max_c, np.int32)
-        holes = np.empty(max_c, np.uint8)
+        # result arrays of the C call: per thread, kept from call to call (what is handed out below are copies of the used parts)
+        sc = getattr(_scratch, "arrays", None)
+        if sc is None or sc[0] != (max_c, max_p):
+            pts = np.empty((max_p, 2), np.int32)
+            counts = np.empty(max_c, np.int32)
+            holes = np.empty(max_c, np.uint8)
+            sc = _scratch.arrays = ((max_c, max_p), pts, counts, holes)
+        _, pts, counts, holes = sc
         nc, npts = _vp.C.c_int32(0), _vp.C.c_int64(0)
         bits = getattr(dev, "_bits", None) if dev is not None else None
         if bits is not None and dev._dev_ok and dev._ctx is ctx:
@@ -242,6 +247,7 @@ def find_contours(mat: np.ndarray, mode: int = _vp.RETR_EXTERNAL, method: int = 
 
 
 _capacity = {}            # (h, w) -> (contours, points, calls left before shrinking) the result arrays of find_contours start with
+_scratch = threading.local()
 
 
 class ContourList(tuple):
